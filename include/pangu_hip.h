@@ -1,0 +1,121 @@
+/*
+ * pangu_hip.h — C ABI of the MI355X (gfx950) kernels behind the Pangu-Weather hot path.
+ *
+ * Drop-in boundary.  The reference (zhaoshan2/pangu-pytorch) has no native layer: its "operator API" for
+ * this path is the nn.Module surface of models/pangu_model.py:8-87 and the layer classes of
+ * models/layers.py.  This library sits UNDER that surface: each entry point replaces the ATen-op chain of
+ * one reference method (cited per function) and is what a ctypes/cffi binding on the reference side binds
+ * (see INTEGRATION.md).  Plain pointers and sizes only — no torch types.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless stated; tensors are dense row-major fp32 (dtype-tagged
+ *     variants take PANGU_F32 / PANGU_BF16 where noted);
+ *   - `stream` is a hipStream_t passed as void*; nothing allocates, synchronises or branches on device
+ *     data on the host => every call is hipGraph-capturable;
+ *   - return value: PANGU_OK (0), a negative PANGU_E_* for bad arguments (nothing launched), or a positive
+ *     hipError_t if the launch itself failed;
+ *   - token tensors are (N, C) with N = Z*H*W tokens in (z,h,w) order (reference layers.py:188,247),
+ *     row stride given explicitly as `ld*` (in elements) where a kernel supports strided rows.
+ */
+#ifndef PANGU_HIP_H
+#define PANGU_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PANGU_ABI_VERSION 1
+
+#define PANGU_OK 0
+#define PANGU_E_SHAPE (-1)     /* unsupported shape / divisibility */
+#define PANGU_E_NULL (-2)      /* required pointer is NULL */
+#define PANGU_E_DTYPE (-3)     /* unsupported dtype tag */
+#define PANGU_E_ARG (-4)       /* other invalid argument */
+
+#define PANGU_F32 0
+#define PANGU_BF16 1
+
+#define PANGU_ACT_NONE 0
+#define PANGU_ACT_GELU 1       /* exact erf GELU, reference layers.py:261 */
+
+typedef void* pangu_stream_t;  /* hipStream_t */
+
+int pangu_abi_version(void);
+const char* pangu_error_string(int code);
+
+/* ---- integer contract (bit-exact vs oracle) ------------------------------------------------------- */
+
+/* out[nLon][types][144] int32: source token of every window slot, -1 = zero pad.
+ * Replaces view/pad/roll/partition of EarthSpecificBlock.forward, reference layers.py:188-221. */
+int pangu_window_index_export(pangu_stream_t stream, int32_t* out, int Z, int H, int W, int shifted);
+
+/* out[types][144][144] fp32 in {0,-100}: shifted-window mask, reference layers.py:153-181 (gen_mask). */
+int pangu_window_mask_export(pangu_stream_t stream, float* out, int Z, int H, int W);
+
+/* ---- dense projections ---------------------------------------------------------------------------- */
+
+/* C[M,N] = act(A[M,K] @ W[N,K]^T + bias[N]).  W is the torch nn.Linear / Conv1d(k=1) weight as stored
+ * (out,in).  bias may be NULL.  K % 16 == 0.  Replaces nn.Linear / nn.Conv1d calls at reference
+ * layers.py:68,86,265-268,365,418,457,476,498,520,536. */
+int pangu_linear_fwd(pangu_stream_t stream, const float* A, int lda, const float* W, const float* bias,
+                     float* C, int ldc, int M, int N, int K, int act);
+
+/* ---- Earth-specific window attention -------------------------------------------------------------- */
+
+/* Fused roll + window partition + (q*scale)k^T + earth_specific_bias + shift mask + softmax + .v +
+ * window reverse + roll back + crop, one (window, head) per workgroup.
+ *   qkv  [N][3C]  linear1 output on the UNPADDED tokens (channel = which*C + head*32 + d, layers.py:368-371)
+ *   qkv_bias [3C] linear1.bias: the q/k/v of zero-pad tokens (layers.py:192 pads before linear1)
+ *   esb  [types][heads][144][144] earth_specific_bias (layers.py:306-311)
+ *   out  [N][C]   attention output before linear2 (channel = head*32 + d, layers.py:413-415)
+ *   lse  [N][heads] optional (may be NULL): log-sum-exp of each query row, saved for backward
+ * Replaces reference layers.py:192-247 + :368-415. */
+int pangu_window_attn_fwd(pangu_stream_t stream, const float* qkv, const float* qkv_bias, const float* esb,
+                          float* out, float* lse, int Z, int H, int W, int C, int heads, int shifted);
+
+/* ---- row kernels ----------------------------------------------------------------------------------- */
+
+/* out[r] = shortcut[r] + branch_scale * (LayerNorm(y[r]) * gamma + beta)
+ * (post-norm residual, reference layers.py:250-251; branch_scale = 1 in eval, the DropPath keep factor
+ * 1/(1-p) in training, timm DropPath semantics).  eps = 1e-5.  shortcut/out may have row strides != C
+ * (lds/ldo).  mean_rstd (may be NULL): [N][2] saved statistics for backward. */
+int pangu_ln_residual_fwd(pangu_stream_t stream, const float* y, const float* shortcut, int lds,
+                          const float* gamma, const float* beta, float* out, int ldo, float* mean_rstd,
+                          int N, int C, float branch_scale);
+
+/* DownSample gather + LayerNorm(4C): x[Z][H][W][C] (row stride ldx) -> out[Z*(H+1)/2*(W/2)][4C],
+ * channel = dh*2C + dw*C + c, zero row for h == H (pad).  Reference layers.py:436-454. */
+int pangu_downsample_ln_fwd(pangu_stream_t stream, const float* x, int ldx, const float* gamma,
+                            const float* beta, float* out, float* mean_rstd, int Z, int H, int W, int C);
+
+/* UpSample pixel-shuffle + crop + LayerNorm(Co): y[Z][H2][W2][4*Co] -> out[Z][H][2*W2][Co] with
+ * out[z][2h+dh][2w+dw][c] = y[z][h][w][dh*2Co + dw*Co + c], rows h >= H dropped.  Reference layers.py:480-495.
+ * pre (may be NULL): the shuffled rows before LayerNorm, saved for backward. */
+int pangu_upsample_ln_fwd(pangu_stream_t stream, const float* y, const float* gamma, const float* beta,
+                          float* out, float* mean_rstd, int Z, int H2, int W2, int H, int Co);
+
+/* ---- patch embedding / recovery --------------------------------------------------------------------- */
+
+/* Normalise + zero-pad + patchify the raw fields into GEMM A-matrices (reference layers.py:48-85):
+ *   a_surface [H4*W4][112]  col = c*16 + ph*4 + pw,  c<4: (input_surface-mean)/std, c in 4..6: maps
+ *   a_upper [7*H4*W4][192]  col = c*32 + pz*16 + ph*4 + pw, c<5: (input-mean_used)/std_used, c==5: const_h
+ * with mean_used[c][l] = upper_mean[12-l][c] (level-reversed statistics, layers.py:73-76).
+ * input [5][13][LAT][LON], input_surface [4][LAT][LON], maps [3][4*H4][LON], const_h [13][LAT][LON],
+ * surface_mean/std [4], upper_mean/std [13][5].  LAT=721, LON=1440 -> H4=181, W4=360. */
+int pangu_patch_embed_gather(pangu_stream_t stream, const float* input, const float* input_surface,
+                             const float* surface_mean, const float* surface_std, const float* upper_mean,
+                             const float* upper_std, const float* maps, const float* const_h,
+                             float* a_surface, float* a_upper, int LAT, int LON);
+
+/* Un-patchify + crop (reference layers.py:522-543):
+ *   y_upper [7*H4*W4][160] col = v*32 + pz*16 + ph*4 + pw -> output [5][13][LAT][LON]
+ *   y_surface [H4*W4][64]  col = v*16 + ph*4 + pw          -> output_surface [4][LAT][LON] */
+int pangu_patch_recover_scatter(pangu_stream_t stream, const float* y_upper, const float* y_surface,
+                                float* output, float* output_surface, int LAT, int LON);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PANGU_HIP_H */

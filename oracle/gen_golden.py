@@ -1,0 +1,214 @@
+"""Generate golden vectors by running the REFERENCE itself (build container only; needs /root/reference).
+
+TEST INFRASTRUCTURE. Usage:  python oracle/gen_golden.py [index] [blocks] [layers] [model] [model_bwd]
+Outputs small fixtures (fingerprints: samples + sums, index tensors, packed masks) under tests/golden/.
+Inputs and parameters are closed-form (oracle/synth.py), so tests regenerate them bit-identically.
+"""
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import cases   # noqa: E402
+import ref_import   # noqa: E402
+import synth   # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(os.cpu_count())
+
+
+def save(name, d):
+    np.savez_compressed(os.path.join(OUT, name), **{k: (v.numpy() if torch.is_tensor(v) else v) for k, v in d.items()})
+    print("wrote", name, len(d), "arrays")
+
+
+def load_params(module, prefix):
+    """Overwrite every parameter of a reference module with synthetic values keyed by prefix+local name."""
+    with torch.no_grad():
+        for k, p in module.named_parameters():
+            p.copy_(synth.synth_param(prefix + k, tuple(p.shape)))
+
+
+def gen_index(L, M):
+    out = {}
+    # position_index (layers.py:319-357)
+    att = L.EarthAttention3D(192, 6, 0, (2, 6, 12), device="cpu")
+    pi = att.position_index
+    assert pi.shape == (20736,) and int(pi.min()) == 0 and int(pi.max()) == 3311
+    out["position_index"] = pi.to(torch.int16)
+    meta = {"position_index_sha": hashlib.sha256(pi.numpy().astype(np.int64).tobytes()).hexdigest()[:16]}
+    for C in (192, 384):
+        st = cases.STAGES[C]
+        Z, H, W = st["Z"], st["H"], 24
+        blk = L.EarthSpecificBlock(C, 0.0, st["heads"], device="cpu")
+        # mask (layers.py:153-181) on the padded+rolled frame
+        x = torch.zeros(1, Z, H + 5, W, C)
+        mask = blk.gen_mask(x)                                # (nLon, types, 144, 144)
+        assert all(torch.equal(mask[0], mask[i]) for i in range(mask.shape[0]))
+        assert set(mask.unique().tolist()) <= {0.0, -100.0}
+        out[f"mask_bits_{C}"] = np.packbits((mask[0] != 0).numpy())
+        meta[f"mask_shape_{C}"] = list(mask[0].shape)
+        meta[f"mask_frac_{C}"] = float((mask[0] != 0).float().mean())
+        # window gather index: push token ids through the block with attention replaced by a recorder
+        N = Z * H * W
+        ids = (torch.arange(N, dtype=torch.float32) + 1).view(1, N, 1).expand(1, N, C).contiguous()
+        for roll in (False, True):
+            rec = {}
+
+            class Recorder(torch.nn.Module):
+                def forward(self, xw, mask):
+                    rec["xw"] = xw[..., 0].clone()
+                    return xw
+            blk.attention = Recorder()
+            blk.norm1, blk.norm2 = torch.nn.Identity(), torch.nn.Identity()
+            blk.linear = torch.nn.Identity()
+            y = blk(ids, Z, H, W, roll)
+            # with attention = identity the partition->reverse->crop round trip must be exact: y = x + (x + x)
+            assert torch.equal(y, ids * 4), "round trip not exact"
+            out[f"win_index_{C}_{int(roll)}"] = (rec["xw"].to(torch.int64) - 1).to(torch.int32)
+    save("index.npz", out)
+    with open(os.path.join(OUT, "index_meta.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
+def gen_blocks(L, M):
+    for C in (192, 384):
+        st = cases.STAGES[C]
+        Z, H, W = st["Z"], st["H"], 24
+        for roll in (False, True):
+            torch.manual_seed(0)
+            blk = L.EarthSpecificBlock(C, 0.1, st["heads"], device="cpu").eval()   # DropPath present, eval => identity
+            pre = cases.block_prefix(C, roll)
+            load_params(blk, pre)
+            x = cases.block_input(C, W).requires_grad_(True)
+            t = time.time()
+            y = blk(x, Z, H, W, roll)
+            tag = f"block_{C}_{int(roll)}"
+            d = cases.summarize(y, tag + ".out")
+            cot = cases.cotangent(tag, y.shape)
+            (y * cot).sum().backward()
+            d.update(cases.summarize(x.grad, tag + ".dx"))
+            for k, p in blk.named_parameters():
+                d.update(cases.summarize(p.grad, tag + ".d_" + k))
+            print(tag, "ref fwd+bwd %.1fs" % (time.time() - t))
+            save(tag + ".npz", d)
+
+
+def gen_layers(L, M):
+    d = {}
+    # ---- PatchEmbedding_pretrain (layers.py:12-93), full resolution only
+    inp, inp_s, stats, maps, const_h = cases.model_inputs()
+    pe = L.PatchEmbedding_pretrain((2, 4, 4), 192)
+    load_params(pe, "_input_layer.")
+    t = time.time()
+    x0 = pe(inp, inp_s, stats, maps, const_h)
+    print("embed ref %.1fs" % (time.time() - t), x0.shape)
+    d.update(cases.summarize(x0, "embed.out"))
+    cot = cases.cotangent("embed", x0.shape)
+    (x0 * cot).sum().backward()
+    for k, p in pe.named_parameters():
+        d.update(cases.summarize(p.grad, "embed.d_" + k))
+    del x0, cot
+    # ---- DownSample (layers.py:423-459)
+    ds = L.DownSample(192)
+    load_params(ds, "downsample.")
+    xin = synth.uniform((1, 8 * 181 * 360, 192), synth.name_seed("down_in")).requires_grad_(True)
+    y = ds(xin, 8, 181, 360)
+    d.update(cases.summarize(y, "down.out"))
+    (y * cases.cotangent("down", y.shape)).sum().backward()
+    d.update(cases.summarize(xin.grad, "down.dx"))
+    for k, p in ds.named_parameters():
+        d.update(cases.summarize(p.grad, "down.d_" + k))
+    # ---- UpSample (layers.py:461-499)
+    us = L.UpSample(384, 192)
+    load_params(us, "upsample.")
+    xin = synth.uniform((1, 8 * 91 * 180, 384), synth.name_seed("up_in")).requires_grad_(True)
+    y = us(xin)
+    d.update(cases.summarize(y, "up.out"))
+    (y * cases.cotangent("up", y.shape)).sum().backward()
+    d.update(cases.summarize(xin.grad, "up.dx"))
+    for k, p in us.named_parameters():
+        d.update(cases.summarize(p.grad, "up.d_" + k))
+    # ---- PatchRecovery_pretrain (layers.py:501-545)
+    pr = L.PatchRecovery_pretrain(384)
+    load_params(pr, "_output_layer.")
+    xin = synth.uniform((1, 8 * 181 * 360, 384), synth.name_seed("recover_in")).requires_grad_(True)
+    o, os_ = pr(xin, 8, 181, 360)
+    d.update(cases.summarize(o, "recover.out"))
+    d.update(cases.summarize(os_, "recover.out_surface"))
+    ((o * cases.cotangent("recover", o.shape)).sum() + (os_ * cases.cotangent("recover_s", os_.shape)).sum()).backward()
+    d.update(cases.summarize(xin.grad, "recover.dx"))
+    for k, p in pr.named_parameters():
+        d.update(cases.summarize(p.grad, "recover.d_" + k))
+    save("layers_fullres.npz", d)
+
+
+def build_model(M):
+    torch.manual_seed(0)
+    model = M.PanguModel(device="cpu")
+    shapes = {k: list(v.shape) for k, v in model.state_dict().items()}
+    with open(os.path.join(OUT, "keys_shapes.json"), "w") as f:
+        json.dump({"state_dict": shapes,
+                   "named_parameters_order": [k for k, _ in model.named_parameters()],
+                   "n_params": sum(p.numel() for p in model.parameters())}, f, indent=0)
+    # the reference's own key table (keys_all.csv column 1) must be the same set
+    import csv
+    with open(os.path.join(ref_import.REF_ROOT, "keys_all.csv")) as f:
+        csv_keys = [r["torch_name"] for r in csv.DictReader(f) if r["torch_name"]]
+    assert set(csv_keys) == set(shapes), "keys_all.csv != state_dict keys"
+    assert len(csv_keys) == 223
+    load_params(model, "")
+    return model
+
+
+def gen_model(L, M, backward):
+    model = build_model(M).eval()
+    inp, inp_s, stats, maps, const_h = cases.model_inputs()
+    d = {}
+    t = time.time()
+    if not backward:
+        with torch.no_grad():
+            out, out_s = model(inp, inp_s, stats, maps, const_h)
+        print("model fwd ref %.1fs" % (time.time() - t))
+        d.update(cases.summarize(out, "model.out"))
+        d.update(cases.summarize(out_s, "model.out_surface"))
+        save("model_fwd.npz", d)
+        return
+    # training-step body, models/pangu_sample.py:52-71 in eval mode (DropPath off), checkpointing as shipped
+    out, out_s = model(inp, inp_s, stats, maps, const_h)
+    tgt, tgt_s = cases.model_targets()
+    crit = torch.nn.L1Loss(reduction="none")
+    uw = torch.tensor([3.00, 0.60, 1.50, 0.77, 0.54]).view(1, 5, 1, 1, 1)      # config.py:45, utils_data.py:297-300
+    sw = torch.tensor([1.50, 0.77, 0.66, 3.00]).view(1, 4, 1, 1)
+    loss = torch.mean(crit(out, tgt) * uw) + torch.mean(crit(out_s, tgt_s) * sw) * 0.25
+    loss.backward()
+    print("model fwd+bwd ref %.1fs loss %.8f" % (time.time() - t, loss.item()))
+    d["model.loss"] = torch.tensor([loss.item()], dtype=torch.float64)
+    for k, p in model.named_parameters():
+        s = cases.summarize(p.grad, "model.d_" + k)
+        d[f"model.d_{k}.samples"] = s[f"model.d_{k}.samples"][:256]
+        d[f"model.d_{k}.abs_sum"] = s[f"model.d_{k}.abs_sum"]
+    save("model_bwd.npz", d)
+
+
+if __name__ == "__main__":
+    assert ref_import.available(), "reference not mounted"
+    L, M = ref_import.load()
+    what = sys.argv[1:] or ["index", "blocks", "layers", "model"]
+    if "index" in what:
+        gen_index(L, M)
+    if "blocks" in what:
+        gen_blocks(L, M)
+    if "layers" in what:
+        gen_layers(L, M)
+    if "model" in what:
+        gen_model(L, M, backward=False)
+    if "model_bwd" in what:
+        gen_model(L, M, backward=True)

@@ -1,0 +1,261 @@
+"""CPU oracle for the Pangu-Weather hot path — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A from-scratch restatement (torch-CPU fp32 tensor algebra + explicit integer index tensors) of the
+reference's forward pass, loss and — through torch autograd over this restatement — its gradients.
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this module;
+the product (`pangu-pytorch_amd/`) never does.
+
+Parity pinning: validated against golden vectors produced by importing the reference itself in the
+build container (`oracle/gen_golden.py` -> `tests/golden/*`), see `tests/test_oracle_golden.py`.
+
+Reference map (all file:line into /root/reference):
+  window_source_index   models/layers.py:188-221 (view/pad/roll/partition), :227-247 (reverse/roll-back/crop)
+  shift_mask            models/layers.py:153-181
+  position_index        models/layers.py:319-357
+  patch_embed           models/layers.py:40-93
+  earth_block           models/layers.py:183-253, attention :360-421, Mlp :264-270
+  down_sample           models/layers.py:432-459
+  up_sample             models/layers.py:474-499
+  patch_recover         models/layers.py:511-545
+  forward               models/pangu_model.py:50-87
+  train_loss            models/pangu_sample.py:57-67, era5_data/utils_data.py:315-321, era5_data/config.py:45-46
+
+Design differences from the reference (same maths): batch-generic (the reference is B=1 only); the
+pad/roll/partition/reverse/crop chain is ONE gather index; the mask is closed-form; attention is
+chunked over longitude windows to bound memory.
+"""
+import math
+import torch
+import torch.nn.functional as F
+
+WZ, WH, WW = 2, 6, 12           # window (layers.py:19,137)
+WTOK = WZ * WH * WW              # 144
+HEAD_DIM = 32
+PAD_H_BACK = 5                   # layers.py:145
+UPPER_WEIGHTS = (3.00, 0.60, 1.50, 0.77, 0.54)     # era5_data/config.py:45
+SURFACE_WEIGHTS = (1.50, 0.77, 0.66, 3.00)         # era5_data/config.py:46
+
+
+# ----------------------------------------------------------------------------------------------
+# integer index tensors (bit-exact contract)
+# ----------------------------------------------------------------------------------------------
+def window_geometry(Z, H, W):
+    Hp = H + PAD_H_BACK
+    assert Z % WZ == 0 and Hp % WH == 0 and W % WW == 0
+    return Hp, W // WW, Z // WZ, Hp // WH      # Hp, nLon, nZw, nHw
+
+
+def window_source_index(Z, H, W, shifted):
+    """int32 (nLon, types, 144): flat token index (z*H+h)*W+w feeding window slot (l,t,n); -1 = zero pad.
+
+    The attention result of slot (l,t,n) is written back to the same token (pad slots are dropped).
+    """
+    Hp, nLon, nZw, nHw = window_geometry(Z, H, W)
+    l = torch.arange(nLon).view(-1, 1, 1)
+    t = torch.arange(nZw * nHw).view(1, -1, 1)
+    n = torch.arange(WTOK).view(1, 1, -1)
+    zwin, hwin = t // nHw, t % nHw
+    zi, hi, wi = n // (WH * WW), (n // WW) % WH, n % WW
+    zf, hf, wf = WZ * zwin + zi, WH * hwin + hi, WW * l + wi
+    if shifted:   # torch.roll(shifts=(-1,-3,-6)) on the PADDED tensor, layers.py:201
+        z, h, w = (zf + WZ // 2) % Z, (hf + WH // 2) % Hp, (wf + WW // 2) % W
+    else:
+        z, h, w = zf + 0 * l, hf + 0 * l, wf + 0 * t
+    idx = (z * H + h) * W + w
+    idx = torch.where(h >= H, torch.full_like(idx, -1), idx)
+    return idx.expand(nLon, nZw * nHw, WTOK).contiguous().to(torch.int32)
+
+
+def shift_mask(Z, H, W):
+    """float32 (types,144,144) in {0,-100}; identical for every longitude window (layers.py:153-181)."""
+    Hp, nLon, nZw, nHw = window_geometry(Z, H, W)
+    t = torch.arange(nZw * nHw).view(-1, 1, 1)
+    ni = torch.arange(WTOK).view(1, -1, 1)
+    nj = torch.arange(WTOK).view(1, 1, -1)
+    zwin, hwin = t // nHw, t % nHw
+    zi_i, zi_j = ni // 72, nj // 72
+    hi_i, hi_j = (ni // 12) % 6, (nj // 12) % 6
+    cut = ((zwin == nZw - 1) & (zi_i != zi_j)) | ((hwin == nHw - 1) & ((hi_i < 3) != (hi_j < 3)))
+    return torch.where(cut, torch.tensor(-100.0), torch.tensor(0.0))
+
+
+def shift_mask_region_ids(Z, H, W):
+    """The same mask derived the long way (region-id image -> partition -> pairwise difference)."""
+    Hp, nLon, nZw, nHw = window_geometry(Z, H, W)
+    img = torch.zeros(Z, Hp, W)
+    zs = (slice(0, -WZ), slice(-WZ, -WZ // 2), slice(-WZ // 2, None))
+    hs = (slice(0, -WH), slice(WH, -WH // 2), slice(-WH // 2, None))     # sic: +WH start, layers.py:163
+    cnt = 0
+    for z in zs:
+        for h in hs:
+            img[z, h, :] = cnt
+            cnt += 1
+    ids = img.view(nZw, WZ, nHw, WH, nLon, WW).permute(4, 0, 2, 1, 3, 5).reshape(nLon, nZw * nHw, WTOK)
+    d = ids.unsqueeze(2) - ids.unsqueeze(3)
+    return torch.where(d != 0, torch.tensor(-100.0), torch.tensor(0.0))   # (nLon,types,144,144)
+
+
+def position_index():
+    """int64 (20736,) in [0,3312): compact Earth-specific-bias index (layers.py:319-357; unused by forward)."""
+    n = torch.arange(WTOK)
+    zi, hi, wi = n // 72, (n // 12) % 6, n % 12
+    dz = zi.view(-1, 1) + zi.view(1, -1) * WZ
+    dh = hi.view(-1, 1) + hi.view(1, -1) * WH
+    dw = wi.view(-1, 1) - wi.view(1, -1) + (WW - 1)
+    return (dz * (2 * WW - 1) * WH * WH + dh * (2 * WW - 1) + dw).flatten()
+
+
+# ----------------------------------------------------------------------------------------------
+# floating-point path
+# ----------------------------------------------------------------------------------------------
+def patch_embed_matrices(inp, inp_surface, statistics, maps, const_h):
+    """The two patchified GEMM operands: (B, H4*W4, 112) surface and (B, 7*H4*W4, 192) upper-air."""
+    s_mean, s_std, u_mean, u_std = statistics
+    B = inp.shape[0]
+    Hh, Ww = inp.shape[-2], inp.shape[-1]
+    H4, W4 = (Hh + 3) // 4, Ww // 4
+    # surface: normalise, pad bottom by 3, append the 3 constant maps, 4x4 patches
+    s = (inp_surface - s_mean.view(1, -1, 1, 1)) / s_std.view(1, -1, 1, 1)
+    s = F.pad(s, (0, 0, 0, 3))
+    s = torch.cat((s, maps.expand(B, -1, -1, -1)), dim=1)                      # (B,7,724,1440)
+    a_s = s.view(B, 7, H4, 4, W4, 4).permute(0, 2, 4, 1, 3, 5).reshape(B, H4 * W4, 112)
+    # upper: statistics are stored level-reversed (layers.py:73-76)
+    um = u_mean.reshape(13, 5).flip(0).t().reshape(1, 5, 13, 1, 1)
+    us = u_std.reshape(13, 5).flip(0).t().reshape(1, 5, 13, 1, 1)
+    u = (inp - um) / us
+    u = torch.cat((u, const_h.reshape(1, 1, 13, Hh, Ww).expand(B, -1, -1, -1, -1)), dim=1)   # (B,6,13,721,1440)
+    u = F.pad(u, (0, 0, 0, 3, 0, 1))                                            # (B,6,14,724,1440)
+    a_u = u.view(B, 6, 7, 2, H4, 4, W4, 4).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B, 7 * H4 * W4, 192)
+    return a_s, a_u
+
+
+def patch_embed(p, inp, inp_surface, statistics, maps, const_h):
+    """-> (B, 8*181*360, 192) tokens in (z,h,w) order. p: dict with _input_layer.* keys."""
+    a_s, a_u = patch_embed_matrices(inp, inp_surface, statistics, maps, const_h)
+    tok_s = a_s @ p["_input_layer.conv_surface.weight"][:, :, 0].t() + p["_input_layer.conv_surface.bias"]
+    tok_u = a_u @ p["_input_layer.conv.weight"][:, :, 0].t() + p["_input_layer.conv.bias"]
+    return torch.cat((tok_s, tok_u), dim=1)
+
+
+def window_attention_core(qkv, b1, bias, Z, H, W, heads, shifted, lon_chunk=4):
+    """qkv (B,N,3C) = linear1 on the unpadded tokens; zero-pad slots take q/k/v = b1 (linear1 of a zero row).
+    Returns the attention output before linear2, (B,N,C), and the per-(token, head) log-sum-exp (B,N,heads)."""
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    idx = window_source_index(Z, H, W, shifted).long()
+    nLon, types, _ = idx.shape
+    gidx = torch.where(idx < 0, torch.full_like(idx, N), idx)            # pad -> extra row holding b1
+    qp = torch.cat((qkv, b1.view(1, 1, C3).expand(B, 1, C3)), dim=1)
+    outp = qkv.new_zeros(B, N + 1, C)
+    lsep = qkv.new_zeros(B, N + 1, heads)
+    mask = shift_mask(Z, H, W) if shifted else None
+    scale = HEAD_DIM ** -0.5
+    bi = torch.arange(B).view(B, 1, 1, 1)
+    for l0 in range(0, nLon, lon_chunk):
+        gi = gidx[l0:l0 + lon_chunk]                                     # (lc,types,144)
+        w = qp[:, gi].view(B, gi.shape[0], types, WTOK, 3, heads, HEAD_DIM).permute(4, 0, 1, 2, 5, 3, 6)
+        q, k, v = w[0] * scale, w[1], w[2]                               # (B,lc,types,heads,144,32)
+        s = q @ k.transpose(-2, -1) + bias[0].unsqueeze(0).unsqueeze(0)
+        if mask is not None:
+            s = s + mask.view(1, 1, types, 1, WTOK, WTOK)
+        o = torch.softmax(s, dim=-1) @ v                                 # (B,lc,types,heads,144,32)
+        o = o.permute(0, 1, 2, 4, 3, 5).reshape(B, gi.shape[0], types, WTOK, C)
+        outp = outp.index_put((bi, gi.unsqueeze(0)), o)
+        lsep = lsep.index_put((bi, gi.unsqueeze(0)), torch.logsumexp(s, dim=-1).permute(0, 1, 2, 4, 3))
+    return outp[:, :N], lsep[:, :N]
+
+
+def window_attention(x, w1, b1, w2, b2, bias, Z, H, W, heads, shifted, lon_chunk=4):
+    """x (B,N,C) -> attention branch output (B,N,C) (before norm1). bias: (1,types,heads,144,144).
+    linear1/linear2 are per-token, so they commute with the window gather/scatter."""
+    o, _ = window_attention_core(x @ w1.t() + b1, b1, bias, Z, H, W, heads, shifted, lon_chunk)
+    return o @ w2.t() + b2
+
+
+def mlp(x, w1, b1, w2, b2):
+    return F.gelu(x @ w1.t() + b1) @ w2.t() + b2          # exact-erf GELU (layers.py:261)
+
+
+def earth_block(p, prefix, x, Z, H, W, heads, shifted):
+    C = x.shape[-1]
+    g = lambda k: p[prefix + k]
+    a = window_attention(x, g("attention.linear1.weight"), g("attention.linear1.bias"),
+                         g("attention.linear2.weight"), g("attention.linear2.bias"),
+                         g("attention.earth_specific_bias"), Z, H, W, heads, shifted)
+    x = x + F.layer_norm(a, (C,), g("norm1.weight"), g("norm1.bias"))            # post-norm, layers.py:250
+    m = mlp(x, g("linear.linear1.weight"), g("linear.linear1.bias"),
+            g("linear.linear2.weight"), g("linear.linear2.bias"))
+    return x + F.layer_norm(m, (C,), g("norm2.weight"), g("norm2.bias"))         # layers.py:251
+
+
+def earth_layer(p, li, depth, x, Z, H, W, heads):
+    for i in range(depth):
+        x = earth_block(p, f"layers.EarthSpecificLayer{li}.blocks.EarthSpecificBlock{i}.", x, Z, H, W, heads,
+                        shifted=(i % 2 == 1))
+    return x
+
+
+def down_sample(p, x, Z, H, W):
+    B, N, C = x.shape
+    x = F.pad(x.view(B, Z, H, W, C), (0, 0, 0, 0, 0, 1))
+    H2, W2 = (H + 1) // 2, W // 2
+    x = x.view(B, Z, H2, 2, W2, 2, C).permute(0, 1, 2, 4, 3, 5, 6).reshape(B, Z * H2 * W2, 4 * C)
+    x = F.layer_norm(x, (4 * C,), p["downsample.norm.weight"], p["downsample.norm.bias"])
+    return x @ p["downsample.linear.weight"].t()
+
+
+def up_sample(p, x, Z, H2, W2, H):
+    B, N, C2 = x.shape
+    x = x @ p["upsample.linear1.weight"].t()                       # (B,N,4*Co)
+    Co = x.shape[-1] // 4
+    x = x.view(B, Z, H2, W2, 2, 2, Co).permute(0, 1, 2, 4, 3, 5, 6).reshape(B, Z, 2 * H2, 2 * W2, Co)
+    x = x[:, :, :H].reshape(B, Z * H * 2 * W2, Co)
+    x = F.layer_norm(x, (Co,), p["upsample.norm.weight"], p["upsample.norm.bias"])
+    return x @ p["upsample.linear2.weight"].t()
+
+
+def patch_recover(p, x, Z, H, W, levels=13, lat=721):
+    B, N, C = x.shape
+    x = x.view(B, Z, H, W, C)
+    up = x[:, 1:] @ p["_output_layer.conv.weight"][:, :, 0].t() + p["_output_layer.conv.bias"]     # (B,7,H,W,160)
+    up = up.view(B, Z - 1, H, W, 5, 2, 4, 4).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(B, 5, 2 * (Z - 1), 4 * H, 4 * W)
+    out = up[:, :, :levels, :lat]
+    sf = x[:, 0] @ p["_output_layer.conv_surface.weight"][:, :, 0].t() + p["_output_layer.conv_surface.bias"]
+    sf = sf.view(B, H, W, 4, 4, 4).permute(0, 3, 1, 4, 2, 5).reshape(B, 4, 4 * H, 4 * W)
+    return out.contiguous(), sf[:, :, :lat].contiguous()
+
+
+def forward(p, inp, inp_surface, statistics, maps, const_h,
+            depths=(2, 6, 6, 2), heads=(6, 12, 12, 6)):
+    """Full model forward (models/pangu_model.py:50-87). Returns (output, output_surface), normalised units."""
+    x = patch_embed(p, inp, inp_surface, statistics, maps, const_h)
+    x = earth_layer(p, 0, depths[0], x, 8, 181, 360, heads[0])
+    skip = x
+    x = down_sample(p, x, 8, 181, 360)
+    x = earth_layer(p, 1, depths[1], x, 8, 91, 180, heads[1])
+    x = earth_layer(p, 2, depths[2], x, 8, 91, 180, heads[2])
+    x = up_sample(p, x, 8, 91, 180, 181)
+    x = earth_layer(p, 3, depths[3], x, 8, 181, 360, heads[3])
+    x = torch.cat((skip, x), dim=-1)
+    return patch_recover(p, x, 8, 181, 360)
+
+
+def norm_target(target, target_surface, stats_last):
+    """era5_data/utils_data.py:315-321 with weather_statistics_last = (s_mean(1,4,1,1), s_std, u_mean(1,5,13,1,1), u_std)."""
+    s_mean, s_std, u_mean, u_std = stats_last
+    return (target - u_mean) / u_std, (target_surface - s_mean) / s_std
+
+
+def train_loss(output, output_surface, target, target_surface):
+    """models/pangu_sample.py:61-67 (targets already normalised)."""
+    wu = torch.tensor(UPPER_WEIGHTS, dtype=output.dtype).view(1, 5, 1, 1, 1)
+    ws = torch.tensor(SURFACE_WEIGHTS, dtype=output.dtype).view(1, 4, 1, 1)
+    lu = ((output - target).abs() * wu).mean()
+    ls = ((output_surface - target_surface).abs() * ws).mean()
+    return lu + 0.25 * ls
+
+
+def gather_grad_mean(grads_per_rank):
+    """Intended DP semantics of era5_data/utils_dist.py:125-134: all_reduce(SUM) then / world_size."""
+    world = len(grads_per_rank)
+    return {k: sum(g[k] for g in grads_per_rank) / world for k in grads_per_rank[0]}

@@ -1,0 +1,209 @@
+// Earth-specific 3D window attention, fp32, gfx950.
+//
+// One workgroup (3 waves) per (longitude window l, window type t, head): 144 tokens x 32 dims.
+// Roll / pad / partition / reverse / crop are address arithmetic (win_src_token); the shift mask is closed
+// form; nothing of size (..,144,144) ever reaches HBM.
+//   K, V of the window are staged in LDS ([144][36] floats, padded rows: conflict-free reads).
+//   Each wave owns 3 query tiles of 16 rows.  Per tile it computes the TRANSPOSED scores
+//     S^T[key][query] = K . (scale*Q)^T      with v_mfma_f32_16x16x4_f32 (9 key tiles x 8 k-steps),
+//   so a query's 144 scores live in 16 lanes-groups' registers: softmax = in-lane reduce + 2 shuffles,
+//   and the probability registers are directly the B operand of the second product
+//     O^T[d][query] = V^T[d][key] . P^T[key][query]
+//   (the MFMA k index is the accumulator's register index: no LDS round trip, no lane movement).
+// Workgroup order is XCD-aware: the nLon windows sharing one (type, head) bias tile (83 KB) are consecutive
+// on one XCD, so the 62 MB bias tensor streams from HBM once per block and is re-read from L2.
+#include "common.h"
+
+namespace {
+
+constexpr int KV_LD = 36;
+
+template <bool SHIFTED>
+__global__ __launch_bounds__(192) void window_attn_f32_kernel(const float* __restrict__ qkv,
+                                                              const float* __restrict__ qkv_bias,
+                                                              const float* __restrict__ esb,
+                                                              float* __restrict__ out, float* __restrict__ lse,
+                                                              WinGeom g, int C, int heads, int n_pairs) {
+  __shared__ __attribute__((aligned(16))) float Ks[PANGU_WTOK * KV_LD];
+  __shared__ __attribute__((aligned(16))) float Vs[PANGU_WTOK * KV_LD];
+  __shared__ int tok_s[PANGU_WTOK];
+
+  // block -> (pair=(t,head), l): blocks b, b+8, .. share an XCD and walk l for one pair
+  const int b = blockIdx.x;
+  const int xcd = b & 7, local = b >> 3;
+  const int pair = (local / g.nLon) * 8 + xcd;
+  const int l = local % g.nLon;
+  if (pair >= n_pairs) return;
+  const int t = pair / heads, hd = pair - t * heads;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int C3 = 3 * C;
+  const float scale = 0.17677669529663687f;   // 32^-0.5, reference layers.py:289
+
+  if (tid < PANGU_WTOK) tok_s[tid] = win_src_token(g, l, t, tid, SHIFTED);
+  __syncthreads();
+
+  // ---- stage K and V: 144 rows x 8 float4 each
+  for (int f = tid; f < PANGU_WTOK * 8; f += 192) {
+    const int n = f >> 3, c4 = (f & 7) * 4;
+    const int tok = tok_s[n];
+    const float* src = tok >= 0 ? qkv + (size_t)tok * C3 : qkv_bias;
+    const f32x4 kv = *reinterpret_cast<const f32x4*>(src + C + hd * 32 + c4);
+    const f32x4 vv = *reinterpret_cast<const f32x4*>(src + 2 * C + hd * 32 + c4);
+    *reinterpret_cast<f32x4*>(&Ks[n * KV_LD + c4]) = kv;
+    *reinterpret_cast<f32x4*>(&Vs[n * KV_LD + c4]) = vv;
+  }
+  __syncthreads();
+
+  const int lq = lane & 15, lg = lane >> 4;
+  const float* bias_tile = esb + (size_t)(t * heads + hd) * PANGU_WTOK * PANGU_WTOK;
+
+  bool zcut = false, hcut = false;
+  if (SHIFTED) {
+    const int zwin = t / g.nHw, hwin = t - zwin * g.nHw;
+    zcut = zwin == g.nZw - 1;
+    hcut = hwin == g.nHw - 1;
+  }
+
+  for (int qt = wave; qt < 9; qt += 3) {
+    const int qn = qt * 16 + lq;                 // this lane's query slot in the window
+    const int qtok = tok_s[qn];
+    // Q fragment: 8 dims d = 8*lg .. 8*lg+7 of query qn, pre-scaled
+    f32x4 q0, q1;
+    {
+      const float* src = (qtok >= 0 ? qkv + (size_t)qtok * C3 : qkv_bias) + hd * 32 + lg * 8;
+      q0 = *reinterpret_cast<const f32x4*>(src);
+      q1 = *reinterpret_cast<const f32x4*>(src + 4);
+      q0 *= scale; q1 *= scale;
+    }
+    // ---- S^T = K (scale Q)^T : 9 key tiles
+    f32x4 s[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const f32x4 k0 = *reinterpret_cast<const f32x4*>(&Ks[(j * 16 + lq) * KV_LD + lg * 8]);
+      const f32x4 k1 = *reinterpret_cast<const f32x4*>(&Ks[(j * 16 + lq) * KV_LD + lg * 8 + 4]);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) s[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(k0[ks], q0[ks], s[j], 0, 0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) s[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(k1[ks], q1[ks], s[j], 0, 0, 0);
+    }
+    // lane holds S^T[key = 16j + 4lg + r][query = qn], r = 0..3
+    // ---- + earth-specific bias (+ mask), row max
+    const float* brow = bias_tile + (size_t)qn * PANGU_WTOK + lg * 4;
+    float mx = -INFINITY;
+    const int zq = qn >= 72, hq = ((qn / 12) % 6) < 3;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(brow + j * 16);
+      s[j] += bv;
+      if (SHIFTED) {
+        if (zcut || hcut) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kn = j * 16 + lg * 4 + r;
+            const int zk = kn >= 72, hk = ((kn / 12) % 6) < 3;
+            if ((zcut && zq != zk) || (hcut && hq != hk)) s[j][r] += -100.0f;
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[j][r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(s[j][r] - mx);
+        s[j][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    // ---- O^T = V^T P^T : two 16-dim tiles, k = key
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = j * 16 + lg * 4 + r;
+        const float v0 = Vs[key * KV_LD + lq];
+        const float v1 = Vs[key * KV_LD + 16 + lq];
+        o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, s[j][r], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, s[j][r], o1, 0, 0, 0);
+      }
+    }
+    // lane holds O^T[d = 16*dt + 4lg + r][query = qn]
+    if (qtok >= 0) {
+      const float inv = 1.0f / sum;
+      o0 *= inv; o1 *= inv;
+      float* dst = out + (size_t)qtok * C + hd * 32 + lg * 4;
+      *reinterpret_cast<f32x4*>(dst) = o0;
+      *reinterpret_cast<f32x4*>(dst + 16) = o1;
+      if (lse && lg == 0) lse[(size_t)qtok * heads + hd] = mx + __logf(sum);
+    }
+  }
+}
+
+__global__ void window_index_export_kernel(int32_t* out, WinGeom g, int shifted) {
+  const int total = g.nLon * g.types * PANGU_WTOK;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int n = i % PANGU_WTOK, t = (i / PANGU_WTOK) % g.types, l = i / (PANGU_WTOK * g.types);
+    out[i] = win_src_token(g, l, t, n, shifted);
+  }
+}
+
+__global__ void window_mask_export_kernel(float* out, WinGeom g) {
+  const int total = g.types * PANGU_WTOK * PANGU_WTOK;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int nj = i % PANGU_WTOK, ni = (i / PANGU_WTOK) % PANGU_WTOK, t = i / (PANGU_WTOK * PANGU_WTOK);
+    out[i] = win_mask(g, t, ni, nj);
+  }
+}
+
+int check_geom(int Z, int H, int W) {
+  if (Z <= 0 || H <= 0 || W <= 0) return PANGU_E_SHAPE;
+  if (Z % PANGU_WZ || (H + PANGU_PAD_H) % PANGU_WH || W % PANGU_WW) return PANGU_E_SHAPE;
+  return PANGU_OK;
+}
+
+}  // namespace
+
+extern "C" int pangu_window_attn_fwd(pangu_stream_t stream, const float* qkv, const float* qkv_bias,
+                                     const float* esb, float* out, float* lse, int Z, int H, int W, int C,
+                                     int heads, int shifted) {
+  if (!qkv || !qkv_bias || !esb || !out) return PANGU_E_NULL;
+  if (int e = check_geom(Z, H, W)) return e;
+  if (heads <= 0 || C != heads * PANGU_HEAD_DIM) return PANGU_E_SHAPE;
+  const WinGeom g = make_geom(Z, H, W);
+  const int n_pairs = g.types * heads;
+  const int grid = ((n_pairs + 7) / 8) * 8 * g.nLon;
+  hipStream_t s = (hipStream_t)stream;
+  if (shifted)
+    hipLaunchKernelGGL(window_attn_f32_kernel<true>, dim3(grid), dim3(192), 0, s, qkv, qkv_bias, esb, out, lse, g, C,
+                       heads, n_pairs);
+  else
+    hipLaunchKernelGGL(window_attn_f32_kernel<false>, dim3(grid), dim3(192), 0, s, qkv, qkv_bias, esb, out, lse, g,
+                       C, heads, n_pairs);
+  return pangu_launch_status();
+}
+
+extern "C" int pangu_window_index_export(pangu_stream_t stream, int32_t* out, int Z, int H, int W, int shifted) {
+  if (!out) return PANGU_E_NULL;
+  if (int e = check_geom(Z, H, W)) return e;
+  const WinGeom g = make_geom(Z, H, W);
+  hipLaunchKernelGGL(window_index_export_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, out, g, shifted ? 1 : 0);
+  return pangu_launch_status();
+}
+
+extern "C" int pangu_window_mask_export(pangu_stream_t stream, float* out, int Z, int H, int W) {
+  if (!out) return PANGU_E_NULL;
+  if (int e = check_geom(Z, H, W)) return e;
+  const WinGeom g = make_geom(Z, H, W);
+  hipLaunchKernelGGL(window_mask_export_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, out, g);
+  return pangu_launch_status();
+}

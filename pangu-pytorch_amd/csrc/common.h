@@ -1,0 +1,63 @@
+// Shared device helpers for the Pangu-Weather gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pangu_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define PANGU_WZ 2
+#define PANGU_WH 6
+#define PANGU_WW 12
+#define PANGU_WTOK 144
+#define PANGU_HEAD_DIM 32
+#define PANGU_PAD_H 5
+
+// Geometry of one attention stage: grid (Z,H,W), padded latitude Hp = H+5, windows (2,6,12).
+struct WinGeom {
+  int Z, H, W, Hp, nLon, nZw, nHw, types;
+};
+
+__host__ __device__ inline WinGeom make_geom(int Z, int H, int W) {
+  WinGeom g;
+  g.Z = Z; g.H = H; g.W = W; g.Hp = H + PANGU_PAD_H;
+  g.nLon = W / PANGU_WW; g.nZw = Z / PANGU_WZ; g.nHw = g.Hp / PANGU_WH; g.types = g.nZw * g.nHw;
+  return g;
+}
+
+// Flat token index (z*H+h)*W+w that feeds window slot (l, t, n), or -1 for a zero-pad slot.
+// Folds view/pad/roll/partition (reference models/layers.py:188-221) into address arithmetic;
+// the same token receives the attention output (reverse/roll-back/crop, layers.py:227-247).
+__host__ __device__ inline int win_src_token(const WinGeom& g, int l, int t, int n, int shifted) {
+  int zwin = t / g.nHw, hwin = t - zwin * g.nHw;
+  int zi = n / 72, r = n - zi * 72, hi = r / 12, wi = r - hi * 12;
+  int z = 2 * zwin + zi, h = 6 * hwin + hi, w = 12 * l + wi;
+  if (shifted) {
+    z += 1; if (z >= g.Z) z -= g.Z;
+    h += 3; if (h >= g.Hp) h -= g.Hp;
+    w += 6; if (w >= g.W) w -= g.W;
+  }
+  return h >= g.H ? -1 : (z * g.H + h) * g.W + w;
+}
+
+// Shifted-window mask (reference models/layers.py:153-181) in closed form: -100 or 0.
+__host__ __device__ inline float win_mask(const WinGeom& g, int t, int ni, int nj) {
+  int zwin = t / g.nHw, hwin = t - zwin * g.nHw;
+  bool zcut = (zwin == g.nZw - 1) && ((ni / 72) != (nj / 72));
+  bool hcut = (hwin == g.nHw - 1) && ((((ni / 12) % 6) < 3) != (((nj / 12) % 6) < 3));
+  return (zcut || hcut) ? -100.0f : 0.0f;
+}
+
+__device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int pangu_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? PANGU_OK : (int)e;
+}

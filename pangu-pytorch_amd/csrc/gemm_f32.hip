@@ -1,0 +1,176 @@
+// fp32 projection GEMM for gfx950: C[M,N] = act(A[M,K] @ W[N,K]^T + bias), exact-f32 MFMA.
+//
+// Shape regime of this path: M = 65k..521k tokens, N,K in {64..1536} -> output-tile parallel, no split-K.
+// Tile: 128 x (64*TN) per 256-thread workgroup (4 waves as 2x2, each 64 x 32*TN = 2 x TN MFMA 32x32 tiles),
+// BK = 16, LDS double-buffered with register prefetch (one barrier per K-step).
+// MFMA: v_mfma_f32_32x32x2_f32 (64 FLOP/clk/SIMD = the chip's f32 matrix peak, 157 TF).  Both operands are
+// K-contiguous in memory, so each lane reads its 8 k-values of a K-step as two ds_read_b128: the MFMA's
+// k index is permuted (lane half h owns k = 8h..8h+7) identically for A and W, which leaves the sum unchanged.
+// LDS rows are padded to 20 floats: conflict-free for the ds_read_b128 lane groups.
+// Block -> tile map is XCD-aware: workgroups that share an A row-panel (the n-tiles of one m-tile) are
+// consecutive on ONE XCD, so the panel is fetched from HBM once and re-read from that XCD's L2.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 16;
+constexpr int LDS_LD = 20;   // padded row (floats)
+
+template <int TN, int ACT, bool HAS_BIAS>
+__global__ __launch_bounds__(256, 2) void gemm_tn_f32_kernel(const float* __restrict__ A, int lda,
+                                                             const float* __restrict__ W,
+                                                             const float* __restrict__ bias,
+                                                             float* __restrict__ C, int ldc, int M, int N, int K,
+                                                             int m_tiles, int n_tiles) {
+  constexpr int BN = 64 * TN;
+  __shared__ __attribute__((aligned(16))) float smem[2][(BM + BN) * LDS_LD];
+
+  // XCD-aware tile assignment (blocks b, b+8, b+16.. share an XCD; they walk the n-tiles of one m-tile).
+  const int b = blockIdx.x;
+  const int xcd = b & 7, local = b >> 3;
+  const int m_tile = (local / n_tiles) * 8 + xcd;
+  const int n_tile = local % n_tiles;
+  if (m_tile >= m_tiles) return;
+  const int m0 = m_tile * BM, n0 = n_tile * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  // global -> register staging assignment: float4 index f = tid + 256*i, row = f>>2, kq = f&3
+  const int ld_row = tid >> 2, ld_kq = tid & 3;
+  const float* a_ptr[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int r = m0 + ld_row + 64 * i;
+    r = r < M ? r : M - 1;
+    a_ptr[i] = A + (size_t)r * lda + ld_kq * 4;
+  }
+  const float* w_ptr[TN];
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    int r = n0 + ld_row + 64 * i;
+    r = r < N ? r : N - 1;
+    w_ptr[i] = W + (size_t)r * K + ld_kq * 4;
+  }
+  const int st_a = ld_row * LDS_LD + ld_kq * 4;   // + 64*LDS_LD*i
+
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ra[2], rw[TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i]);
+#pragma unroll
+  for (int i = 0; i < TN; ++i) rw[i] = *reinterpret_cast<const f32x4*>(w_ptr[i]);
+  {
+    float* As = smem[0];
+    float* Ws = As + BM * LDS_LD;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(&As[st_a + 64 * LDS_LD * i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) *reinterpret_cast<f32x4*>(&Ws[st_a + 64 * LDS_LD * i]) = rw[i];
+  }
+  __syncthreads();
+
+  const int KT = K / BK;
+  const int rd_a = (wm * 64 + lr) * LDS_LD + lh * 8;
+  const int rd_w = (wn * 32 * TN + lr) * LDS_LD + lh * 8;
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const bool more = kt + 1 < KT;
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + (kt + 1) * BK);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) rw[i] = *reinterpret_cast<const f32x4*>(w_ptr[i] + (kt + 1) * BK);
+    }
+    const float* As = smem[kt & 1];
+    const float* Ws = As + BM * LDS_LD;
+    f32x4 fa[2][2], fw[TN][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      fa[i][0] = *reinterpret_cast<const f32x4*>(&As[rd_a + i * 32 * LDS_LD]);
+      fa[i][1] = *reinterpret_cast<const f32x4*>(&As[rd_a + i * 32 * LDS_LD + 4]);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      fw[j][0] = *reinterpret_cast<const f32x4*>(&Ws[rd_w + j * 32 * LDS_LD]);
+      fw[j][1] = *reinterpret_cast<const f32x4*>(&Ws[rd_w + j * 32 * LDS_LD + 4]);
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s >> 2][s & 3], fw[j][s >> 2][s & 3], acc[i][j], 0, 0, 0);
+    if (more) {
+      float* An = smem[(kt + 1) & 1];
+      float* Wn = An + BM * LDS_LD;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(&An[st_a + 64 * LDS_LD * i]) = ra[i];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) *reinterpret_cast<f32x4*>(&Wn[st_a + 64 * LDS_LD * i]) = rw[i];
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * 32 * TN + j * 32 + lr;
+    const bool col_ok = col < N;
+    float bv = 0.f;
+    if (HAS_BIAS) bv = bias[col_ok ? col : N - 1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row0 = m0 + wm * 64 + i * 32 + 4 * lh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2);
+        float v = acc[i][j][r] + bv;
+        if (ACT == PANGU_ACT_GELU) v = gelu_erf(v);
+        if (col_ok && row < M) C[(size_t)row * ldc + col] = v;
+      }
+    }
+  }
+}
+
+template <int TN>
+int launch_tn(hipStream_t s, const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M,
+              int N, int K, int act) {
+  constexpr int BN = 64 * TN;
+  const int m_tiles = (M + BM - 1) / BM, n_tiles = (N + BN - 1) / BN;
+  const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
+  dim3 g(grid), blk(256);
+#define PANGU_GEMM_LAUNCH(ACT, HB) \
+  hipLaunchKernelGGL((gemm_tn_f32_kernel<TN, ACT, HB>), g, blk, 0, s, A, lda, W, bias, C, ldc, M, N, K, m_tiles, n_tiles)
+  if (act == PANGU_ACT_GELU) {
+    if (bias) PANGU_GEMM_LAUNCH(PANGU_ACT_GELU, true); else PANGU_GEMM_LAUNCH(PANGU_ACT_GELU, false);
+  } else {
+    if (bias) PANGU_GEMM_LAUNCH(PANGU_ACT_NONE, true); else PANGU_GEMM_LAUNCH(PANGU_ACT_NONE, false);
+  }
+#undef PANGU_GEMM_LAUNCH
+  return pangu_launch_status();
+}
+
+}  // namespace
+
+extern "C" int pangu_linear_fwd(pangu_stream_t stream, const float* A, int lda, const float* W, const float* bias,
+                                float* C, int ldc, int M, int N, int K, int act) {
+  if (!A || !W || !C) return PANGU_E_NULL;
+  if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || lda < K || ldc < N || (lda & 3)) return PANGU_E_SHAPE;
+  if (act != PANGU_ACT_NONE && act != PANGU_ACT_GELU) return PANGU_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  // widest tile that divides N (192 covers every projection of this model except the recovery convs)
+  if (N % 192 == 0) return launch_tn<3>(s, A, lda, W, bias, C, ldc, M, N, K, act);
+  if (N % 128 == 0) return launch_tn<2>(s, A, lda, W, bias, C, ldc, M, N, K, act);
+  return launch_tn<1>(s, A, lda, W, bias, C, ldc, M, N, K, act);
+}

@@ -1,0 +1,110 @@
+"""Forward compositions of the HIP kernels for each reference layer (inference path, no autograd graph).
+
+Token tensors are (B, N, C); B is folded into rows for projections / LayerNorm and looped for the
+geometry-dependent kernels (the reference itself is B=1 only, models/layers.py:219,227).
+"""
+import torch
+
+from . import ops
+
+
+def _tok2d(x):
+    """(B,N,C) -> 2-D row view (B*N, C) (row-strided views stay views)."""
+    B, N, C = x.shape
+    if x.stride(2) != 1 or (B > 1 and x.stride(0) != N * x.stride(1)):
+        x = x.contiguous()
+    return x.as_strided((B * N, C), (x.stride(1), 1), x.storage_offset())
+
+
+def mlp(m, x2d):
+    h = ops.linear(x2d, m.linear1.weight, m.linear1.bias, act=ops.ACT_GELU)
+    return ops.linear(h, m.linear2.weight, m.linear2.bias)
+
+
+def earth_block(blk, x, Z, H, W, roll, out=None):
+    """x (B,N,C) -> (B,N,C).  reference layers.py:183-253 as 7 kernel launches per sample."""
+    B, N, C = x.shape
+    att = blk.attention
+    x2 = _tok2d(x)
+    dp = blk.drop_path
+    s1 = dp.sample_scale(blk.training) if hasattr(dp, "sample_scale") else 1.0
+    s2 = dp.sample_scale(blk.training) if hasattr(dp, "sample_scale") else 1.0
+    if s1 != 0.0:
+        qkv = ops.linear(x2, att.linear1.weight, att.linear1.bias)                      # (B*N, 3C)
+        esb = att.earth_specific_bias[0]
+        o = torch.cat([ops.window_attention(qkv[b * N:(b + 1) * N], att.linear1.bias, esb, Z, H, W,
+                                            att.head_number, roll) for b in range(B)], 0) if B > 1 else \
+            ops.window_attention(qkv, att.linear1.bias, esb, Z, H, W, att.head_number, roll)
+        y = ops.linear(o, att.linear2.weight, att.linear2.bias)
+        x1 = ops.ln_residual(y, x2, blk.norm1.weight, blk.norm1.bias, branch_scale=s1)
+    else:
+        x1 = x2
+    if s2 != 0.0:
+        m = mlp(blk.linear, x1)
+        o2 = _tok2d(out) if out is not None else None
+        x2o = ops.ln_residual(m, x1, blk.norm2.weight, blk.norm2.bias, out=o2, branch_scale=s2)
+    else:
+        x2o = x1
+        if out is not None:
+            _tok2d(out).copy_(x1)
+            x2o = _tok2d(out)
+    return out if out is not None else x2o.view(B, N, C)
+
+
+def patch_embed(m, inp, inp_surface, statistics, maps, const_h):
+    """reference layers.py:40-93 -> (B, 8*181*360, 192)."""
+    s_mean, s_std, u_mean, u_std = statistics
+    B = inp.shape[0]
+    LAT, LON = inp.shape[-2], inp.shape[-1]
+    H4, W4 = (LAT + 3) // 4, LON // 4
+    n_s, n_u = H4 * W4, 7 * H4 * W4
+    dim = m.conv.weight.shape[0]
+    x = torch.empty((B, n_s + n_u, dim), dtype=torch.float32, device=inp.device)
+    f32 = lambda t: t.to(device=inp.device, dtype=torch.float32).contiguous()
+    s_mean, s_std = f32(s_mean).reshape(-1), f32(s_std).reshape(-1)
+    u_mean, u_std = f32(u_mean).reshape(13, 5), f32(u_std).reshape(13, 5)
+    maps_c = f32(maps).reshape(3, 4 * H4, LON)
+    const_c = f32(const_h).reshape(13, LAT, LON)
+    for b in range(B):
+        a_s, a_u = ops.patch_embed_gather(inp[b].contiguous(), inp_surface[b].contiguous(), s_mean, s_std, u_mean,
+                                          u_std, maps_c, const_c)
+        ops.linear(a_s, m.conv_surface.weight, m.conv_surface.bias, out=x[b, :n_s])
+        ops.linear(a_u, m.conv.weight, m.conv.bias, out=x[b, n_s:])
+    return x
+
+
+def down_sample(m, x, Z, H, W):
+    B, N, C = x.shape
+    outs = []
+    for b in range(B):
+        g = ops.downsample_ln(_tok2d(x[b:b + 1]), m.norm.weight, m.norm.bias, Z, H, W)
+        outs.append(ops.linear(g, m.linear.weight))
+    return torch.stack(outs, 0) if B > 1 else outs[0].unsqueeze(0)
+
+
+def up_sample(m, x, Z, H2, W2, H, out=None):
+    B, N, C2 = x.shape
+    y = ops.linear(_tok2d(x), m.linear1.weight)                          # (B*N, 4Co)
+    Co = y.shape[1] // 4
+    Nf = Z * H * 2 * W2
+    if out is None:
+        out = torch.empty((B, Nf, Co), dtype=torch.float32, device=x.device)
+    for b in range(B):
+        g = ops.upsample_ln(y[b * N:(b + 1) * N], m.norm.weight, m.norm.bias, Z, H2, W2, H)
+        ops.linear(g, m.linear2.weight, out=_tok2d(out[b:b + 1]))
+    return out
+
+
+def patch_recover(m, x, Z, H, W, LAT=721, LON=1440):
+    """x (B, Z*H*W, C) (may be a row-strided view) -> (B,5,13,LAT,LON), (B,4,LAT,LON).  reference layers.py:511-545."""
+    B, N, C = x.shape
+    n_s = H * W
+    outs, outs_s = [], []
+    for b in range(B):
+        xb = _tok2d(x[b:b + 1])
+        y_s = ops.linear(xb[:n_s], m.conv_surface.weight, m.conv_surface.bias)
+        y_u = ops.linear(xb[n_s:], m.conv.weight, m.conv.bias)
+        o, os_ = ops.patch_recover_scatter(y_u, y_s, LAT, LON)
+        outs.append(o)
+        outs_s.append(os_)
+    return torch.stack(outs, 0), torch.stack(outs_s, 0)

@@ -1,0 +1,166 @@
+"""Layer modules of the Pangu-Weather network, MI355X-native.
+
+Mirror of the reference's module tree (models/layers.py): same class names, constructor arguments,
+sub-module names and parameter shapes, so `state_dict()` keys/shapes match the 223-row keys_all.csv and
+`named_modules()` introspection (LoRA targets, torch_summarize) keeps working.  The arithmetic is NOT the
+reference's op chain: every forward calls hand-written gfx950 kernels through the C ABI (`ops.py`), with
+all view/pad/roll/permute/crop steps folded into kernel address arithmetic.  nn.Linear / nn.Conv1d /
+nn.LayerNorm sub-modules are parameter containers only.
+"""
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from . import fused
+
+WINDOW = (2, 6, 12)
+
+
+def _trunc_normal_(t, std):
+    return nn.init.trunc_normal_(t, std=std)      # stands in for timm's trunc_normal_ (reference layers.py:9)
+
+
+class DropPath(nn.Module):
+    """Stochastic depth (timm semantics, reference layers.py:140): in training each residual branch of a
+    sample is dropped with prob p, else scaled 1/(1-p).  Only the per-sample factor is drawn here; it is
+    applied inside the fused LayerNorm-residual kernel (and a dropped branch is not computed at all)."""
+
+    def __init__(self, drop_prob=0.0):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+
+    def sample_scale(self, training):
+        if not training or self.drop_prob == 0.0:
+            return 1.0
+        keep = 1.0 - self.drop_prob
+        return (1.0 / keep) if torch.rand(()).item() < keep else 0.0
+
+    def extra_repr(self):
+        return f"drop_prob={self.drop_prob:.3f}"
+
+
+class PatchEmbedding_pretrain(nn.Module):
+    """reference layers.py:12-93."""
+
+    def __init__(self, patch_size, dim):
+        super().__init__()
+        self.conv = nn.Conv1d(in_channels=192, out_channels=dim, kernel_size=1, stride=1)
+        self.conv_surface = nn.Conv1d(in_channels=112, out_channels=dim, kernel_size=1, stride=1)
+        self.window_size = WINDOW
+
+    def forward(self, input, input_surface, statistics, maps, const_h):
+        return fused.patch_embed(self, input, input_surface, statistics, maps, const_h)
+
+
+class Mlp(nn.Module):
+    """reference layers.py:255-270 (dropout p=0 is the identity and is not materialised)."""
+
+    def __init__(self, dim, dropout_rate):
+        super().__init__()
+        self.linear1 = nn.Linear(dim, dim * 4)
+        self.linear2 = nn.Linear(dim * 4, dim)
+        self.activation = nn.GELU()
+        self.drop = nn.Dropout(dropout_rate)
+
+    def forward(self, x):
+        shp = x.shape
+        return fused.mlp(self, x.reshape(-1, shp[-1])).reshape(shp)
+
+
+class EarthAttention3D(nn.Module):
+    """reference layers.py:272-421.  Parameters only; the arithmetic is the fused window-attention kernel."""
+
+    def __init__(self, dim, heads, dropout_rate, window_size, device=None):
+        super().__init__()
+        self.device = device
+        self.linear1 = nn.Linear(dim, dim * 3, bias=True)
+        self.linear2 = nn.Linear(dim, dim)
+        self.head_number = heads
+        self.dim = dim
+        self.scale = (dim // heads) ** -0.5
+        self.window_size = window_size
+        input_shape = {192: (8, 186), 384: (8, 96)}[dim]                       # reference layers.py:298-301
+        self.type_of_windows = (input_shape[0] // window_size[0]) * (input_shape[1] // window_size[1])
+        wtok = window_size[0] * window_size[1] * window_size[2]
+        self.earth_specific_bias = nn.Parameter(torch.zeros(1, self.type_of_windows, heads, wtok, wtok, device=device))
+        _trunc_normal_(self.earth_specific_bias, std=0.02)
+
+
+class EarthSpecificBlock(nn.Module):
+    """reference layers.py:127-253."""
+
+    def __init__(self, dim, drop_path_ratio, heads, device=None):
+        super().__init__()
+        self.device = device
+        self.window_size = WINDOW
+        self.drop_path = DropPath(drop_path_ratio) if drop_path_ratio > 0.0 else nn.Identity()
+        self.norm1 = nn.LayerNorm(dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.linear = Mlp(dim, 0)
+        self.attention = EarthAttention3D(dim, heads, 0, self.window_size, device=device)
+        self.padding_front, self.padding_back = 0, 5
+        self.type_of_windows = self.attention.type_of_windows
+
+    def forward(self, x, Z, H, W, roll, out=None):
+        return fused.earth_block(self, x, Z, H, W, roll, out=out)
+
+
+class EarthSpecificLayer(nn.Module):
+    """reference layers.py:96-125.  `use_checkpoint` is accepted for signature parity and ignored: with the
+    fused attention nothing of size (..,144,144) is kept, so activations fit HBM without recompute."""
+
+    def __init__(self, depth, dim, drop_path_ratio_list, heads, use_checkpoint=False, device=None):
+        super().__init__()
+        self.device = device
+        self.depth = depth
+        blocks = OrderedDict()
+        for i in range(depth):
+            blocks[f"EarthSpecificBlock{i}"] = EarthSpecificBlock(dim, drop_path_ratio_list[i], heads, device=device)
+        self.blocks = nn.Sequential(blocks)
+        self.use_checkpoint = use_checkpoint
+
+    def forward(self, x, Z, H, W, out=None):
+        n = len(self.blocks)
+        for i, blk in enumerate(self.blocks):
+            x = blk(x, Z, H, W, roll=(i % 2 == 1), out=out if i == n - 1 else None)
+        return x
+
+
+class DownSample(nn.Module):
+    """reference layers.py:423-459."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.linear = nn.Linear(in_features=4 * dim, out_features=2 * dim, bias=False)
+        self.norm = nn.LayerNorm(4 * dim)
+
+    def forward(self, x, Z, H, W):
+        return fused.down_sample(self, x, Z, H, W)
+
+
+class UpSample(nn.Module):
+    """reference layers.py:461-499."""
+
+    def __init__(self, input_dim, output_dim):
+        super().__init__()
+        self.linear1 = nn.Linear(input_dim, output_dim * 4, bias=False)
+        self.linear2 = nn.Linear(output_dim, output_dim, bias=False)
+        self.norm = nn.LayerNorm(output_dim)
+
+    def forward(self, x, Z=8, H2=91, W2=180, H=181, out=None):
+        return fused.up_sample(self, x, Z, H2, W2, H, out=out)
+
+
+class PatchRecovery_pretrain(nn.Module):
+    """reference layers.py:501-545."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.patch_size = (2, 4, 4)
+        self.dim = dim
+        self.conv = nn.Conv1d(in_channels=dim, out_channels=160, kernel_size=1, stride=1)
+        self.conv_surface = nn.Conv1d(in_channels=dim, out_channels=64, kernel_size=1, stride=1)
+
+    def forward(self, x, Z, H, W):
+        return fused.patch_recover(self, x, Z, H, W)

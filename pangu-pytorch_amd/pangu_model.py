@@ -1,0 +1,85 @@
+"""PanguModel — drop-in for the reference's models/pangu_model.py:8-87 on MI355X.
+
+Same constructor (`depths, num_heads, dims, patch_size, device`), same 223 state_dict keys/shapes (the
+onnx2torch layout of keys_all.csv), same `forward(input, input_surface, statistics, maps, const_h)`
+returning `(output, output_surface)` in normalised units, `.device`, and a plain nn.Module tree that
+survives `copy.deepcopy` / pickling.  The arithmetic runs on hand-written gfx950 kernels (C ABI in
+include/pangu_hip.h); calling it with CPU tensors raises — there is no fallback path.
+"""
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from .layers import (DownSample, EarthSpecificLayer, PatchEmbedding_pretrain, PatchRecovery_pretrain, UpSample,
+                     _trunc_normal_)
+
+
+class PanguModel(nn.Module):
+    def __init__(self, depths=[2, 6, 6, 2], num_heads=[6, 12, 12, 6], dims=[192, 384, 384, 192],
+                 patch_size=(2, 4, 4), device=None):
+        super().__init__()
+        self.device = device
+        self._input_layer = PatchEmbedding_pretrain(patch_size, dims[0])
+        self.downsample = DownSample(dims[0])
+        dpr = [x.item() for x in torch.linspace(0, 0.2, sum(depths))]          # reference pangu_model.py:19
+        self.num_layers = len(depths)
+        layer_list = OrderedDict()
+        for i in range(self.num_layers):
+            layer_list[f"EarthSpecificLayer{i}"] = EarthSpecificLayer(
+                depth=depths[i], dim=dims[i], drop_path_ratio_list=dpr[sum(depths[:i]):sum(depths[:i + 1])],
+                heads=num_heads[i], use_checkpoint=False, device=device)
+        self.layers = nn.Sequential(layer_list)
+        self.upsample = UpSample(dims[-2], dims[-1])
+        self._output_layer = PatchRecovery_pretrain(dims[-2])
+        self.apply(self._init_weights)
+        # optional default constants (NOT in state_dict): lets callers use forward(input, input_surface)
+        self.register_buffer("_c_surface_mean", None, persistent=False)
+        self.register_buffer("_c_surface_std", None, persistent=False)
+        self.register_buffer("_c_upper_mean", None, persistent=False)
+        self.register_buffer("_c_upper_std", None, persistent=False)
+        self.register_buffer("_c_maps", None, persistent=False)
+        self.register_buffer("_c_const_h", None, persistent=False)
+
+    def _init_weights(self, m):                                                # reference pangu_model.py:41-48
+        if isinstance(m, nn.Linear):
+            _trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def set_constants(self, statistics, maps, const_h):
+        """Register default `statistics, maps, const_h` so forward can be called with two arguments."""
+        dev = next(self.parameters()).device
+        self._c_surface_mean, self._c_surface_std, self._c_upper_mean, self._c_upper_std = (
+            torch.as_tensor(t, dtype=torch.float32).to(dev) for t in statistics)
+        self._c_maps = torch.as_tensor(maps, dtype=torch.float32).to(dev)
+        self._c_const_h = torch.as_tensor(const_h, dtype=torch.float32).to(dev)
+
+    def forward(self, input, input_surface, statistics=None, maps=None, const_h=None):
+        """reference pangu_model.py:50-87."""
+        if statistics is None or maps is None or const_h is None:
+            if self._c_maps is None:
+                raise TypeError("forward() needs statistics, maps, const_h (or call set_constants() first)")
+            statistics = statistics if statistics is not None else (
+                self._c_surface_mean, self._c_surface_std, self._c_upper_mean, self._c_upper_std)
+            maps = maps if maps is not None else self._c_maps
+            const_h = const_h if const_h is not None else self._c_const_h
+        if not (input.is_cuda and input_surface.is_cuda):
+            raise RuntimeError("PanguModel (MI355X build) needs its inputs on a HIP device; there is no CPU fallback "
+                               f"(got {input.device})")
+        B = input.shape[0]
+        x = self._input_layer(input, input_surface, statistics, maps, const_h)             # (B,521280,192)
+        N, C = x.shape[1], x.shape[2]
+        # skip connection: layer 0 writes its result into the left half, layer 3 into the right half of one
+        # (B,N,2C) buffer, so the channel concat of reference pangu_model.py:81 costs no copy
+        cat = torch.empty((B, N, 2 * C), dtype=x.dtype, device=x.device)
+        skip = self.layers[0](x, 8, 181, 360, out=cat[:, :, :C])
+        x = self.downsample(skip, 8, 181, 360)
+        x = self.layers[1](x, 8, 91, 180)
+        x = self.layers[2](x, 8, 91, 180)
+        x = self.upsample(x)
+        self.layers[3](x, 8, 181, 360, out=cat[:, :, C:])
+        return self._output_layer(cat, 8, 181, 360)

@@ -1,0 +1,85 @@
+"""CPU-side checks of the drop-in boundary: the C ABI library exports what include/pangu_hip.h declares, the
+Python binding table matches the header, and the nn.Module surface matches the reference's contract."""
+import copy
+import ctypes
+import json
+import os
+import pickle
+
+import pytest
+import torch
+
+import pangu_pytorch_amd as P
+from pangu_pytorch_amd import _lib
+
+
+def test_header_vs_binding_table():
+    assert _lib.header_functions() == sorted(_lib.SIGNATURES)
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libpangu_hip.so not built (run __graft_entry__.build())")
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _lib.header_functions():
+        assert hasattr(lib, name), name
+    lib.pangu_abi_version.restype = ctypes.c_int
+    assert lib.pangu_abi_version() == 1
+
+
+def test_argument_validation_without_gpu():
+    """Bad arguments are rejected on the host before any launch (no GPU needed)."""
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libpangu_hip.so not built")
+    lib = _lib.load()
+    assert lib.pangu_linear_fwd(None, None, 0, None, None, None, 0, 1, 1, 16, 0) == -2          # NULL
+    assert lib.pangu_linear_fwd(None, 8, 8, 8, None, 8, 8, 4, 8, 8, 0) == -1                      # K % 16
+    assert lib.pangu_window_attn_fwd(None, 8, 8, 8, 8, None, 8, 181, 25, 192, 6, 0) == -1         # W % 12
+    assert lib.pangu_window_attn_fwd(None, 8, 8, 8, 8, None, 8, 181, 24, 192, 5, 0) == -1         # C != 32*heads
+    assert lib.pangu_error_string(-1) == b"unsupported shape"
+
+
+@pytest.fixture(scope="module")
+def model():
+    torch.manual_seed(0)
+    return P.PanguModel(device="cpu")
+
+
+def test_state_dict_keys_and_shapes(model, golden_dir):
+    ks = json.load(open(os.path.join(golden_dir, "keys_shapes.json")))
+    sd = {k: list(v.shape) for k, v in model.state_dict().items()}
+    assert sd == ks["state_dict"] and len(sd) == 223
+    assert sum(p.numel() for p in model.parameters()) == ks["n_params"] == 276659936
+    assert [k for k, _ in model.named_parameters()] == ks["named_parameters_order"]
+
+
+def test_strict_load_state_dict_roundtrip(model):
+    sd = {k: torch.zeros_like(v) for k, v in model.state_dict().items()}
+    m2 = P.PanguModel(device="cpu")
+    missing = m2.load_state_dict({"model": sd}["model"], strict=True)       # reference test_main.py:64-65
+    assert not missing.missing_keys and not missing.unexpected_keys
+
+
+def test_module_is_deepcopy_and_pickle_safe(model):
+    blk = model.layers[0].blocks[0]
+    assert pickle.loads(pickle.dumps(blk)).attention.head_number == 6      # reference pangu_sample.py:162-164
+    m2 = copy.deepcopy(model.layers[1])
+    assert m2.blocks[1].attention.earth_specific_bias.shape == (1, 64, 12, 144, 144)
+
+
+def test_init_matches_reference_policy(model):
+    blk = model.layers[0].blocks[1]
+    assert float(blk.norm1.weight.min()) == 1.0 and float(blk.norm1.bias.abs().max()) == 0.0
+    assert float(blk.linear.linear1.bias.abs().max()) == 0.0
+    assert 0.015 < float(blk.linear.linear1.weight.std()) < 0.025
+    assert 0.015 < float(blk.attention.earth_specific_bias.std()) < 0.025
+    dpr = [b.drop_path.drop_prob if hasattr(b.drop_path, "drop_prob") else 0.0
+           for l in model.layers for b in l.blocks]
+    assert dpr[0] == 0.0 and abs(dpr[-1] - 0.2) < 1e-6 and len(dpr) == 16
+
+
+def test_cpu_tensors_fail_loudly(model):
+    with pytest.raises(RuntimeError, match="no CPU fallback|MI355X"):
+        model(torch.zeros(1, 5, 13, 721, 1440), torch.zeros(1, 4, 721, 1440),
+              (torch.zeros(4), torch.ones(4), torch.zeros(13, 1, 1, 5), torch.ones(13, 1, 1, 5)),
+              torch.zeros(1, 3, 724, 1440), torch.zeros(1, 1, 1, 13, 721, 1440))

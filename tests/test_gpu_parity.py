@@ -1,0 +1,232 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the reference-generated golden
+fixtures.  Needs an MI355X: run with `-m gpu`.
+
+Tolerances: integer/index/mask tensors bit-exact; fp32 kernels <= 1e-3 relative (north_star), in practice
+1e-5..1e-4 (both sides accumulate in fp32; only summation order differs)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import pangu_oracle as O
+import synth
+
+pytestmark = pytest.mark.gpu
+REL = 1e-3          # the contract (BASELINE.json north_star)
+TIGHT = 2e-4        # what fp32-vs-fp32 should achieve; a regression canary
+
+
+@pytest.fixture(scope="module")
+def P():
+    import pangu_pytorch_amd as P
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    P._lib.load()
+    return P
+
+
+def rel_err(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+# ---------------------------------------------------------------- integer contract
+@pytest.mark.parametrize("Z,H,W", [(8, 181, 24), (8, 91, 24), (8, 181, 360), (8, 91, 180)])
+@pytest.mark.parametrize("shifted", [False, True])
+def test_window_index_bit_exact(P, Z, H, W, shifted):
+    got = P.ops.window_index(Z, H, W, shifted, "cuda").cpu()
+    assert torch.equal(got, O.window_source_index(Z, H, W, shifted))
+
+
+@pytest.mark.parametrize("Z,H,W", [(8, 181, 24), (8, 91, 24), (8, 181, 360)])
+def test_window_mask_bit_exact(P, Z, H, W):
+    got = P.ops.window_mask(Z, H, W, "cuda").cpu()
+    assert torch.equal(got, O.shift_mask(Z, H, W))
+
+
+def test_window_index_golden(P, golden_dir):
+    g = np.load(os.path.join(golden_dir, "index.npz"))
+    for C in (192, 384):
+        st = cases.STAGES[C]
+        for roll in (0, 1):
+            got = P.ops.window_index(st["Z"], st["H"], 24, roll, "cuda").cpu().numpy()
+            assert np.array_equal(got, g[f"win_index_{C}_{roll}"])
+        m = P.ops.window_mask(st["Z"], st["H"], 24, "cuda").cpu().numpy()
+        assert np.array_equal(np.packbits(m != 0), g[f"mask_bits_{C}"])
+
+
+# ---------------------------------------------------------------- projections
+@pytest.mark.parametrize("M,N,K,act,bias", [
+    (1000, 192, 192, 0, True), (4099, 576, 192, 0, True), (2048, 768, 192, 1, True), (777, 192, 768, 0, True),
+    (1531, 1152, 384, 0, True), (513, 1536, 384, 1, True), (300, 384, 1536, 0, True), (999, 384, 768, 0, False),
+    (1234, 160, 384, 0, True), (321, 64, 384, 0, True), (650, 192, 112, 0, True), (128, 128, 16, 0, False),
+])
+def test_linear(P, M, N, K, act, bias):
+    a = synth.uniform((M, K), 11)
+    w = synth.uniform((N, K), 12, 1.0 / K ** 0.5)
+    b = synth.uniform((N,), 13, 0.5) if bias else None
+    ref = a @ w.t()
+    if bias:
+        ref = ref + b
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    got = P.ops.linear(a.cuda(), w.cuda(), b.cuda() if bias else None, act=act)
+    assert rel_err(got, ref) < TIGHT
+
+
+def test_linear_strided_rows(P):
+    a_full = synth.uniform((700, 384), 21).cuda()
+    w = synth.uniform((192, 192), 22, 0.07).cuda()
+    out_full = torch.zeros((700, 384), device="cuda")
+    P.ops.linear(a_full[:, 192:], w, None, out=out_full[:, :192])
+    ref = a_full[:, 192:].cpu() @ w.cpu().t()
+    assert rel_err(out_full[:, :192], ref) < TIGHT
+    assert float(out_full[:, 192:].abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------- attention core
+@pytest.mark.parametrize("C", [192, 384])
+@pytest.mark.parametrize("shifted", [False, True])
+def test_window_attention_core(P, C, shifted):
+    st = cases.STAGES[C]
+    Z, H, W, heads = st["Z"], st["H"], 24, st["heads"]
+    N = Z * H * W
+    qkv = synth.uniform((1, N, 3 * C), 31, 1.5)
+    b1 = synth.uniform((3 * C,), 32, 0.5)
+    esb = synth.uniform((1, st["types"], heads, 144, 144), 33, 0.5)
+    ref, ref_lse = O.window_attention_core(qkv, b1, esb, Z, H, W, heads, shifted)
+    got, lse = P.ops.window_attention(qkv[0].cuda(), b1.cuda(), esb[0].cuda(), Z, H, W, heads, shifted, want_lse=True)
+    assert rel_err(got, ref[0]) < TIGHT
+    assert rel_err(lse, ref_lse[0]) < TIGHT
+
+
+# ---------------------------------------------------------------- row kernels
+@pytest.mark.parametrize("C", [192, 384, 768])
+def test_ln_residual(P, C):
+    N = 1003
+    y, sc = synth.uniform((N, C), 41, 2.0, 0.3), synth.uniform((N, C), 42)
+    g, b = synth.uniform((C,), 43, 0.1, 1.0), synth.uniform((C,), 44, 0.1)
+    ref = sc + 1.25 * torch.nn.functional.layer_norm(y, (C,), g, b)
+    got, stats = P.ops.ln_residual(y.cuda(), sc.cuda(), g.cuda(), b.cuda(), branch_scale=1.25, want_stats=True)
+    assert rel_err(got, ref) < TIGHT
+    assert rel_err(stats[:, 0], y.mean(1)) < TIGHT
+    assert rel_err(stats[:, 1], (y.var(1, unbiased=False) + 1e-5).rsqrt()) < TIGHT
+
+
+def test_downsample_upsample(P):
+    Z, H, W, C = 8, 181, 24, 192
+    p = {k: synth.synth_param(k, s) for k, s in cases.model_param_shapes().items()
+         if k.startswith(("downsample.", "upsample."))}
+    x = synth.uniform((1, Z * H * W, C), 51)
+    ref = O.down_sample(p, x, Z, H, W)
+    g = P.ops.downsample_ln(x[0].cuda(), p["downsample.norm.weight"].cuda(), p["downsample.norm.bias"].cuda(), Z, H, W)
+    got = P.ops.linear(g, p["downsample.linear.weight"].cuda())
+    assert rel_err(got, ref[0]) < TIGHT
+    H2, W2 = 91, 12
+    x2 = synth.uniform((1, Z * H2 * W2, 384), 52)
+    ref = O.up_sample(p, x2, Z, H2, W2, H)
+    y = P.ops.linear(x2[0].cuda(), p["upsample.linear1.weight"].cuda())
+    g = P.ops.upsample_ln(y, p["upsample.norm.weight"].cuda(), p["upsample.norm.bias"].cuda(), Z, H2, W2, H)
+    got = P.ops.linear(g, p["upsample.linear2.weight"].cuda())
+    assert rel_err(got, ref[0]) < TIGHT
+
+
+def test_patch_embed_gather_and_recover_small(P):
+    """Ragged sizes: LAT not a multiple of 4, W4 not a multiple of the 64-token chunk."""
+    LAT, LON = 41, 4 * 70
+    H4, W4 = 11, 70
+    g = lambda n, s, sc=1.0, sh=0.0: synth.uniform(s, synth.name_seed(n), sc, sh)
+    inp, inp_s = g("i", (1, 5, 13, LAT, LON)), g("is", (1, 4, LAT, LON))
+    stats = (g("sm", (4,), 0.3), g("ss", (4,), 0.2, 1.2), g("um", (13, 1, 1, 5), 0.3), g("us", (13, 1, 1, 5), 0.2, 1.2))
+    maps, const_h = g("m", (1, 3, 4 * H4, LON)), g("c", (1, 1, 1, 13, LAT, LON))
+    ra_s, ra_u = O.patch_embed_matrices(inp, inp_s, stats, maps, const_h)
+    a_s, a_u = P.ops.patch_embed_gather(inp[0].cuda(), inp_s[0].cuda(), stats[0].cuda(), stats[1].cuda(),
+                                        stats[2].reshape(13, 5).cuda(), stats[3].reshape(13, 5).cuda(),
+                                        maps[0].cuda(), const_h.reshape(13, LAT, LON).cuda())
+    assert rel_err(a_s, ra_s[0]) < 1e-6 and rel_err(a_u, ra_u[0]) < 1e-6
+    # recover: scatter of random GEMM outputs == oracle's un-patchify with identity convs
+    yu, ys = g("yu", (7 * H4 * W4, 160)), g("ys", (H4 * W4, 64))
+    o, os_ = P.ops.patch_recover_scatter(yu.cuda(), ys.cuda(), LAT, LON)
+    ro = yu.view(7, H4, W4, 5, 2, 4, 4).permute(3, 0, 4, 1, 5, 2, 6).reshape(5, 14, 4 * H4, LON)[:, :13, :LAT]
+    rs = ys.view(H4, W4, 4, 4, 4).permute(2, 0, 3, 1, 4).reshape(4, 4 * H4, LON)[:, :LAT]
+    assert torch.equal(o.cpu(), ro) and torch.equal(os_.cpu(), rs)
+
+
+# ---------------------------------------------------------------- block level vs reference golden + oracle
+def _load_block(P, C, roll):
+    st = cases.STAGES[C]
+    blk = P.layers.EarthSpecificBlock(C, 0.1, st["heads"], device="cuda").cuda().eval()
+    pre = cases.block_prefix(C, roll)
+    blk.load_state_dict({k: synth.synth_param(pre + k, s, "cuda") for k, s in cases.block_param_shapes(C).items()})
+    return blk, st
+
+
+@pytest.mark.parametrize("C", [192, 384])
+@pytest.mark.parametrize("roll", [False, True])
+def test_block_forward_golden(P, golden_dir, C, roll):
+    tag = f"block_{C}_{int(roll)}"
+    g = np.load(os.path.join(golden_dir, tag + ".npz"))
+    blk, st = _load_block(P, C, roll)
+    x = cases.block_input(C, 24, "cuda")
+    with torch.no_grad():
+        y = blk(x, st["Z"], st["H"], 24, roll)
+    assert cases.compare_summary(y, g, tag + ".out", REL) < TIGHT
+
+
+@pytest.mark.parametrize("C,W", [(192, 12), (384, 36)])
+def test_block_forward_oracle_other_widths(P, C, W):
+    blk, st = _load_block(P, C, True)
+    x = cases.block_input(C, W, "cuda")
+    with torch.no_grad():
+        y = blk(x, st["Z"], st["H"], W, True)
+    p = cases.block_params(C, True)
+    ref = O.earth_block(p, cases.block_prefix(C, True), x.cpu(), st["Z"], st["H"], W, st["heads"], True)
+    assert rel_err(y, ref) < TIGHT
+
+
+# ---------------------------------------------------------------- full-resolution layers and model
+def _model(P):
+    m = P.PanguModel(device="cuda").cuda().eval()
+    m.load_state_dict(synth.fill_state_dict(cases.model_param_shapes(), "cuda"))
+    return m
+
+
+def test_fullres_layers_golden(P, golden_dir):
+    g = np.load(os.path.join(golden_dir, "layers_fullres.npz"))
+    m = _model(P)
+    inp, inp_s, stats, maps, const_h = cases.model_inputs("cuda")
+    with torch.no_grad():
+        x0 = m._input_layer(inp, inp_s, stats, maps, const_h)
+        assert x0.shape == (1, 521280, 192)
+        assert cases.compare_summary(x0, g, "embed.out", REL) < TIGHT
+        xin = synth.uniform((1, 8 * 181 * 360, 192), synth.name_seed("down_in"), device="cuda")
+        assert cases.compare_summary(m.downsample(xin, 8, 181, 360), g, "down.out", REL) < TIGHT
+        xin = synth.uniform((1, 8 * 91 * 180, 384), synth.name_seed("up_in"), device="cuda")
+        assert cases.compare_summary(m.upsample(xin), g, "up.out", REL) < TIGHT
+        xin = synth.uniform((1, 8 * 181 * 360, 384), synth.name_seed("recover_in"), device="cuda")
+        o, os_ = m._output_layer(xin, 8, 181, 360)
+        assert o.shape == (1, 5, 13, 721, 1440) and os_.shape == (1, 4, 721, 1440)
+        assert cases.compare_summary(o, g, "recover.out", REL) < TIGHT
+        assert cases.compare_summary(os_, g, "recover.out_surface", REL) < TIGHT
+
+
+def test_full_model_forward_golden(P, golden_dir):
+    """BASELINE config 2: single-GPU fp32 forward, parity vs the reference's CPU forward <= 1e-3."""
+    path = os.path.join(golden_dir, "model_fwd.npz")
+    if not os.path.exists(path):
+        pytest.skip("model_fwd.npz not generated")
+    g = np.load(path)
+    m = _model(P)
+    inp, inp_s, stats, maps, const_h = cases.model_inputs("cuda")
+    with torch.no_grad():
+        out, out_s = m(inp, inp_s, stats, maps, const_h)
+    assert out.shape == (1, 5, 13, 721, 1440) and out_s.shape == (1, 4, 721, 1440)
+    assert torch.isfinite(out).all() and torch.isfinite(out_s).all()
+    assert cases.compare_summary(out, g, "model.out", REL) < REL
+    assert cases.compare_summary(out_s, g, "model.out_surface", REL) < REL
+    # two-argument call with registered constants gives the same result
+    m.set_constants(stats, maps, const_h)
+    with torch.no_grad():
+        out2, _ = m(inp, inp_s)
+    assert torch.equal(out, out2)

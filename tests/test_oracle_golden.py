@@ -1,0 +1,99 @@
+"""Pin the CPU oracle (oracle/pangu_oracle.py) to golden vectors produced by the reference itself
+(oracle/gen_golden.py, run in the build container against /root/reference)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import pangu_oracle as O
+import synth
+
+FP_TOL = 2e-5      # fp32 CPU restatement vs fp32 CPU reference: summation-order noise only
+
+
+def _load(golden_dir, name):
+    path = os.path.join(golden_dir, name)
+    if not os.path.exists(path):
+        pytest.skip(f"{name} not generated")
+    return np.load(path)
+
+
+def test_position_index_bit_exact(golden_dir):
+    g = _load(golden_dir, "index.npz")
+    mine = O.position_index()
+    assert mine.dtype == torch.int64 and mine.shape == (20736,)
+    assert np.array_equal(mine.numpy(), g["position_index"].astype(np.int64))
+    meta = json.load(open(os.path.join(golden_dir, "index_meta.json")))
+    assert hashlib.sha256(mine.numpy().tobytes()).hexdigest()[:16] == meta["position_index_sha"]
+    assert meta["position_index_sha"] == "514371e088c3a008"        # SURVEY.md §7 probe value
+
+
+@pytest.mark.parametrize("C", [192, 384])
+def test_shift_mask_bit_exact(golden_dir, C):
+    g = _load(golden_dir, "index.npz")
+    st = cases.STAGES[C]
+    m = O.shift_mask(st["Z"], st["H"], 24)
+    assert m.shape == (st["types"], 144, 144)
+    assert set(m.unique().tolist()) == {0.0, -100.0}
+    assert np.array_equal(np.packbits((m != 0).numpy()), g[f"mask_bits_{C}"])
+    # closed form == region-id derivation, for every longitude window
+    long_way = O.shift_mask_region_ids(st["Z"], st["H"], 24)
+    for l in range(long_way.shape[0]):
+        assert torch.equal(long_way[l], m)
+
+
+@pytest.mark.parametrize("C", [192, 384])
+def test_shift_mask_full_size_sha(C):
+    """sha256-16 of the full (nLon,types,144,144) fp32 mask measured on the reference."""
+    st = cases.STAGES[C]
+    W = 360 if C == 192 else 180
+    m = O.shift_mask(st["Z"], st["H"], W)
+    h = hashlib.sha256()
+    for _ in range(W // 12):
+        h.update(m.numpy().tobytes())
+    assert h.hexdigest()[:16] == {192: "10f6f498518d3c73", 384: "7fe79f2147d4b92c"}[C]
+
+
+@pytest.mark.parametrize("C", [192, 384])
+@pytest.mark.parametrize("roll", [False, True])
+def test_window_index_bit_exact(golden_dir, C, roll):
+    g = _load(golden_dir, "index.npz")
+    st = cases.STAGES[C]
+    idx = O.window_source_index(st["Z"], st["H"], 24, roll)
+    assert idx.dtype == torch.int32
+    assert np.array_equal(idx.numpy(), g[f"win_index_{C}_{int(roll)}"])
+    # every real token appears exactly once
+    flat = idx[idx >= 0].long()
+    assert flat.numel() == st["Z"] * st["H"] * 24 and flat.unique().numel() == flat.numel()
+
+
+@pytest.mark.parametrize("C", [192, 384])
+@pytest.mark.parametrize("roll", [False, True])
+def test_block_forward_backward(golden_dir, C, roll):
+    tag = f"block_{C}_{int(roll)}"
+    g = _load(golden_dir, tag + ".npz")
+    st = cases.STAGES[C]
+    p = {k: v.requires_grad_(True) for k, v in cases.block_params(C, roll).items()}
+    x = cases.block_input(C, 24).requires_grad_(True)
+    pre = cases.block_prefix(C, roll)
+    y = O.earth_block(p, pre, x, st["Z"], st["H"], 24, st["heads"], roll)
+    assert cases.compare_summary(y, g, tag + ".out", FP_TOL) < FP_TOL
+    (y * cases.cotangent(tag, y.shape)).sum().backward()
+    assert cases.compare_summary(x.grad, g, tag + ".dx", FP_TOL) < 5 * FP_TOL
+    for k in cases.block_param_shapes(C):
+        err = cases.compare_summary(p[pre + k].grad, g, tag + ".d_" + k, FP_TOL)
+        assert err < 10 * FP_TOL, (k, err)
+
+
+def test_state_dict_contract(golden_dir):
+    path = os.path.join(golden_dir, "keys_shapes.json")
+    if not os.path.exists(path):
+        pytest.skip("keys_shapes.json not generated")
+    ks = json.load(open(path))
+    mine = cases.model_param_shapes()
+    assert len(mine) == 223 and ks["n_params"] == 276659936
+    assert {k: list(v) for k, v in mine.items()} == ks["state_dict"]
