@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Headline benchmark: PanguModel forward steps/sec on synthetic 721x1440x(13*5+4) fields, fp32, one sample per GPU.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one `PanguModel.forward` (BASELINE.json configs[1]: single-GPU fp32 forward through the HIP path) on one
+sample resident in HBM.  With N ranks every rank runs its own sample (pure data parallel, no data-path
+collective in inference): value = N*K / max-over-ranks time, "scaling": "weak".
+
+Rank 0 prints ONE JSON line with the contract keys plus
+  roofline      live HIP-event timing of the dominant kernel (the f32 MFMA projection GEMM) over the timed region
+  cpu_baseline  the CPU oracle (oracle/pangu_oracle.py, a port of the reference's algorithm) timed on this host on a
+                bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+FWD_GFLOP = 8421.2          # SURVEY.md §8(a) ledger: dense-contraction GFLOP per forward step
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline():
+    """Time the CPU oracle on a 1/5-longitude slice of each stage and extrapolate to one forward step."""
+    import cases
+    import pangu_oracle as O
+    # pick the thread count torch's CPU backend runs this workload fastest with on this host (the reference's
+    # scripts pin 16: inference/test_main.py:60); huge hosts lose time to oversubscription at cpu_count threads
+    st = cases.STAGES[384]
+    xs, ps, pre = cases.block_input(384, 12), cases.block_params(384, False), cases.block_prefix(384, False)
+    best = (1e30, 1)
+    for nt in (8, 16, 32, 64, 128):
+        if nt > (os.cpu_count() or 1):
+            break
+        torch.set_num_threads(nt)
+        with torch.no_grad():
+            O.earth_block(ps, pre, xs, st["Z"], st["H"], 12, st["heads"], False)
+            t0 = time.perf_counter()
+            O.earth_block(ps, pre, xs, st["Z"], st["H"], 12, st["heads"], False)
+            best = min(best, (time.perf_counter() - t0, nt))
+    threads = best[1]
+    torch.set_num_threads(threads)
+    t_total = 0.0
+    parts = {}
+    with torch.no_grad():
+        for C, W, pairs in ((192, 72, 2), (384, 36, 6)):
+            st = cases.STAGES[C]
+            x = cases.block_input(C, W)
+            t_pair = 0.0
+            for roll in (False, True):
+                p = cases.block_params(C, roll)
+                pre = cases.block_prefix(C, roll)
+                O.earth_block(p, pre, x[:, :st["Z"] * st["H"] * 12], st["Z"], st["H"], 12, st["heads"], roll)  # warm
+                t0 = time.perf_counter()
+                O.earth_block(p, pre, x, st["Z"], st["H"], W, st["heads"], roll)
+                t_pair += time.perf_counter() - t0
+            parts[C] = t_pair
+            t_total += 5.0 * pairs * t_pair
+    return {
+        "value": 1.0 / t_total, "unit": "forward steps/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
+        "sample": ("oracle earth_block pairs (unshifted+shifted) on a 1/5-longitude slice: C=192 at 8x181x72 "
+                   f"({parts[192]:.2f}s), C=384 at 8x91x36 ({parts[384]:.2f}s); extrapolated x5 to the 4+12 blocks of one "
+                   "forward (embed/recover/resample excluded, <4% of FLOPs)"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import cases
+    import synth
+    import pangu_pytorch_amd as P
+    from pangu_pytorch_amd import ops
+
+    dev = torch.device("cuda", local_rank)
+    torch.manual_seed(0)
+    model = P.PanguModel(device=dev).to(dev).eval()          # random-init weights of the real architecture
+    inp, inp_s, stats, maps, const_h = cases.model_inputs(dev)
+    if rank:
+        inp = synth.uniform(inp.shape, 1000 + rank, device=dev)      # a different sample per rank
+
+    def step():
+        with torch.no_grad():
+            return model(inp, inp_s, stats, maps, const_h)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ops.timing_start()                     # HIP-event pairs around every GEMM launch of the timed region
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    gemm_ms, gemm_flop, gemm_launches = ops.timing_stop("linear")
+    assert torch.isfinite(out[0]).all()
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        res = {
+            "metric": "forward steps/sec (721x1440x13pl) per MI355X", "value": world * args.steps / elapsed,
+            "unit": "forward steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "PanguModel fp32 forward, 1 sample/GPU, input (1,5,13,721,1440)+(1,4,721,1440), "
+                                   "depths 2-6-6-2, dims 192/384, random-init weights (BASELINE configs[1])",
+                       "parallelism": f"dp{world}"},
+            "model_tflops": FWD_GFLOP / ms,
+            "roofline": {"bound": "mfma", "kernel": "gemm_tn_f32_kernel (all projection GEMMs)", "achieved": achieved,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": None, "launches": gemm_launches, "avg_launch_ms": gemm_ms / max(gemm_launches, 1),
+                         "share_of_step": gemm_ms / (ms * args.steps)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -122,22 +122,39 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_kernel(const float* __rest
     __syncthreads();
   }
 
-  // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+  // Each 32x32 tile is transposed through a wave-private LDS patch (aliasing the staging buffers, free after
+  // the loop's last barrier) so that a lane stores 16 B and a wave-instruction covers 8 rows x 128 B:
+  // 24 global_store_dwordx4 per lane instead of 96 dword stores (the store tail is issue-bound).
+  constexpr int EP_LD = 36;
+  float* ep = &smem[0][0] + wave * (32 * EP_LD);
+  const int er = lane >> 3, ec = (lane & 7) * 4;
+  // Branch-free tail handling: stores go through a buffer descriptor whose range check drops rows >= M (and
+  // lanes whose column is >= N are pointed past the range).  Divergent branches around the stores would make
+  // hipcc serialise them with s_waitcnt vmcnt(0).
+  const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      C, 0, (int)(((size_t)(M - 1) * ldc + N) * sizeof(float)), 0x00020000);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn * 32 * TN + j * 32 + lr;
-    const bool col_ok = col < N;
-    float bv = 0.f;
-    if (HAS_BIAS) bv = bias[col_ok ? col : N - 1];
+    const int col = n0 + wn * 32 * TN + j * 32 + ec;
+    const bool col_ok = col < N;            // N % 4 == 0 is enforced by the launcher
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (HAS_BIAS) bv = *reinterpret_cast<const f32x4*>(bias + (col_ok ? col : 0));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int row0 = m0 + wm * 64 + i * 32 + 4 * lh;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + (r & 3) + 8 * (r >> 2);
-        float v = acc[i][j][r] + bv;
-        if (ACT == PANGU_ACT_GELU) v = gelu_erf(v);
-        if (col_ok && row < M) C[(size_t)row * ldc + col] = v;
+      for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2) + 4 * lh) * EP_LD + lr] = acc[i][j][r];
+      const int row0 = m0 + wm * 64 + i * 32 + er;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(&ep[(er + 8 * it) * EP_LD + ec]);
+        v += bv;
+        if (ACT == PANGU_ACT_GELU) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = gelu_erf(v[c]);
+        }
+        const unsigned off = col_ok ? ((unsigned)(row0 + 8 * it) * (unsigned)ldc + (unsigned)col) * 4u : 0xFFFFFFFFu;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), c_rsrc, (int)off, 0, 0);
       }
     }
   }
@@ -166,7 +183,8 @@ int launch_tn(hipStream_t s, const float* A, int lda, const float* W, const floa
 extern "C" int pangu_linear_fwd(pangu_stream_t stream, const float* A, int lda, const float* W, const float* bias,
                                 float* C, int ldc, int M, int N, int K, int act) {
   if (!A || !W || !C) return PANGU_E_NULL;
-  if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || lda < K || ldc < N || (lda & 3)) return PANGU_E_SHAPE;
+  if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || (N & 3) || lda < K || ldc < N || (lda & 3) || (ldc & 3))
+    return PANGU_E_SHAPE;
   if (act != PANGU_ACT_NONE && act != PANGU_ACT_GELU) return PANGU_E_ARG;
   hipStream_t s = (hipStream_t)stream;
   // widest tile that divides N (192 covers every projection of this model except the recovery convs)

@@ -8,6 +8,41 @@ from . import _lib
 
 ACT_NONE, ACT_GELU = 0, 1
 
+# Optional live kernel timing (bench.py): HIP events recorded on the launch stream around each launch.
+_timing = None
+
+
+def timing_start():
+    global _timing
+    _timing = []
+
+
+def timing_stop(kind):
+    """-> (total ms, total algorithmic FLOP (or bytes), launches) of the launches tagged `kind`; stops timing."""
+    global _timing
+    rec, _timing = _timing or [], None
+    torch.cuda.synchronize()
+    ms = sum(a.elapsed_time(b) for k, a, b, w in rec if k == kind)
+    work = sum(w for k, a, b, w in rec if k == kind)
+    return ms, work, sum(1 for r in rec if r[0] == kind)
+
+
+class _timed:
+    def __init__(self, kind, work):
+        self.kind, self.work = kind, work
+
+    def __enter__(self):
+        if _timing is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record(torch.cuda.current_stream())
+
+    def __exit__(self, *exc):
+        if _timing is not None:
+            self.b.record(torch.cuda.current_stream())
+            _timing.append((self.kind, self.a, self.b, self.work))
+
+
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
@@ -61,7 +96,8 @@ def linear(a, weight, bias=None, act=ACT_NONE, out=None):
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     op, ldc = _rows(out, "linear.out")
-    _lib.check(lib.pangu_linear_fwd(_stream(), ap, lda, wp, bp, op, ldc, M, N, K, act), "linear_fwd")
+    with _timed("linear", 2.0 * M * N * K):
+        _lib.check(lib.pangu_linear_fwd(_stream(), ap, lda, wp, bp, op, ldc, M, N, K, act), "linear_fwd")
     return out
 
 
@@ -73,9 +109,11 @@ def window_attention(qkv, qkv_bias, esb, Z, H, W, heads, shifted, want_lse=False
         raise RuntimeError(f"window_attention: {N} tokens != {Z}x{H}x{W}")
     out = torch.empty((N, C), dtype=torch.float32, device=qkv.device)
     lse = torch.empty((N, heads), dtype=torch.float32, device=qkv.device) if want_lse else None
-    _lib.check(lib.pangu_window_attn_fwd(_stream(), _chk(qkv, "qkv"), _chk(qkv_bias, "qkv_bias"), _chk(esb, "esb"),
-                                         out.data_ptr(), lse.data_ptr() if want_lse else None, Z, H, W, C, heads,
-                                         int(shifted)), "window_attn_fwd")
+    Np = (Z // 2) * ((H + 5) // 6) * (W // 12) * 144          # padded token count: the core's FLOPs (4*Np*144*C)
+    with _timed("attn", 4.0 * Np * 144 * C):
+        _lib.check(lib.pangu_window_attn_fwd(_stream(), _chk(qkv, "qkv"), _chk(qkv_bias, "qkv_bias"), _chk(esb, "esb"),
+                                             out.data_ptr(), lse.data_ptr() if want_lse else None, Z, H, W, C, heads,
+                                             int(shifted)), "window_attn_fwd")
     return (out, lse) if want_lse else out
 
 

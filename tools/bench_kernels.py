@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Per-shape kernel micro-benchmarks on one MI355X (development tool, not the headline bench).
+
+  python tools/bench_kernels.py gemm|attn|rows [--lib-compare]
+`--lib-compare` also times torch.matmul (hipBLASLt/rocBLAS) on the same shapes as an external yardstick."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import torch  # noqa: E402
+import pangu_pytorch_amd as P  # noqa: E402
+from pangu_pytorch_amd import ops  # noqa: E402
+
+GEMM_SHAPES = [  # (M, N, K, act, name)
+    (521280, 576, 192, 0, "s0 qkv"), (521280, 192, 192, 0, "s0 proj"), (521280, 768, 192, 1, "s0 mlp1+gelu"),
+    (521280, 192, 768, 0, "s0 mlp2"), (131040, 1152, 384, 0, "s1 qkv"), (131040, 384, 384, 0, "s1 proj"),
+    (131040, 1536, 384, 1, "s1 mlp1+gelu"), (131040, 384, 1536, 0, "s1 mlp2"), (131040, 384, 768, 0, "down"),
+    (131040, 768, 384, 0, "up1"), (456120, 192, 192, 0, "embed"), (456120, 160, 384, 0, "recover"),
+]
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def gemm(lib_compare):
+    tot = tot_lib = 0.0
+    for M, N, K, act, name in GEMM_SHAPES:
+        a = torch.randn(M, K, device="cuda")
+        w = torch.randn(N, K, device="cuda") / K ** 0.5
+        b = torch.randn(N, device="cuda")
+        out = torch.empty(M, N, device="cuda")
+        ms = timeit(lambda: ops.linear(a, w, b, act=act, out=out))
+        line = f"{name:14s} M={M:6d} N={N:4d} K={K:4d}  {ms:7.3f} ms  {2.0 * M * N * K / ms / 1e9:6.1f} TF/s"
+        if lib_compare:
+            f = (lambda: torch.nn.functional.gelu(torch.addmm(b, a, w.t()))) if act else (lambda: torch.addmm(b, a, w.t()))
+            ms2 = timeit(f)
+            line += f"   | torch {ms2:7.3f} ms {2.0 * M * N * K / ms2 / 1e9:6.1f} TF/s"
+        print(line)
+
+
+def attn():
+    for C, Z, H, W, heads, types in ((192, 8, 181, 360, 6, 124), (384, 8, 91, 180, 12, 64)):
+        N = Z * H * W
+        qkv = torch.randn(N, 3 * C, device="cuda")
+        b1 = torch.randn(3 * C, device="cuda")
+        esb = torch.randn(types, heads, 144, 144, device="cuda") * 0.1
+        for sh in (False, True):
+            ms = timeit(lambda: ops.window_attention(qkv, b1, esb, Z, H, W, heads, sh))
+            Np = (Z // 2) * ((H + 5) // 6) * (W // 12) * 144
+            fl = 4.0 * Np * 144 * C
+            by = (N * 4 * C + esb.numel()) * 4.0
+            print(f"attn C={C} shifted={int(sh)}: {ms:7.3f} ms  {fl / ms / 1e9:6.1f} TF/s  {by / ms / 1e6:7.1f} GB/s (algorithmic)")
+
+
+def rows():
+    for N, C in ((521280, 192), (131040, 384)):
+        y, s = torch.randn(N, C, device="cuda"), torch.randn(N, C, device="cuda")
+        g, b = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+        out = torch.empty_like(y)
+        ms = timeit(lambda: ops.ln_residual(y, s, g, b, out=out))
+        print(f"ln_residual N={N} C={C}: {ms:7.3f} ms  {3.0 * N * C * 4 / ms / 1e6:7.1f} GB/s")
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
+    {"gemm": lambda: gemm("--lib-compare" in sys.argv), "attn": attn, "rows": rows}[what]()
