@@ -38,7 +38,8 @@ extern "C" {
 #define PANGU_BF16 1
 
 #define PANGU_ACT_NONE 0
-#define PANGU_ACT_GELU 1       /* exact erf GELU, reference layers.py:261 */
+#define PANGU_ACT_GELU 1       /* exact erf GELU, reference layers.py:261; aux (optional) receives the pre-activation */
+#define PANGU_ACT_GELU_BWD 2   /* C = (A @ W^T) * gelu'(aux): backward through the GELU, aux = saved pre-activation */
 
 typedef void* pangu_stream_t;  /* hipStream_t */
 
@@ -57,10 +58,18 @@ int pangu_window_mask_export(pangu_stream_t stream, float* out, int Z, int H, in
 /* ---- dense projections ---------------------------------------------------------------------------- */
 
 /* C[M,N] = act(A[M,K] @ W[N,K]^T + bias[N]).  W is the torch nn.Linear / Conv1d(k=1) weight as stored
- * (out,in).  bias may be NULL.  K % 16 == 0.  Replaces nn.Linear / nn.Conv1d calls at reference
- * layers.py:68,86,265-268,365,418,457,476,498,520,536. */
+ * (out,in).  bias may be NULL.  K % 16 == 0, N % 4 == 0.  aux [M][N] (dense): see PANGU_ACT_*; NULL otherwise.
+ * Replaces nn.Linear / nn.Conv1d calls at reference layers.py:68,86,265-268,365,418,457,476,498,520,536.
+ * The input-gradient of a projection is the same call with W^T: dA[M,K] = dC[M,N] @ (W^T)[K,N]^T. */
 int pangu_linear_fwd(pangu_stream_t stream, const float* A, int lda, const float* W, const float* bias,
-                     float* C, int ldc, int M, int N, int K, int act);
+                     float* C, int ldc, int M, int N, int K, int act, float* aux);
+
+/* Weight/bias gradient of a projection (autograd of the calls above; the training step of reference
+ * models/pangu_sample.py:71 `loss.backward()`):
+ *   dW[N,K] += dC[M,N]^T @ A[M,K]      db[N] += sum_m dC[m,:]   (db may be NULL)
+ * ACCUMULATES with fp32 atomics into caller-initialised buffers (zero them, or pass live .grad buffers). */
+int pangu_linear_wgrad(pangu_stream_t stream, const float* dC, int lddc, const float* A, int lda, float* dW,
+                       float* db, int M, int N, int K);
 
 /* ---- Earth-specific window attention -------------------------------------------------------------- */
 
@@ -75,6 +84,16 @@ int pangu_linear_fwd(pangu_stream_t stream, const float* A, int lda, const float
 int pangu_window_attn_fwd(pangu_stream_t stream, const float* qkv, const float* qkv_bias, const float* esb,
                           float* out, float* lse, int Z, int H, int W, int C, int heads, int shifted);
 
+/* Backward of pangu_window_attn_fwd.  One workgroup per (window type, head) walks the nLon longitude windows
+ * and keeps the bias gradient d_esb[t][head] = sum_l dS in registers (no atomics, written once).
+ *   out, lse: the forward's outputs;  dout [N][C]: gradient w.r.t. out
+ *   dqkv [N][3C]: gradient w.r.t. qkv (every real token is written exactly once per q/k/v)
+ *   dqkv_bias [3C]: ACCUMULATED (atomics) gradient reaching linear1.bias through the zero-pad slots
+ *   d_esb [types][heads][144][144]: overwritten */
+int pangu_window_attn_bwd(pangu_stream_t stream, const float* qkv, const float* qkv_bias, const float* esb,
+                          const float* out, const float* lse, const float* dout, float* dqkv, float* dqkv_bias,
+                          float* d_esb, int Z, int H, int W, int C, int heads, int shifted);
+
 /* ---- row kernels ----------------------------------------------------------------------------------- */
 
 /* out[r] = shortcut[r] + branch_scale * (LayerNorm(y[r]) * gamma + beta)
@@ -85,16 +104,29 @@ int pangu_ln_residual_fwd(pangu_stream_t stream, const float* y, const float* sh
                           const float* gamma, const float* beta, float* out, int ldo, float* mean_rstd,
                           int N, int C, float branch_scale);
 
+/* Backward of the LayerNorm branch of pangu_ln_residual_fwd (the shortcut's gradient is dout itself):
+ *   dy [N][C] overwritten;  dgamma[C], dbeta[C] ACCUMULATED (atomics).  dout may be row-strided (lddo). */
+int pangu_ln_residual_bwd(pangu_stream_t stream, const float* dout, int lddo, const float* y, const float* gamma,
+                          float* dy, float* dgamma, float* dbeta, int N, int C, float branch_scale);
+
 /* DownSample gather + LayerNorm(4C): x[Z][H][W][C] (row stride ldx) -> out[Z*(H+1)/2*(W/2)][4C],
  * channel = dh*2C + dw*C + c, zero row for h == H (pad).  Reference layers.py:436-454. */
 int pangu_downsample_ln_fwd(pangu_stream_t stream, const float* x, int ldx, const float* gamma,
                             const float* beta, float* out, float* mean_rstd, int Z, int H, int W, int C);
+
+/* Backward: dout [rows][4C] -> dx [Z*H*W][C] (overwritten, every token once); dgamma/dbeta [4C] ACCUMULATED. */
+int pangu_downsample_ln_bwd(pangu_stream_t stream, const float* dout, const float* x, int ldx, const float* gamma,
+                            float* dx, float* dgamma, float* dbeta, int Z, int H, int W, int C);
 
 /* UpSample pixel-shuffle + crop + LayerNorm(Co): y[Z][H2][W2][4*Co] -> out[Z][H][2*W2][Co] with
  * out[z][2h+dh][2w+dw][c] = y[z][h][w][dh*2Co + dw*Co + c], rows h >= H dropped.  Reference layers.py:480-495.
  * pre (may be NULL): the shuffled rows before LayerNorm, saved for backward. */
 int pangu_upsample_ln_fwd(pangu_stream_t stream, const float* y, const float* gamma, const float* beta,
                           float* out, float* mean_rstd, int Z, int H2, int W2, int H, int Co);
+
+/* Backward: dout [Z*H*2W2][Co] -> dy [Z*H2*W2][4Co] (overwritten; cropped rows get 0); dgamma/dbeta ACCUMULATED. */
+int pangu_upsample_ln_bwd(pangu_stream_t stream, const float* dout, const float* y, const float* gamma, float* dy,
+                          float* dgamma, float* dbeta, int Z, int H2, int W2, int H, int Co);
 
 /* ---- patch embedding / recovery --------------------------------------------------------------------- */
 
@@ -114,6 +146,11 @@ int pangu_patch_embed_gather(pangu_stream_t stream, const float* input, const fl
  *   y_surface [H4*W4][64]  col = v*16 + ph*4 + pw          -> output_surface [4][LAT][LON] */
 int pangu_patch_recover_scatter(pangu_stream_t stream, const float* y_upper, const float* y_surface,
                                 float* output, float* output_surface, int LAT, int LON);
+
+/* Backward of the scatter: gradients of the two field tensors -> dy_upper [7*H4*W4][160], dy_surface [H4*W4][64]
+ * (cropped positions get 0). */
+int pangu_patch_recover_gather_bwd(pangu_stream_t stream, const float* d_output, const float* d_output_surface,
+                                   float* dy_upper, float* dy_surface, int LAT, int LON);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,179 @@
+"""torch.autograd.Function wrappers: one per reference layer, each a hand-scheduled chain of HIP kernels.
+
+Per-sample 2-D token tensors (N, C).  Nothing of size (..,144,144) is saved: attention backward recomputes
+the probabilities from q, k, v and the per-row log-sum-exp, so a whole training step keeps ~64 GB of fp32
+activations and needs no block re-computation (the reference re-runs every block forward in backward,
+models/layers.py:115-119).
+
+Gradient of a projection y = a @ W^T + b:   da = dy @ W  (the forward GEMM with W^T),  dW, db = wgrad(dy, a).
+"""
+import torch
+
+from . import ops
+
+
+def _wt(w):
+    """(out,in[,1]) weight -> contiguous (in,out): the `W` operand of ops.linear for the input gradient."""
+    return w.reshape(w.shape[0], -1).t().contiguous()
+
+
+class EarthBlockFn(torch.autograd.Function):
+    """reference models/layers.py:183-253 (+ attention :360-421, Mlp :264-270) for one sample."""
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, n2w, n2b, m1w, m1b, m2w, m2b, esb, a1w, a1b, a2w, a2b, geom, s1, s2):
+        Z, H, W, heads, shifted = geom
+        ctx.geom, ctx.s1, ctx.s2 = geom, s1, s2
+        saved = [x, n1w, n2w, m1w, m2w, esb, a1w, a1b, a2w]
+        x1 = x
+        if s1 != 0.0:
+            qkv = ops.linear(x, a1w, a1b)
+            o, lse = ops.window_attention(qkv, a1b, esb[0], Z, H, W, heads, shifted, want_lse=True)
+            y = ops.linear(o, a2w, a2b)
+            x1 = ops.ln_residual(y, x, n1w, n1b, branch_scale=s1)
+            saved += [qkv, o, lse, y]
+        if s2 != 0.0:
+            pre = torch.empty((x.shape[0], m1w.shape[0]), dtype=x.dtype, device=x.device)
+            h = ops.linear(x1, m1w, m1b, act=ops.ACT_GELU, aux=pre)
+            m = ops.linear(h, m2w, m2b)
+            x2 = ops.ln_residual(m, x1, n2w, n2b, branch_scale=s2)
+            saved += [x1, pre, h, m]
+        else:
+            x2 = x1
+        ctx.save_for_backward(*saved)
+        return x2
+
+    @staticmethod
+    def backward(ctx, dout):
+        Z, H, W, heads, shifted = ctx.geom
+        s1, s2 = ctx.s1, ctx.s2
+        sv = list(ctx.saved_tensors)
+        x, n1w, n2w, m1w, m2w, esb, a1w, a1b, a2w = sv[:9]
+        rest = sv[9:]
+        if s1 != 0.0:
+            qkv, o, lse, y = rest[:4]
+            rest = rest[4:]
+        g = {k: None for k in ("n1w", "n1b", "n2w", "n2b", "m1w", "m1b", "m2w", "m2b", "esb", "a1w", "a1b", "a2w", "a2b")}
+        dx1 = dout
+        if s2 != 0.0:
+            x1, pre, h, m = rest
+            dm, g["n2w"], g["n2b"] = ops.ln_residual_bwd(dout, m, n2w, s2)
+            g["m2w"], g["m2b"] = ops.linear_wgrad(dm, h)
+            dpre = ops.linear(dm, _wt(m2w), None, act=ops.ACT_GELU_BWD, aux=pre)
+            del dm
+            g["m1w"], g["m1b"] = ops.linear_wgrad(dpre, x1)
+            dx1 = ops.linear(dpre, _wt(m1w))
+            del dpre
+            dx1 += dout
+        dx = dx1
+        if s1 != 0.0:
+            dy, g["n1w"], g["n1b"] = ops.ln_residual_bwd(dx1, y, n1w, s1)
+            g["a2w"], g["a2b"] = ops.linear_wgrad(dy, o)
+            do = ops.linear(dy, _wt(a2w))
+            del dy
+            dqkv, dqb_pad, desb = ops.window_attention_bwd(qkv, a1b, esb[0], o, lse, do, Z, H, W, heads, shifted)
+            del do
+            g["esb"] = desb.unsqueeze(0)
+            g["a1w"], g["a1b"] = ops.linear_wgrad(dqkv, x)
+            g["a1b"] += dqb_pad
+            dx = ops.linear(dqkv, _wt(a1w))
+            dx += dx1
+        elif not dx.is_contiguous():
+            dx = dx.contiguous()
+        return (dx, g["n1w"], g["n1b"], g["n2w"], g["n2b"], g["m1w"], g["m1b"], g["m2w"], g["m2b"], g["esb"],
+                g["a1w"], g["a1b"], g["a2w"], g["a2b"], None, None, None)
+
+
+class PatchEmbedFn(torch.autograd.Function):
+    """reference models/layers.py:40-93 for one sample; the raw fields get no gradient."""
+
+    @staticmethod
+    def forward(ctx, cw, cb, sw, sb, inp, inp_s, s_mean, s_std, u_mean, u_std, maps, const_h):
+        a_s, a_u = ops.patch_embed_gather(inp, inp_s, s_mean, s_std, u_mean, u_std, maps, const_h)
+        n_s = a_s.shape[0]
+        x = torch.empty((n_s + a_u.shape[0], cw.shape[0]), dtype=torch.float32, device=inp.device)
+        ops.linear(a_s, sw, sb, out=x[:n_s])
+        ops.linear(a_u, cw, cb, out=x[n_s:])
+        ctx.save_for_backward(a_s, a_u)
+        ctx.shapes = (cw.shape, sw.shape)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        a_s, a_u = ctx.saved_tensors
+        n_s = a_s.shape[0]
+        dsw, dsb = ops.linear_wgrad(dx[:n_s], a_s)
+        dcw, dcb = ops.linear_wgrad(dx[n_s:], a_u)
+        return (dcw.reshape(ctx.shapes[0]), dcb, dsw.reshape(ctx.shapes[1]), dsb) + (None,) * 8
+
+
+class DownSampleFn(torch.autograd.Function):
+    """reference models/layers.py:432-459 for one sample."""
+
+    @staticmethod
+    def forward(ctx, x, lw, nw, nb, geom):
+        Z, H, W = geom
+        g = ops.downsample_ln(x, nw, nb, Z, H, W)
+        ctx.save_for_backward(x, g, lw, nw)
+        ctx.geom = geom
+        return ops.linear(g, lw)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, g, lw, nw = ctx.saved_tensors
+        Z, H, W = ctx.geom
+        dout = dout.contiguous()
+        dlw, _ = ops.linear_wgrad(dout, g, want_bias=False)
+        dg = ops.linear(dout, _wt(lw))
+        dx, dnw, dnb = ops.downsample_ln_bwd(dg, x, nw, Z, H, W)
+        return dx, dlw, dnw, dnb, None
+
+
+class UpSampleFn(torch.autograd.Function):
+    """reference models/layers.py:474-499 for one sample."""
+
+    @staticmethod
+    def forward(ctx, x, l1w, l2w, nw, nb, geom):
+        Z, H2, W2, H = geom
+        y = ops.linear(x, l1w)
+        g = ops.upsample_ln(y, nw, nb, Z, H2, W2, H)
+        ctx.save_for_backward(x, y, g, l1w, l2w, nw)
+        ctx.geom = geom
+        return ops.linear(g, l2w)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y, g, l1w, l2w, nw = ctx.saved_tensors
+        Z, H2, W2, H = ctx.geom
+        dout = dout.contiguous()
+        dl2w, _ = ops.linear_wgrad(dout, g, want_bias=False)
+        dg = ops.linear(dout, _wt(l2w))
+        dy, dnw, dnb = ops.upsample_ln_bwd(dg, y, nw, Z, H2, W2, H)
+        dl1w, _ = ops.linear_wgrad(dy, x, want_bias=False)
+        dx = ops.linear(dy, _wt(l1w))
+        return dx, dl1w, dl2w, dnw, dnb, None
+
+
+class PatchRecoverFn(torch.autograd.Function):
+    """reference models/layers.py:511-545 for one sample: x (N, C) -> (5,13,LAT,LON), (4,LAT,LON)."""
+
+    @staticmethod
+    def forward(ctx, x, cw, cb, sw, sb, geom):
+        n_s, LAT, LON = geom
+        y_s = ops.linear(x[:n_s], sw, sb)
+        y_u = ops.linear(x[n_s:], cw, cb)
+        ctx.save_for_backward(x, cw, sw)
+        ctx.geom = geom
+        return ops.patch_recover_scatter(y_u, y_s, LAT, LON)
+
+    @staticmethod
+    def backward(ctx, d_out, d_out_s):
+        x, cw, sw = ctx.saved_tensors
+        n_s, LAT, LON = ctx.geom
+        dy_u, dy_s = ops.patch_recover_gather_bwd(d_out.contiguous(), d_out_s.contiguous())
+        dcw, dcb = ops.linear_wgrad(dy_u, x[n_s:])
+        dsw, dsb = ops.linear_wgrad(dy_s, x[:n_s])
+        dx = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
+        ops.linear(dy_s, _wt(sw), out=dx[:n_s])
+        ops.linear(dy_u, _wt(cw), out=dx[n_s:])
+        return dx, dcw.reshape(cw.shape), dcb, dsw.reshape(sw.shape), dsb, None

@@ -1,0 +1,243 @@
+// Backward of the Earth-specific window attention, fp32, gfx950.
+//
+// One workgroup of 9 waves per (window type t, head); it walks the nLon longitude windows that share the
+// bias tile esb[t][head], so the bias gradient d_esb[t][head] = sum_l dS stays in registers (36 per wave) and
+// is written once: no atomics, no (..,144,144) tensor in HBM.
+// Per window, Q(scaled), K, V, dO (144 x 32 each) are staged in LDS; P is recomputed from the saved
+// log-sum-exp.  Wave w owns QUERY tile w for {dQ, d_esb} and KEY tile w for {dK, dV}; the scores are computed in
+// both orientations (S^T for the first, S for the second) so that every probability / dS accumulator is
+// directly an MFMA operand of the next product (no LDS transposes, no cross-wave reductions):
+//   phase A (S^T[key][query], query tile w):  dP^T = V dO^T,  dS^T = P^T o (dP^T - delta),  dQ^T = K^T dS^T
+//   phase B (S[query][key],  key tile w):     dP = dO V^T,    dS = P o (dP - delta),  dV = P^T dO,  dK = dS^T Qs
+// 504 v_mfma_f32_16x16x4_f32 per wave and window.  Zero-pad slots (q/k/v = linear1.bias) send their k/v gradient
+// to dqkv_bias with atomics (2.7 % of slots); every real token row of dqkv is written exactly once.
+#include "common.h"
+
+namespace {
+
+constexpr int KV_LD = 36;
+constexpr int NW = 9;                      // waves per workgroup = query tiles = key tiles
+constexpr int NT = NW * 64;
+
+template <bool SHIFTED>
+__global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ esb,
+    const float* __restrict__ out, const float* __restrict__ lse, const float* __restrict__ dout,
+    float* __restrict__ dqkv, float* __restrict__ dqkv_bias, float* __restrict__ d_esb, WinGeom g, int C, int heads) {
+  __shared__ __attribute__((aligned(16))) float Qs[PANGU_WTOK * KV_LD];
+  __shared__ __attribute__((aligned(16))) float Ks[PANGU_WTOK * KV_LD];
+  __shared__ __attribute__((aligned(16))) float Vs[PANGU_WTOK * KV_LD];
+  __shared__ __attribute__((aligned(16))) float Gs[PANGU_WTOK * KV_LD];     // dO
+  __shared__ __attribute__((aligned(16))) float lse_s[PANGU_WTOK];
+  __shared__ __attribute__((aligned(16))) float del_s[PANGU_WTOK];
+  __shared__ int tok_s[PANGU_WTOK];
+
+  const int pair = blockIdx.x;
+  const int t = pair / heads, hd = pair - t * heads;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 15, lg = lane >> 4;
+  const int C3 = 3 * C;
+  const float scale = 0.17677669529663687f;
+  const float* bias_tile = esb + (size_t)pair * PANGU_WTOK * PANGU_WTOK;
+
+  bool zcut = false, hcut = false;
+  if (SHIFTED) {
+    const int zwin = t / g.nHw, hwin = t - zwin * g.nHw;
+    zcut = zwin == g.nZw - 1;
+    hcut = hwin == g.nHw - 1;
+  }
+  auto masked = [&](int nq, int nk) -> bool {
+    const bool zd = (nq >= 72) != (nk >= 72);
+    const bool hdiff = (((nq / 12) % 6) < 3) != (((nk / 12) % 6) < 3);
+    return (zcut && zd) || (hcut && hdiff);
+  };
+
+  f32x4 dbias[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) dbias[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int l = 0; l < g.nLon; ++l) {
+    __syncthreads();                               // previous window's LDS reads are done
+    if (tid < PANGU_WTOK) tok_s[tid] = win_src_token(g, l, t, tid, SHIFTED);
+    __syncthreads();
+    // ---- stage Qs (scaled), K, V, dO; delta = rowsum(dO o O); lse
+    for (int f = tid; f < PANGU_WTOK * 8; f += NT) {
+      const int n = f >> 3, c4 = (f & 7) * 4;
+      const int tok = tok_s[n];
+      const float* src = tok >= 0 ? qkv + (size_t)tok * C3 : qkv_bias;
+      f32x4 qv = *reinterpret_cast<const f32x4*>(src + hd * 32 + c4);
+      const f32x4 kv = *reinterpret_cast<const f32x4*>(src + C + hd * 32 + c4);
+      const f32x4 vv = *reinterpret_cast<const f32x4*>(src + 2 * C + hd * 32 + c4);
+      f32x4 gv = {0.f, 0.f, 0.f, 0.f}, ov = {0.f, 0.f, 0.f, 0.f};
+      if (tok >= 0) {
+        gv = *reinterpret_cast<const f32x4*>(dout + (size_t)tok * C + hd * 32 + c4);
+        ov = *reinterpret_cast<const f32x4*>(out + (size_t)tok * C + hd * 32 + c4);
+      }
+      qv *= scale;
+      *reinterpret_cast<f32x4*>(&Qs[n * KV_LD + c4]) = qv;
+      *reinterpret_cast<f32x4*>(&Ks[n * KV_LD + c4]) = kv;
+      *reinterpret_cast<f32x4*>(&Vs[n * KV_LD + c4]) = vv;
+      *reinterpret_cast<f32x4*>(&Gs[n * KV_LD + c4]) = gv;
+      float d = (gv[0] * ov[0] + gv[1] * ov[1]) + (gv[2] * ov[2] + gv[3] * ov[3]);
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      d += __shfl_xor(d, 4, 64);
+      if ((f & 7) == 0) {
+        del_s[n] = d;
+        // a pad query's row of P must vanish (its output is discarded): lse = +huge makes exp(S - lse) = 0
+        lse_s[n] = tok >= 0 ? lse[(size_t)tok * heads + hd] : 1e30f;
+      }
+    }
+    __syncthreads();
+
+    // =========================== phase A: query tile `wave`, S^T orientation ===========================
+    {
+      const int qn = wave * 16 + lq;
+      const int qtok = tok_s[qn];
+      const f32x4 q0 = *reinterpret_cast<const f32x4*>(&Qs[qn * KV_LD + lg * 8]);
+      const f32x4 q1 = *reinterpret_cast<const f32x4*>(&Qs[qn * KV_LD + lg * 8 + 4]);
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(&Gs[qn * KV_LD + lg * 8]);
+      const f32x4 g1 = *reinterpret_cast<const f32x4*>(&Gs[qn * KV_LD + lg * 8 + 4]);
+      const float my_lse = lse_s[qn], my_del = del_s[qn];
+      const float* brow = bias_tile + (size_t)qn * PANGU_WTOK + lg * 4;
+      f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        __builtin_amdgcn_sched_barrier(0);      // keep each key tile's loads inside its iteration (VGPR cap 168)
+        const int krow = (j * 16 + lq) * KV_LD + lg * 8;
+        const f32x4 k0 = *reinterpret_cast<const f32x4*>(&Ks[krow]);
+        const f32x4 k1 = *reinterpret_cast<const f32x4*>(&Ks[krow + 4]);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(&Vs[krow]);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(&Vs[krow + 4]);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_16x16x4f32(k0[ks], q0[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x4f32(v0[ks], g0[ks], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_16x16x4f32(k1[ks], q1[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x4f32(v1[ks], g1[ks], dp, 0, 0, 0);
+        }
+        // lane: [key = 16j + 4lg + r][query = qn]
+        s += *reinterpret_cast<const f32x4*>(brow + j * 16);
+        f32x4 ds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sv = s[r];
+          if (SHIFTED) { if (masked(qn, j * 16 + lg * 4 + r)) sv += -100.0f; }
+          const float p = __expf(sv - my_lse);
+          ds[r] = p * (dp[r] - my_del);
+        }
+        dbias[j] += ds;
+        // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = j * 16 + lg * 4 + r;
+          dq0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[key * KV_LD + lq], ds[r], dq0, 0, 0, 0);
+          dq1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[key * KV_LD + 16 + lq], ds[r], dq1, 0, 0, 0);
+        }
+      }
+      // lane: dQ^T[d = 16dt + 4lg + r][query = qn]; q was pre-scaled, so dq = scale * dQs
+      if (qtok >= 0) {
+        float* dst = dqkv + (size_t)qtok * C3 + hd * 32 + lg * 4;
+        *reinterpret_cast<f32x4*>(dst) = dq0 * scale;
+        *reinterpret_cast<f32x4*>(dst + 16) = dq1 * scale;
+      }
+    }
+
+    // =========================== phase B: key tile `wave`, S orientation ===========================
+    {
+      const int kn = wave * 16 + lq;                        // this lane's key column
+      const f32x4 k0 = *reinterpret_cast<const f32x4*>(&Ks[kn * KV_LD + lg * 8]);
+      const f32x4 k1 = *reinterpret_cast<const f32x4*>(&Ks[kn * KV_LD + lg * 8 + 4]);
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(&Vs[kn * KV_LD + lg * 8]);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(&Vs[kn * KV_LD + lg * 8 + 4]);
+      f32x4 dv0 = {0.f, 0.f, 0.f, 0.f}, dv1 = dv0, dk0 = dv0, dk1 = dv0;
+#pragma unroll 1
+      for (int i = 0; i < 9; ++i) {
+        const int qrow = (i * 16 + lq) * KV_LD + lg * 8;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(&Qs[qrow]);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(&Qs[qrow + 4]);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(&Gs[qrow]);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(&Gs[qrow + 4]);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[ks], k0[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[ks], v0[ks], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ks], k1[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[ks], v1[ks], dp, 0, 0, 0);
+        }
+        // lane: [query = 16i + 4lg + r][key = kn]
+        const f32x4 ls = *reinterpret_cast<const f32x4*>(&lse_s[i * 16 + lg * 4]);
+        const f32x4 dl = *reinterpret_cast<const f32x4*>(&del_s[i * 16 + lg * 4]);
+        f32x4 p, ds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qn = i * 16 + lg * 4 + r;
+          float sv = s[r] + bias_tile[(size_t)qn * PANGU_WTOK + kn];
+          if (SHIFTED) { if (masked(qn, kn)) sv += -100.0f; }
+          p[r] = __expf(sv - ls[r]);
+          ds[r] = p[r] * (dp[r] - dl[r]);
+        }
+        // dV[key][d] += P[query][key] dO[query][d];  dK[key][d] += dS[query][key] Qs[query][d]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qn = i * 16 + lg * 4 + r;
+          dv0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p[r], Gs[qn * KV_LD + lq], dv0, 0, 0, 0);
+          dv1 = __builtin_amdgcn_mfma_f32_16x16x4f32(p[r], Gs[qn * KV_LD + 16 + lq], dv1, 0, 0, 0);
+          dk0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[r], Qs[qn * KV_LD + lq], dk0, 0, 0, 0);
+          dk1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[r], Qs[qn * KV_LD + 16 + lq], dk1, 0, 0, 0);
+        }
+      }
+      // lane: dK/dV[key = 16*wave + 4lg + r][d = 16dt + lq]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ktok = tok_s[wave * 16 + lg * 4 + r];
+        if (ktok >= 0) {
+          float* dst = dqkv + (size_t)ktok * C3 + hd * 32 + lq;
+          dst[C] = dk0[r];
+          dst[C + 16] = dk1[r];
+          dst[2 * C] = dv0[r];
+          dst[2 * C + 16] = dv1[r];
+        } else {
+          float* dst = dqkv_bias + hd * 32 + lq;
+          atomicAdd(dst + C, dk0[r]);
+          atomicAdd(dst + C + 16, dk1[r]);
+          atomicAdd(dst + 2 * C, dv0[r]);
+          atomicAdd(dst + 2 * C + 16, dv1[r]);
+        }
+      }
+    }
+  }
+  // ---- bias gradient tile: lane holds sum_l dS^T[key = 16j + 4lg + r][query = 16*wave + lq]
+  float* drow = d_esb + (size_t)pair * PANGU_WTOK * PANGU_WTOK + (size_t)(wave * 16 + lq) * PANGU_WTOK + lg * 4;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) *reinterpret_cast<f32x4*>(drow + j * 16) = dbias[j];
+}
+
+}  // namespace
+
+extern "C" int pangu_window_attn_bwd(pangu_stream_t stream, const float* qkv, const float* qkv_bias, const float* esb,
+                                     const float* out, const float* lse, const float* dout, float* dqkv,
+                                     float* dqkv_bias, float* d_esb, int Z, int H, int W, int C, int heads,
+                                     int shifted) {
+  if (!qkv || !qkv_bias || !esb || !out || !lse || !dout || !dqkv || !dqkv_bias || !d_esb) return PANGU_E_NULL;
+  if (Z <= 0 || H <= 0 || W <= 0 || Z % PANGU_WZ || (H + PANGU_PAD_H) % PANGU_WH || W % PANGU_WW) return PANGU_E_SHAPE;
+  if (heads <= 0 || C != heads * PANGU_HEAD_DIM) return PANGU_E_SHAPE;
+  const WinGeom g = make_geom(Z, H, W);
+  const int n_pairs = g.types * heads;
+  hipStream_t s = (hipStream_t)stream;
+  if (shifted)
+    hipLaunchKernelGGL(window_attn_bwd_f32_kernel<true>, dim3(n_pairs), dim3(NT), 0, s, qkv, qkv_bias, esb, out, lse,
+                       dout, dqkv, dqkv_bias, d_esb, g, C, heads);
+  else
+    hipLaunchKernelGGL(window_attn_bwd_f32_kernel<false>, dim3(n_pairs), dim3(NT), 0, s, qkv, qkv_bias, esb, out, lse,
+                       dout, dqkv, dqkv_bias, d_esb, g, C, heads);
+  return pangu_launch_status();
+}

@@ -52,6 +52,11 @@ __host__ __device__ inline float win_mask(const WinGeom& g, int t, int ni, int n
 
 __device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// d/dx gelu(x) = Phi(x) + x*phi(x)
+__device__ inline float gelu_erf_grad(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
 __device__ inline float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

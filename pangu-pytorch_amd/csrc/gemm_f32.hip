@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_kernel(const float* __rest
                                                              const float* __restrict__ W,
                                                              const float* __restrict__ bias,
                                                              float* __restrict__ C, int ldc, int M, int N, int K,
-                                                             int m_tiles, int n_tiles) {
+                                                             int m_tiles, int n_tiles, float* __restrict__ aux) {
   constexpr int BN = 64 * TN;
   __shared__ __attribute__((aligned(16))) float smem[2][(BM + BN) * LDS_LD];
 
@@ -134,6 +134,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_kernel(const float* __rest
   // hipcc serialise them with s_waitcnt vmcnt(0).
   const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       C, 0, (int)(((size_t)(M - 1) * ldc + N) * sizeof(float)), 0x00020000);
+  // aux [M][N] dense: GELU -> optional pre-activation output (zero-sized range when absent: stores dropped);
+  // GELU_BWD -> saved pre-activation input
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      aux, 0, aux ? (int)((size_t)M * N * sizeof(float)) : 0, 0x00020000);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + wn * 32 * TN + j * 32 + ec;
@@ -149,9 +153,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_kernel(const float* __rest
       for (int it = 0; it < 4; ++it) {
         f32x4 v = *reinterpret_cast<const f32x4*>(&ep[(er + 8 * it) * EP_LD + ec]);
         v += bv;
+        const unsigned xoff = col_ok ? ((unsigned)(row0 + 8 * it) * (unsigned)N + (unsigned)col) * 4u : 0xFFFFFFFFu;
         if (ACT == PANGU_ACT_GELU) {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), x_rsrc, (int)xoff, 0, 0);
 #pragma unroll
           for (int c = 0; c < 4; ++c) v[c] = gelu_erf(v[c]);
+        }
+        if (ACT == PANGU_ACT_GELU_BWD) {
+          const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)xoff, 0, 0));
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] *= gelu_erf_grad(x[c]);
         }
         const unsigned off = col_ok ? ((unsigned)(row0 + 8 * it) * (unsigned)ldc + (unsigned)col) * 4u : 0xFFFFFFFFu;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), c_rsrc, (int)off, 0, 0);
@@ -162,15 +173,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_kernel(const float* __rest
 
 template <int TN>
 int launch_tn(hipStream_t s, const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M,
-              int N, int K, int act) {
+              int N, int K, int act, float* aux) {
   constexpr int BN = 64 * TN;
   const int m_tiles = (M + BM - 1) / BM, n_tiles = (N + BN - 1) / BN;
   const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
   dim3 g(grid), blk(256);
 #define PANGU_GEMM_LAUNCH(ACT, HB) \
-  hipLaunchKernelGGL((gemm_tn_f32_kernel<TN, ACT, HB>), g, blk, 0, s, A, lda, W, bias, C, ldc, M, N, K, m_tiles, n_tiles)
+  hipLaunchKernelGGL((gemm_tn_f32_kernel<TN, ACT, HB>), g, blk, 0, s, A, lda, W, bias, C, ldc, M, N, K, m_tiles, n_tiles, aux)
   if (act == PANGU_ACT_GELU) {
     if (bias) PANGU_GEMM_LAUNCH(PANGU_ACT_GELU, true); else PANGU_GEMM_LAUNCH(PANGU_ACT_GELU, false);
+  } else if (act == PANGU_ACT_GELU_BWD) {
+    if (bias) PANGU_GEMM_LAUNCH(PANGU_ACT_GELU_BWD, true); else PANGU_GEMM_LAUNCH(PANGU_ACT_GELU_BWD, false);
   } else {
     if (bias) PANGU_GEMM_LAUNCH(PANGU_ACT_NONE, true); else PANGU_GEMM_LAUNCH(PANGU_ACT_NONE, false);
   }
@@ -181,14 +194,15 @@ int launch_tn(hipStream_t s, const float* A, int lda, const float* W, const floa
 }  // namespace
 
 extern "C" int pangu_linear_fwd(pangu_stream_t stream, const float* A, int lda, const float* W, const float* bias,
-                                float* C, int ldc, int M, int N, int K, int act) {
+                                float* C, int ldc, int M, int N, int K, int act, float* aux) {
   if (!A || !W || !C) return PANGU_E_NULL;
   if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || (N & 3) || lda < K || ldc < N || (lda & 3) || (ldc & 3))
     return PANGU_E_SHAPE;
-  if (act != PANGU_ACT_NONE && act != PANGU_ACT_GELU) return PANGU_E_ARG;
+  if (act != PANGU_ACT_NONE && act != PANGU_ACT_GELU && act != PANGU_ACT_GELU_BWD) return PANGU_E_ARG;
+  if (act == PANGU_ACT_GELU_BWD && !aux) return PANGU_E_NULL;
   hipStream_t s = (hipStream_t)stream;
   // widest tile that divides N (192 covers every projection of this model except the recovery convs)
-  if (N % 192 == 0) return launch_tn<3>(s, A, lda, W, bias, C, ldc, M, N, K, act);
-  if (N % 128 == 0) return launch_tn<2>(s, A, lda, W, bias, C, ldc, M, N, K, act);
-  return launch_tn<1>(s, A, lda, W, bias, C, ldc, M, N, K, act);
+  if (N % 192 == 0) return launch_tn<3>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
+  if (N % 128 == 0) return launch_tn<2>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
+  return launch_tn<1>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
 }

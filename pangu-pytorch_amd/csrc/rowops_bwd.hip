@@ -1,0 +1,264 @@
+// Backward of the HBM-bound row kernels (fp32): LayerNorm-residual, down/up-sample LayerNorm with their
+// gather/scatter addressing, and the patch-recovery scatter.  One wave per row; LayerNorm statistics are
+// recomputed from the saved pre-norm row (one extra wave reduction) instead of being stored.
+// dgamma/dbeta: per-lane register accumulators over the rows a wave visits, reduced across the workgroup's
+// 4 waves in LDS, one atomicAdd per column per workgroup.
+#include "common.h"
+
+namespace {
+
+constexpr float LN_EPS = 1e-5f;
+constexpr int ROWS_PER_BLOCK = 4;
+
+// y: pre-norm row (in), g: upstream gradient row already multiplied by the branch scale (in) -> dy (out, in y)
+template <int NV>
+__device__ inline void row_ln_bwd(f32x4 (&y)[NV], const f32x4 (&g)[NV], int nvec, int lane, int C,
+                                  const float* __restrict__ gamma, f32x4 (&dg)[NV], f32x4 (&db)[NV]) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (lane + 64 * i < nvec) s += (y[i][0] + y[i][1]) + (y[i][2] + y[i][3]);
+  const float mean = wave_sum(s) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (lane + 64 * i < nvec) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { const float d = y[i][c] - mean; q += d * d; }
+    }
+  const float rstd = rsqrtf(wave_sum(q) / C + LN_EPS);
+  f32x4 gg[NV];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (lane + 64 * i < nvec) {
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 4 * (lane + 64 * i));
+      y[i] = (y[i] - mean) * rstd;                  // xhat
+      gg[i] = g[i] * gm;
+      dg[i] += g[i] * y[i];
+      db[i] += g[i];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { s1 += gg[i][c]; s2 += gg[i][c] * y[i][c]; }
+    }
+  const float m1 = wave_sum(s1) / C, m2 = wave_sum(s2) / C;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (lane + 64 * i < nvec) y[i] = (gg[i] - m1 - y[i] * m2) * rstd;
+}
+
+template <int NV>
+__device__ inline void flush_param_grads(const f32x4 (&dg)[NV], const f32x4 (&db)[NV], int nvec, int lane, int wave,
+                                         float* __restrict__ dgamma, float* __restrict__ dbeta, float* red) {
+  // red: [2][4 waves][4*nvec] floats of LDS
+  const int C = 4 * nvec;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (lane + 64 * i < nvec) {
+      *reinterpret_cast<f32x4*>(&red[wave * C + 4 * (lane + 64 * i)]) = dg[i];
+      *reinterpret_cast<f32x4*>(&red[(4 + wave) * C + 4 * (lane + 64 * i)]) = db[i];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    atomicAdd(&dgamma[c], (red[c] + red[C + c]) + (red[2 * C + c] + red[3 * C + c]));
+    atomicAdd(&dbeta[c], (red[4 * C + c] + red[5 * C + c]) + (red[6 * C + c] + red[7 * C + c]));
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_residual_bwd_kernel(const float* __restrict__ dout, int lddo,
+                                                              const float* __restrict__ yin,
+                                                              const float* __restrict__ gamma, float* __restrict__ dy,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              int N, int C, float branch_scale) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nvec = C >> 2;
+  f32x4 dg[NV], db[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { dg[i] = f32x4{0.f, 0.f, 0.f, 0.f}; db[i] = dg[i]; }
+  for (int row = blockIdx.x * ROWS_PER_BLOCK + wave; row < N; row += gridDim.x * ROWS_PER_BLOCK) {
+    f32x4 y[NV], g[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < nvec) {
+        y[i] = *reinterpret_cast<const f32x4*>(yin + (size_t)row * C + 4 * (lane + 64 * i));
+        g[i] = *reinterpret_cast<const f32x4*>(dout + (size_t)row * lddo + 4 * (lane + 64 * i)) * branch_scale;
+      }
+    row_ln_bwd<NV>(y, g, nvec, lane, C, gamma, dg, db);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < nvec) *reinterpret_cast<f32x4*>(dy + (size_t)row * C + 4 * (lane + 64 * i)) = y[i];
+  }
+  flush_param_grads<NV>(dg, db, nvec, lane, wave, dgamma, dbeta, red);
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void downsample_ln_bwd_kernel(const float* __restrict__ dout,
+                                                                const float* __restrict__ x, int ldx,
+                                                                const float* __restrict__ gamma, float* __restrict__ dx,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                int Z, int H, int W, int C) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int H2 = (H + 1) / 2, W2 = W / 2, C4 = 4 * C, nvec = C4 >> 2, cvec = C >> 2;
+  const int N2 = Z * H2 * W2;
+  f32x4 dg[NV], db[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { dg[i] = f32x4{0.f, 0.f, 0.f, 0.f}; db[i] = dg[i]; }
+  for (int row = blockIdx.x * ROWS_PER_BLOCK + wave; row < N2; row += gridDim.x * ROWS_PER_BLOCK) {
+    const int w2 = row % W2, h2 = (row / W2) % H2, z = row / (W2 * H2);
+    f32x4 y[NV], g[NV];
+    size_t src[NV];
+    bool real[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = lane + 64 * i;
+      if (f < nvec) {
+        const int quad = f / cvec, c4 = f - quad * cvec;
+        const int h = 2 * h2 + (quad >> 1), w = 2 * w2 + (quad & 1);
+        real[i] = h < H;
+        src[i] = (size_t)(z * H + h) * W + w;
+        y[i] = real[i] ? *reinterpret_cast<const f32x4*>(x + src[i] * ldx + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        g[i] = *reinterpret_cast<const f32x4*>(dout + (size_t)row * C4 + 4 * f);
+        src[i] = src[i] * C + 4 * c4;
+      }
+    }
+    row_ln_bwd<NV>(y, g, nvec, lane, C4, gamma, dg, db);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < nvec && real[i]) *reinterpret_cast<f32x4*>(dx + src[i]) = y[i];
+  }
+  flush_param_grads<NV>(dg, db, nvec, lane, wave, dgamma, dbeta, red);
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void upsample_ln_bwd_kernel(const float* __restrict__ dout,
+                                                              const float* __restrict__ yin,
+                                                              const float* __restrict__ gamma, float* __restrict__ dy,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              int Z, int H2, int W2, int H, int Co) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Wf = 2 * W2, Hf = 2 * H2, nvec = Co >> 2;
+  const int Nall = Z * Hf * Wf;         // includes the cropped rows h >= H, which receive zero gradient
+  f32x4 dg[NV], db[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { dg[i] = f32x4{0.f, 0.f, 0.f, 0.f}; db[i] = dg[i]; }
+  for (int r = blockIdx.x * ROWS_PER_BLOCK + wave; r < Nall; r += gridDim.x * ROWS_PER_BLOCK) {
+    const int w = r % Wf, h = (r / Wf) % Hf, z = r / (Wf * Hf);
+    const size_t src = ((size_t)(z * H2 + (h >> 1)) * W2 + (w >> 1)) * (4 * Co) + ((h & 1) * 2 + (w & 1)) * Co;
+    f32x4 y[NV], g[NV];
+    if (h >= H) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < nvec) *reinterpret_cast<f32x4*>(dy + src + 4 * (lane + 64 * i)) = f32x4{0.f, 0.f, 0.f, 0.f};
+      continue;
+    }
+    const size_t orow = ((size_t)z * H + h) * Wf + w;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < nvec) {
+        y[i] = *reinterpret_cast<const f32x4*>(yin + src + 4 * (lane + 64 * i));
+        g[i] = *reinterpret_cast<const f32x4*>(dout + orow * Co + 4 * (lane + 64 * i));
+      }
+    row_ln_bwd<NV>(y, g, nvec, lane, Co, gamma, dg, db);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < nvec) *reinterpret_cast<f32x4*>(dy + src + 4 * (lane + 64 * i)) = y[i];
+  }
+  flush_param_grads<NV>(dg, db, nvec, lane, wave, dgamma, dbeta, red);
+}
+
+// gradient of patch_recover_scatter: gather the field gradients back into GEMM-output layout
+constexpr int EMB_TOK = 64;
+
+__global__ __launch_bounds__(256) void patch_recover_gather_bwd_kernel(const float* __restrict__ d_output,
+                                                                       const float* __restrict__ d_output_surface,
+                                                                       float* __restrict__ dy_upper,
+                                                                       float* __restrict__ dy_surface, int LAT, int LON,
+                                                                       int H4, int W4, int chunks) {
+  __shared__ float tile[EMB_TOK * 161];
+  const int chunk = blockIdx.x % chunks, h4 = (blockIdx.x / chunks) % H4, zp = blockIdx.x / (chunks * H4);
+  const int w0 = chunk * EMB_TOK;
+  const int ntok = min(EMB_TOK, W4 - w0);
+  const int tid = threadIdx.x;
+  const int ncol = zp == 0 ? 64 : 160;
+  const size_t plane = (size_t)LAT * LON;
+  const int nrun = ncol / 4;
+  for (int run = tid >> 6; run < nrun; run += 4) {
+    int v, pz, ph;
+    if (zp == 0) { v = run >> 2; pz = 0; ph = run & 3; } else { v = run >> 3; pz = (run >> 2) & 1; ph = run & 3; }
+    const int lat = 4 * h4 + ph;
+    const int lev = 2 * (zp - 1) + pz;
+    const bool valid = lat < LAT && (zp == 0 || lev < 13);
+    const float* src = zp == 0 ? d_output_surface + v * plane + (size_t)lat * LON
+                               : d_output + ((size_t)v * 13 + lev) * plane + (size_t)lat * LON;
+    for (int i = (tid & 63); i < 4 * ntok; i += 64)
+      tile[(i >> 2) * 161 + run * 4 + (i & 3)] = valid ? src[4 * w0 + i] : 0.f;
+  }
+  __syncthreads();
+  float* dst = zp == 0 ? dy_surface + ((size_t)h4 * W4 + w0) * 64
+                       : dy_upper + (((size_t)(zp - 1) * H4 + h4) * W4 + w0) * 160;
+  for (int i = tid; i < ntok * ncol; i += 256) {
+    const int tk = i / ncol, col = i - tk * ncol;
+    dst[i] = tile[tk * 161 + col];
+  }
+}
+
+int row_grid(int rows) {
+  int blocks = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  return blocks < 2048 ? blocks : 2048;        // 8 workgroups per CU: fewer, fatter register accumulators
+}
+
+}  // namespace
+
+#define PANGU_NV_DISPATCH(C_, KERNEL, ...)                                                                           \
+  do {                                                                                                               \
+    const size_t shm = (size_t)8 * (C_) * sizeof(float);                                                             \
+    if ((C_) <= 256) hipLaunchKernelGGL(KERNEL<1>, g, b, shm, s, __VA_ARGS__);                                       \
+    else if ((C_) <= 512) hipLaunchKernelGGL(KERNEL<2>, g, b, shm, s, __VA_ARGS__);                                  \
+    else hipLaunchKernelGGL(KERNEL<4>, g, b, shm, s, __VA_ARGS__);                                                   \
+  } while (0)
+
+extern "C" int pangu_ln_residual_bwd(pangu_stream_t stream, const float* dout, int lddo, const float* y,
+                                     const float* gamma, float* dy, float* dgamma, float* dbeta, int N, int C,
+                                     float branch_scale) {
+  if (!dout || !y || !gamma || !dy || !dgamma || !dbeta) return PANGU_E_NULL;
+  if (N <= 0 || C <= 0 || (C & 3) || C > 1024 || lddo < C || (lddo & 3)) return PANGU_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g(row_grid(N)), b(256);
+  PANGU_NV_DISPATCH(C, ln_residual_bwd_kernel, dout, lddo, y, gamma, dy, dgamma, dbeta, N, C, branch_scale);
+  return pangu_launch_status();
+}
+
+extern "C" int pangu_downsample_ln_bwd(pangu_stream_t stream, const float* dout, const float* x, int ldx,
+                                       const float* gamma, float* dx, float* dgamma, float* dbeta, int Z, int H, int W,
+                                       int C) {
+  if (!dout || !x || !gamma || !dx || !dgamma || !dbeta) return PANGU_E_NULL;
+  if (Z <= 0 || H <= 0 || W <= 0 || (W & 1) || (C & 3) || 4 * C > 1024 || ldx < C || (ldx & 3)) return PANGU_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g(row_grid(Z * ((H + 1) / 2) * (W / 2))), b(256);
+  PANGU_NV_DISPATCH(4 * C, downsample_ln_bwd_kernel, dout, x, ldx, gamma, dx, dgamma, dbeta, Z, H, W, C);
+  return pangu_launch_status();
+}
+
+extern "C" int pangu_upsample_ln_bwd(pangu_stream_t stream, const float* dout, const float* y, const float* gamma,
+                                     float* dy, float* dgamma, float* dbeta, int Z, int H2, int W2, int H, int Co) {
+  if (!dout || !y || !gamma || !dy || !dgamma || !dbeta) return PANGU_E_NULL;
+  if (Z <= 0 || H2 <= 0 || W2 <= 0 || H <= 0 || H > 2 * H2 || (Co & 3) || Co > 1024) return PANGU_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g(row_grid(Z * 2 * H2 * 2 * W2)), b(256);
+  PANGU_NV_DISPATCH(Co, upsample_ln_bwd_kernel, dout, y, gamma, dy, dgamma, dbeta, Z, H2, W2, H, Co);
+  return pangu_launch_status();
+}
+
+extern "C" int pangu_patch_recover_gather_bwd(pangu_stream_t stream, const float* d_output,
+                                              const float* d_output_surface, float* dy_upper, float* dy_surface,
+                                              int LAT, int LON) {
+  if (!d_output || !d_output_surface || !dy_upper || !dy_surface) return PANGU_E_NULL;
+  if (LAT <= 0 || LON <= 0 || (LON & 3)) return PANGU_E_SHAPE;
+  const int H4 = (LAT + 3) / 4, W4 = LON / 4, chunks = (W4 + EMB_TOK - 1) / EMB_TOK;
+  hipLaunchKernelGGL(patch_recover_gather_bwd_kernel, dim3(8 * H4 * chunks), dim3(256), 0, (hipStream_t)stream, d_output,
+                     d_output_surface, dy_upper, dy_surface, LAT, LON, H4, W4, chunks);
+  return pangu_launch_status();
+}

@@ -1,0 +1,178 @@
+// fp32 weight-gradient GEMM for gfx950:  dW[N,K] += dC[M,N]^T @ A[M,K],  db[N] += colsum(dC).
+//
+// The contraction runs over the token dimension M (65k..521k) while the output is small (<= 1536 x 384), so the
+// grid is (output tiles) x (M splits): each 256-thread workgroup owns one 128(n) x 64*TK(k) output tile and a
+// contiguous slab of tokens, accumulates it with v_mfma_f32_32x32x2_f32 and adds the tile to dW with no-return
+// fp32 atomics (each wave-instruction adds two 128-B row segments: the full-rate atomic shape).
+// Both operands are read exactly as they lie in memory (token-major rows): a 16-token slab of dC and of A is
+// staged in LDS as [token][column]; MFMA fragments are ds_read_b32 with consecutive lanes on consecutive
+// columns (conflict-free), lane half h supplying token 2s+h of k-step s.
+// All loads go through range-checked buffer descriptors (rows >= M read as 0, no divergent branches).
+#include "common.h"
+
+namespace {
+
+constexpr int WG_BN = 128;   // output rows (n) per tile
+constexpr int WG_BM = 16;    // tokens per K-step
+
+template <int TK>
+__global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const float* __restrict__ dC, int lddc,
+                                                           const float* __restrict__ A, int lda,
+                                                           float* __restrict__ dW, float* __restrict__ db, int M, int N,
+                                                           int K, int n_tiles, int k_tiles, int rows_per_split) {
+  constexpr int BKC = 64 * TK;                       // output columns (k) per tile
+  constexpr int D_LD = WG_BN + 4, A_LD = BKC + 4;    // +4 keeps rows 16-B aligned and staggers the two lane halves
+  __shared__ __attribute__((aligned(16))) float smem[2][WG_BM * (D_LD + A_LD)];
+
+  const int tile = blockIdx.x % (n_tiles * k_tiles), split = blockIdx.x / (n_tiles * k_tiles);
+  const int n_tile = tile / k_tiles, k_tile = tile - n_tile * k_tiles;
+  const int n0 = n_tile * WG_BN, k0 = k_tile * BKC;
+  const int m_begin = split * rows_per_split;
+  const int m_end = min(M, m_begin + rows_per_split);
+  if (m_begin >= m_end) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  const __amdgpu_buffer_rsrc_t d_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(dC), 0, (int)(((size_t)(M - 1) * lddc + N) * sizeof(float)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(A), 0, (int)(((size_t)(M - 1) * lda + K) * sizeof(float)), 0x00020000);
+
+  // staging assignment.  dC slab: 16 x 128 floats = 512 float4 (2 per thread); A slab: 16 x BKC = 256*TK float4.
+  const int d_row = tid >> 5, d_c4 = tid & 31;                // + 8 rows for the second float4
+  const bool d_ok = n0 + d_c4 * 4 < N;
+  const int a_per_row = 16 * TK;
+  int a_row[TK], a_c4[TK];
+  bool a_ok[TK];
+#pragma unroll
+  for (int i = 0; i < TK; ++i) {
+    const int f = tid + 256 * i;
+    a_row[i] = f / a_per_row;
+    a_c4[i] = f - a_row[i] * a_per_row;
+    a_ok[i] = k0 + a_c4[i] * 4 < K;
+  }
+
+  auto load_d = [&](int m, int i) -> f32x4 {
+    const unsigned off = d_ok ? ((unsigned)(m + d_row + 8 * i) * (unsigned)lddc + (unsigned)(n0 + d_c4 * 4)) * 4u : 0xFFFFFFFFu;
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d_rsrc, (int)off, 0, 0));
+  };
+  auto load_a = [&](int m, int i) -> f32x4 {
+    const unsigned off = a_ok[i] ? ((unsigned)(m + a_row[i]) * (unsigned)lda + (unsigned)(k0 + a_c4[i] * 4)) * 4u : 0xFFFFFFFFu;
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)off, 0, 0));
+  };
+
+  f32x16 acc[2][TK];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TK; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
+
+  // rows >= m_end inside the last slab belong to the next split: mask them through the row bound
+  f32x4 rd[2], ra[TK];
+  auto fetch = [&](int m) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      rd[i] = load_d(m, i);
+      if (m + d_row + 8 * i >= m_end) rd[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < TK; ++i) ra[i] = load_a(m, i);
+  };
+  auto stash = [&](int buf) {
+    float* Ds = smem[buf];
+    float* As = Ds + WG_BM * D_LD;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<f32x4*>(&Ds[(d_row + 8 * i) * D_LD + d_c4 * 4]) = rd[i];
+      dbacc += rd[i];
+    }
+#pragma unroll
+    for (int i = 0; i < TK; ++i) *reinterpret_cast<f32x4*>(&As[a_row[i] * A_LD + a_c4[i] * 4]) = ra[i];
+  };
+
+  fetch(m_begin);
+  stash(0);
+  __syncthreads();
+  const int steps = (m_end - m_begin + WG_BM - 1) / WG_BM;
+  for (int st = 0; st < steps; ++st) {
+    const bool more = st + 1 < steps;
+    if (more) fetch(m_begin + (st + 1) * WG_BM);
+    const float* Ds = smem[st & 1];
+    const float* As = Ds + WG_BM * D_LD;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      float fd[2], fa[TK];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fd[i] = Ds[(2 * s + lh) * D_LD + wn * 64 + i * 32 + lr];
+#pragma unroll
+      for (int j = 0; j < TK; ++j) fa[j] = As[(2 * s + lh) * A_LD + wk * 32 * TK + j * 32 + lr];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fd[i], fa[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) stash((st + 1) & 1);
+    __syncthreads();
+  }
+
+  // dW tile: C/D layout col = lane&31 (k), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (n)
+#pragma unroll
+  for (int j = 0; j < TK; ++j) {
+    const int kc = k0 + wk * 32 * TK + j * 32 + lr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (n < N && kc < K) atomicAdd(&dW[(size_t)n * K + kc], acc[i][j][r]);
+      }
+  }
+  // bias gradient: column sums of the dC slab, from the staging registers (k-tile 0 only)
+  if (db != nullptr && k_tile == 0) {
+    float* red = &smem[0][0];               // [8 row groups][128 columns]
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[d_row * WG_BN + d_c4 * 4 + c] = dbacc[c];
+    __syncthreads();
+    if (tid < WG_BN) {
+      float v = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) v += red[g * WG_BN + tid];
+      if (n0 + tid < N) atomicAdd(&db[n0 + tid], v);
+    }
+  }
+}
+
+template <int TK>
+int launch_wgrad(hipStream_t s, const float* dC, int lddc, const float* A, int lda, float* dW, float* db, int M, int N,
+                 int K) {
+  constexpr int BKC = 64 * TK;
+  const int n_tiles = (N + WG_BN - 1) / WG_BN, k_tiles = (K + BKC - 1) / BKC;
+  const int tiles = n_tiles * k_tiles;
+  // ~3 workgroups per CU slot-pair: enough M-splits to fill 256 CUs x 2, slabs a multiple of the K-step
+  int split = (1536 + tiles - 1) / tiles;
+  int rows = ((M + split - 1) / split + WG_BM - 1) / WG_BM * WG_BM;
+  if (rows < 8 * WG_BM) rows = 8 * WG_BM;
+  split = (M + rows - 1) / rows;
+  hipLaunchKernelGGL((wgrad_f32_kernel<TK>), dim3(tiles * split), dim3(256), 0, s, dC, lddc, A, lda, dW, db, M, N, K,
+                     n_tiles, k_tiles, rows);
+  return pangu_launch_status();
+}
+
+}  // namespace
+
+extern "C" int pangu_linear_wgrad(pangu_stream_t stream, const float* dC, int lddc, const float* A, int lda, float* dW,
+                                  float* db, int M, int N, int K) {
+  if (!dC || !A || !dW) return PANGU_E_NULL;
+  if (M <= 0 || N <= 0 || K <= 0 || (N & 3) || (K & 3) || lddc < N || lda < K || (lddc & 3) || (lda & 3))
+    return PANGU_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (K % 192 == 0) return launch_wgrad<3>(s, dC, lddc, A, lda, dW, db, M, N, K);
+  if (K % 128 == 0) return launch_wgrad<2>(s, dC, lddc, A, lda, dW, db, M, N, K);
+  return launch_wgrad<1>(s, dC, lddc, A, lda, dW, db, M, N, K);
+}

@@ -6,6 +6,18 @@ geometry-dependent kernels (the reference itself is B=1 only, models/layers.py:2
 import torch
 
 from . import ops
+from .autograd import DownSampleFn, EarthBlockFn, PatchEmbedFn, PatchRecoverFn, UpSampleFn
+
+
+def _train_path(module, *tensors):
+    """Autograd path iff grad mode is on and something upstream (a parameter or an activation) needs a gradient."""
+    if not torch.is_grad_enabled():
+        return False
+    return any(p.requires_grad for p in module.parameters()) or any(t.requires_grad for t in tensors)
+
+
+def _stack(outs, B):
+    return outs[0].unsqueeze(0) if B == 1 else torch.stack(outs, 0)
 
 
 def _tok2d(x):
@@ -25,8 +37,23 @@ def earth_block(blk, x, Z, H, W, roll, out=None):
     """x (B,N,C) -> (B,N,C).  reference layers.py:183-253 as 7 kernel launches per sample."""
     B, N, C = x.shape
     att = blk.attention
-    x2 = _tok2d(x)
     dp = blk.drop_path
+    if _train_path(blk, x):
+        outs = []
+        for b in range(B):
+            s1 = dp.sample_scale(blk.training) if hasattr(dp, "sample_scale") else 1.0
+            s2 = dp.sample_scale(blk.training) if hasattr(dp, "sample_scale") else 1.0
+            outs.append(EarthBlockFn.apply(
+                x[b].contiguous(), blk.norm1.weight, blk.norm1.bias, blk.norm2.weight, blk.norm2.bias,
+                blk.linear.linear1.weight, blk.linear.linear1.bias, blk.linear.linear2.weight, blk.linear.linear2.bias,
+                att.earth_specific_bias, att.linear1.weight, att.linear1.bias, att.linear2.weight, att.linear2.bias,
+                (Z, H, W, att.head_number, bool(roll)), s1, s2))
+        y = _stack(outs, B)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
+    x2 = _tok2d(x)
     s1 = dp.sample_scale(blk.training) if hasattr(dp, "sample_scale") else 1.0
     s2 = dp.sample_scale(blk.training) if hasattr(dp, "sample_scale") else 1.0
     if s1 != 0.0:
@@ -65,6 +92,10 @@ def patch_embed(m, inp, inp_surface, statistics, maps, const_h):
     u_mean, u_std = f32(u_mean).reshape(13, 5), f32(u_std).reshape(13, 5)
     maps_c = f32(maps).reshape(3, 4 * H4, LON)
     const_c = f32(const_h).reshape(13, LAT, LON)
+    if _train_path(m):
+        return _stack([PatchEmbedFn.apply(m.conv.weight, m.conv.bias, m.conv_surface.weight, m.conv_surface.bias,
+                                          inp[b].contiguous(), inp_surface[b].contiguous(), s_mean, s_std, u_mean,
+                                          u_std, maps_c, const_c) for b in range(B)], B)
     for b in range(B):
         a_s, a_u = ops.patch_embed_gather(inp[b].contiguous(), inp_surface[b].contiguous(), s_mean, s_std, u_mean,
                                           u_std, maps_c, const_c)
@@ -75,6 +106,9 @@ def patch_embed(m, inp, inp_surface, statistics, maps, const_h):
 
 def down_sample(m, x, Z, H, W):
     B, N, C = x.shape
+    if _train_path(m, x):
+        return _stack([DownSampleFn.apply(x[b].contiguous(), m.linear.weight, m.norm.weight, m.norm.bias, (Z, H, W))
+                       for b in range(B)], B)
     outs = []
     for b in range(B):
         g = ops.downsample_ln(_tok2d(x[b:b + 1]), m.norm.weight, m.norm.bias, Z, H, W)
@@ -84,6 +118,13 @@ def down_sample(m, x, Z, H, W):
 
 def up_sample(m, x, Z, H2, W2, H, out=None):
     B, N, C2 = x.shape
+    if _train_path(m, x):
+        y = _stack([UpSampleFn.apply(x[b].contiguous(), m.linear1.weight, m.linear2.weight, m.norm.weight, m.norm.bias,
+                                     (Z, H2, W2, H)) for b in range(B)], B)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
     y = ops.linear(_tok2d(x), m.linear1.weight)                          # (B*N, 4Co)
     Co = y.shape[1] // 4
     Nf = Z * H * 2 * W2
@@ -99,6 +140,10 @@ def patch_recover(m, x, Z, H, W, LAT=721, LON=1440):
     """x (B, Z*H*W, C) (may be a row-strided view) -> (B,5,13,LAT,LON), (B,4,LAT,LON).  reference layers.py:511-545."""
     B, N, C = x.shape
     n_s = H * W
+    if _train_path(m, x):
+        res = [PatchRecoverFn.apply(x[b].contiguous(), m.conv.weight, m.conv.bias, m.conv_surface.weight,
+                                    m.conv_surface.bias, (n_s, LAT, LON)) for b in range(B)]
+        return _stack([r[0] for r in res], B), _stack([r[1] for r in res], B)
     outs, outs_s = [], []
     for b in range(B):
         xb = _tok2d(x[b:b + 1])

@@ -6,7 +6,7 @@ import torch
 
 from . import _lib
 
-ACT_NONE, ACT_GELU = 0, 1
+ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
 
 # Optional live kernel timing (bench.py): HIP events recorded on the launch stream around each launch.
 _timing = None
@@ -82,8 +82,9 @@ def window_mask(Z, H, W, device):
     return out
 
 
-def linear(a, weight, bias=None, act=ACT_NONE, out=None):
-    """out[M,N] = act(a[M,K] @ weight[N,K]^T + bias). `a`/`out` may be row-strided views."""
+def linear(a, weight, bias=None, act=ACT_NONE, out=None, aux=None):
+    """out[M,N] = act(a[M,K] @ weight[N,K]^T + bias). `a`/`out` may be row-strided views.
+    act=GELU: aux (optional, dense [M,N]) receives the pre-activation; act=GELU_BWD: out = (a@w^T) * gelu'(aux)."""
     lib = _lib.load()
     ap, lda = _rows(a, "linear.a")
     M, K = a.shape
@@ -97,8 +98,24 @@ def linear(a, weight, bias=None, act=ACT_NONE, out=None):
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     op, ldc = _rows(out, "linear.out")
     with _timed("linear", 2.0 * M * N * K):
-        _lib.check(lib.pangu_linear_fwd(_stream(), ap, lda, wp, bp, op, ldc, M, N, K, act), "linear_fwd")
+        _lib.check(lib.pangu_linear_fwd(_stream(), ap, lda, wp, bp, op, ldc, M, N, K, act,
+                                        _chk(aux, "linear.aux") if aux is not None else None), "linear_fwd")
     return out
+
+
+def linear_wgrad(dc, a, want_bias=True):
+    """dW[N,K] = dc[M,N]^T @ a[M,K], db[N] = colsum(dc) (fp32 atomics into zero-initialised buffers)."""
+    lib = _lib.load()
+    dp, lddc = _rows(dc, "wgrad.dc")
+    ap, lda = _rows(a, "wgrad.a")
+    M, N = dc.shape
+    K = a.shape[1]
+    dw = torch.zeros((N, K), dtype=torch.float32, device=dc.device)
+    db = torch.zeros((N,), dtype=torch.float32, device=dc.device) if want_bias else None
+    with _timed("wgrad", 2.0 * M * N * K):
+        _lib.check(lib.pangu_linear_wgrad(_stream(), dp, lddc, ap, lda, dw.data_ptr(),
+                                          db.data_ptr() if want_bias else None, M, N, K), "linear_wgrad")
+    return dw, db
 
 
 def window_attention(qkv, qkv_bias, esb, Z, H, W, heads, shifted, want_lse=False):
@@ -115,6 +132,72 @@ def window_attention(qkv, qkv_bias, esb, Z, H, W, heads, shifted, want_lse=False
                                              out.data_ptr(), lse.data_ptr() if want_lse else None, Z, H, W, C, heads,
                                              int(shifted)), "window_attn_fwd")
     return (out, lse) if want_lse else out
+
+
+def window_attention_bwd(qkv, qkv_bias, esb, out, lse, dout, Z, H, W, heads, shifted):
+    """-> (dqkv [N,3C], dqkv_bias [3C] (pad-slot part of linear1.bias' gradient), d_esb like esb)."""
+    lib = _lib.load()
+    N, C3 = qkv.shape
+    C = C3 // 3
+    dqkv = torch.empty_like(qkv)
+    dqb = torch.zeros((C3,), dtype=torch.float32, device=qkv.device)
+    desb = torch.empty_like(esb)
+    Np = (Z // 2) * ((H + 5) // 6) * (W // 12) * 144
+    with _timed("attn_bwd", 14.0 * Np * 144 * C):
+        _lib.check(lib.pangu_window_attn_bwd(_stream(), _chk(qkv, "qkv"), _chk(qkv_bias, "qkv_bias"), _chk(esb, "esb"),
+                                             _chk(out, "out"), _chk(lse, "lse"), _chk(dout, "dout"), dqkv.data_ptr(),
+                                             dqb.data_ptr(), desb.data_ptr(), Z, H, W, C, heads, int(shifted)),
+                   "window_attn_bwd")
+    return dqkv, dqb, desb
+
+
+def ln_residual_bwd(dout, y, gamma, branch_scale=1.0):
+    """-> (dy, dgamma, dbeta) of out = shortcut + scale*LN(y); dout may be row-strided."""
+    lib = _lib.load()
+    N, C = y.shape
+    dp, lddo = _rows(dout, "ln_bwd.dout")
+    dy = torch.empty_like(y)
+    dg = torch.zeros((C,), dtype=torch.float32, device=y.device)
+    db = torch.zeros((C,), dtype=torch.float32, device=y.device)
+    _lib.check(lib.pangu_ln_residual_bwd(_stream(), dp, lddo, _chk(y, "ln_bwd.y"), _chk(gamma, "gamma"), dy.data_ptr(),
+                                         dg.data_ptr(), db.data_ptr(), N, C, float(branch_scale)), "ln_residual_bwd")
+    return dy, dg, db
+
+
+def downsample_ln_bwd(dout, x, gamma, Z, H, W):
+    lib = _lib.load()
+    xp, ldx = _rows(x, "downsample_bwd.x")
+    C = x.shape[1]
+    dx = torch.empty((Z * H * W, C), dtype=torch.float32, device=x.device)
+    dg = torch.zeros((4 * C,), dtype=torch.float32, device=x.device)
+    db = torch.zeros((4 * C,), dtype=torch.float32, device=x.device)
+    _lib.check(lib.pangu_downsample_ln_bwd(_stream(), _chk(dout, "dout"), xp, ldx, _chk(gamma, "gamma"), dx.data_ptr(),
+                                           dg.data_ptr(), db.data_ptr(), Z, H, W, C), "downsample_ln_bwd")
+    return dx, dg, db
+
+
+def upsample_ln_bwd(dout, y, gamma, Z, H2, W2, H):
+    lib = _lib.load()
+    Co = y.shape[1] // 4
+    dy = torch.empty_like(y)
+    dg = torch.zeros((Co,), dtype=torch.float32, device=y.device)
+    db = torch.zeros((Co,), dtype=torch.float32, device=y.device)
+    _lib.check(lib.pangu_upsample_ln_bwd(_stream(), _chk(dout, "dout"), _chk(y, "y"), _chk(gamma, "gamma"),
+                                         dy.data_ptr(), dg.data_ptr(), db.data_ptr(), Z, H2, W2, H, Co),
+               "upsample_ln_bwd")
+    return dy, dg, db
+
+
+def patch_recover_gather_bwd(d_out, d_out_s):
+    lib = _lib.load()
+    LAT, LON = d_out.shape[-2], d_out.shape[-1]
+    H4, W4 = (LAT + 3) // 4, LON // 4
+    dy_u = torch.empty((7 * H4 * W4, 160), dtype=torch.float32, device=d_out.device)
+    dy_s = torch.empty((H4 * W4, 64), dtype=torch.float32, device=d_out.device)
+    _lib.check(lib.pangu_patch_recover_gather_bwd(_stream(), _chk(d_out, "d_output"), _chk(d_out_s, "d_output_surface"),
+                                                  dy_u.data_ptr(), dy_s.data_ptr(), LAT, LON),
+               "patch_recover_gather_bwd")
+    return dy_u, dy_s
 
 
 def ln_residual(y, shortcut, gamma, beta, out=None, branch_scale=1.0, want_stats=False):

@@ -75,6 +75,14 @@ class PanguModel(nn.Module):
         N, C = x.shape[1], x.shape[2]
         # skip connection: layer 0 writes its result into the left half, layer 3 into the right half of one
         # (B,N,2C) buffer, so the channel concat of reference pangu_model.py:81 costs no copy
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            skip = self.layers[0](x, 8, 181, 360)                 # autograd path: plain concat
+            x = self.downsample(skip, 8, 181, 360)
+            x = self.layers[1](x, 8, 91, 180)
+            x = self.layers[2](x, 8, 91, 180)
+            x = self.upsample(x)
+            x = self.layers[3](x, 8, 181, 360)
+            return self._output_layer(torch.cat((skip, x), dim=-1), 8, 181, 360)
         cat = torch.empty((B, N, 2 * C), dtype=x.dtype, device=x.device)
         skip = self.layers[0](x, 8, 181, 360, out=cat[:, :, :C])
         x = self.downsample(skip, 8, 181, 360)

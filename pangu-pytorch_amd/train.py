@@ -1,0 +1,41 @@
+"""Training-step pieces around the model (counterpart of reference models/pangu_sample.py:45-77).
+
+The loss is the caller's code in the reference (plain torch ops on the two output fields); it is restated here so
+bench/tests/finetune loops need nothing from the reference's era5_data package.
+"""
+import torch
+
+UPPER_WEIGHTS = (3.00, 0.60, 1.50, 0.77, 0.54)       # reference era5_data/config.py:45
+SURFACE_WEIGHTS = (1.50, 0.77, 0.66, 3.00)           # reference era5_data/config.py:46
+
+
+def norm_data(target, target_surface, stats_last):
+    """reference era5_data/utils_data.py:315-321; stats_last = (s_mean(1,4,1,1), s_std, u_mean(1,5,13,1,1), u_std)."""
+    s_mean, s_std, u_mean, u_std = stats_last
+    return (target - u_mean) / u_std, (target_surface - s_mean) / s_std
+
+
+def weighted_l1_loss(output, output_surface, target, target_surface):
+    """reference models/pangu_sample.py:61-67: mean(|o-t| * w_upper) + 0.25 * mean(|o_s-t_s| * w_surface)."""
+    wu = torch.tensor(UPPER_WEIGHTS, dtype=output.dtype, device=output.device).view(1, 5, 1, 1, 1)
+    ws = torch.tensor(SURFACE_WEIGHTS, dtype=output.dtype, device=output.device).view(1, 4, 1, 1)
+    loss_surface = torch.mean(torch.abs(output_surface - target_surface) * ws)
+    loss_upper = torch.mean(torch.abs(output - target) * wu)
+    return loss_upper + loss_surface * 0.25
+
+
+def train_step(model, optimizer, batch, statistics, maps, const_h, stats_last=None, grad_sync=None):
+    """One optimisation step (reference pangu_sample.py:45-77). batch = (input, input_surface, target, target_surface).
+    `grad_sync` (optional callable) runs between backward and optimizer.step(): the data-parallel gradient
+    all-reduce (the reference's intended `gather_grad`, era5_data/utils_dist.py:125-134)."""
+    inp, inp_s, tgt, tgt_s = batch
+    optimizer.zero_grad(set_to_none=True)
+    out, out_s = model(inp, inp_s, statistics, maps, const_h)
+    if stats_last is not None:
+        tgt, tgt_s = norm_data(tgt, tgt_s, stats_last)
+    loss = weighted_l1_loss(out, out_s, tgt, tgt_s)
+    loss.backward()
+    if grad_sync is not None:
+        grad_sync()
+    optimizer.step()
+    return loss.detach()
