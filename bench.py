@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the secondary DDP training-step measurement")
+    ap.add_argument("--train-steps", type=int, default=3)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -132,6 +134,35 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
+    # ---- secondary metric: DDP finetune step (BASELINE configs[3] shape: 1 sample/GPU, fwd + bwd + bucketed RCCL
+    # gradient all-reduce overlapped with backward + Adam), reported beside the headline number
+    train_res = None
+    if not args.no_train:
+        from pangu_pytorch_amd import train
+        from pangu_pytorch_amd.dist import FlatGradSync
+        del out
+        model.train()
+        tgt, tgt_s = cases.model_targets(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=5e-6, weight_decay=3e-6)      # reference finetune_fully.py:121
+        sync = FlatGradSync(model) if world > 1 else None
+        batch = (inp, inp_s, tgt, tgt_s)
+        torch.manual_seed(1234 + rank)            # DropPath draws (host RNG)
+        for _ in range(1):
+            train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=sync.finish if sync else None)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.train_steps):
+            loss = train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=sync.finish if sync else None)
+        barrier()
+        t_train = time.perf_counter() - t1
+        if dist is not None:
+            t = torch.tensor([t_train], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t_train = t.item()
+        train_res = {"metric": "DDP finetune samples/s (fwd+bwd+grad all-reduce+Adam, fp32, 1 sample/GPU, DropPath on)",
+                     "value": world * args.train_steps / t_train, "ms_per_step": t_train / args.train_steps * 1e3,
+                     "steps": args.train_steps, "loss": float(loss), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2**30}
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
@@ -148,6 +179,8 @@ def main():
                          "traffic": None, "launches": gemm_launches, "avg_launch_ms": gemm_ms / max(gemm_launches, 1),
                          "share_of_step": gemm_ms / (ms * args.steps)},
         }
+        if train_res is not None:
+            res["ddp_train"] = train_res
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))

@@ -1,0 +1,159 @@
+"""Data-parallel plumbing: one process per GPU, RCCL over xGMI (torch.distributed backend "nccl" on ROCm).
+
+Counterpart of the reference's era5_data/utils_dist.py (init_dist :13-28, get_dist_info :65-76, and the intended but
+never-called gradient averaging `gather_grad` :125-134 = all_reduce(SUM) then / world_size per parameter).
+
+MI355X design: `gather_grad`'s 223 per-parameter messages (~140 of them < 8 KB) would be launch-latency bound, and
+the payload is dominated by sixteen 62-64 MB earth_specific_bias gradients.  Here gradients live in ONE flat
+fp32 buffer (1.107 GB) cut into buckets along block boundaries in reverse execution order; each bucket is
+all-reduced (average) asynchronously as soon as backward has produced its last gradient, so the collective runs on
+RCCL's stream underneath the remaining backward kernels.  After `finish()` every `p.grad` is a view into the flat
+buffer, which the optimizer then reads in place.
+"""
+import os
+
+import torch
+import torch.distributed as tdist
+
+
+def init_dist(launcher="pytorch", backend="nccl", **kwargs):
+    """reference utils_dist.py:13-28: rank from the environment, one GPU per process."""
+    if launcher != "pytorch":
+        raise ValueError(f"unsupported launcher {launcher!r} (only the torch.distributed.run env:// rendezvous)")
+    rank = int(os.environ["RANK"])
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":
+        local = int(os.environ.get("LOCAL_RANK", rank % max(torch.cuda.device_count(), 1)))
+        torch.cuda.set_device(local)
+        kwargs.setdefault("device_id", torch.device("cuda", local))
+    tdist.init_process_group(backend=backend, **kwargs)
+
+
+def get_dist_info():
+    """reference utils_dist.py:65-76 -> (rank, world_size)."""
+    if tdist.is_available() and tdist.is_initialized():
+        return tdist.get_rank(), tdist.get_world_size()
+    return 0, 1
+
+
+_EXEC_POS = {"_input_layer": 0, "downsample": 2, "upsample": 5, "_output_layer": 7}
+_LAYER_POS = {0: 1, 1: 3, 2: 4, 3: 6}       # forward order: embed, L0, down, L1, L2, up, L3, recover
+
+
+def default_buckets(model):
+    """Parameter groups in the order backward finishes them (reverse forward order): output layer, layer-3 blocks
+    (last first), upsample, layer 2, layer 1, downsample, layer 0, input layer.  One bucket per block: each holds one
+    62-64 MB earth_specific_bias gradient plus ~1.8-7 MB of projection weights."""
+    groups, pos = {}, {}
+    for n, p in model.named_parameters():
+        parts = n.split(".")
+        if parts[0] == "layers" and len(parts) > 4:
+            k = ".".join(parts[:4])             # layers.EarthSpecificLayerI.blocks.EarthSpecificBlockJ
+            li = int("".join(c for c in parts[1] if c.isdigit()) or 0)
+            bj = int("".join(c for c in parts[3] if c.isdigit()) or 0)
+            where = (_LAYER_POS.get(li, 10 + li), bj)
+        else:
+            k = parts[0]
+            where = (_EXEC_POS.get(k, 100 + len(groups)), 0)
+        if k not in groups:
+            groups[k], pos[k] = [], where
+        groups[k].append(p)
+    return [groups[k] for k in sorted(groups, key=lambda k: pos[k], reverse=True)]
+
+
+class FlatGradSync:
+    """Bucketed, backward-overlapped gradient averaging over a flat buffer.
+
+    usage:   sync = FlatGradSync(model);   loss.backward();   sync.finish();   optimizer.step()
+    """
+
+    def __init__(self, model, process_group=None, buckets=None, average=True):
+        self.group = process_group
+        self.world = tdist.get_world_size(process_group) if tdist.is_initialized() else 1
+        self.average = average
+        params = [p for p in model.parameters() if p.requires_grad]
+        buckets = buckets if buckets is not None else default_buckets(model)
+        buckets = [[p for p in b if p.requires_grad] for b in buckets]
+        buckets = [b for b in buckets if b]
+        assert sum(len(b) for b in buckets) == len(params), "buckets must cover every trainable parameter once"
+        dev, dtype = params[0].device, params[0].dtype
+        total = sum(p.numel() for p in params)
+        self.flat = torch.zeros(total, dtype=dtype, device=dev)
+        self.buckets = []          # (start, end, [(param, view)])
+        off = 0
+        self._slot = {}
+        for bi, b in enumerate(buckets):
+            start = off
+            views = []
+            for p in b:
+                v = self.flat[off:off + p.numel()].view_as(p)
+                views.append((p, v))
+                self._slot[p] = (bi, v)
+                off += p.numel()
+            self.buckets.append((start, off, views))
+        self._pending = [len(b[2]) for b in self.buckets]
+        self._fired = set()
+        self._next = 0             # buckets are launched strictly in order: identical collective order on every rank
+        self._works = []
+        self._gloo = tdist.is_initialized() and tdist.get_backend(process_group) == "gloo"
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
+
+    # -- per-parameter hook: move the fresh gradient into its flat slot; launch every bucket that became complete
+    def _on_grad(self, p):
+        bi, view = self._slot[p]
+        if p.grad.data_ptr() != view.data_ptr():
+            view.copy_(p.grad)
+            p.grad = view
+        self._fired.add(p)
+        self._pending[bi] -= 1
+        while self._next < len(self.buckets) and self._pending[self._next] == 0:
+            self._launch(self._next)
+            self._next += 1
+
+    def _launch(self, bi):
+        if self.world == 1:
+            return
+        start, end, _ = self.buckets[bi]
+        chunk = self.flat[start:end]
+        if self.average and not self._gloo:
+            self._works.append((tdist.all_reduce(chunk, op=tdist.ReduceOp.AVG, group=self.group, async_op=True), None))
+        else:   # gloo has no AVG: SUM then divide (exactly gather_grad's arithmetic)
+            self._works.append((tdist.all_reduce(chunk, op=tdist.ReduceOp.SUM, group=self.group, async_op=True),
+                                chunk if self.average else None))
+
+    def finish(self):
+        """Launch what backward left incomplete (parameters without a gradient this step, e.g. a DropPath-dropped
+        branch, contribute zeros), then wait for every bucket.  Afterwards each p.grad is a view of `flat`."""
+        for bi in range(self._next, len(self.buckets)):
+            for p, v in self.buckets[bi][2]:
+                if p not in self._fired:
+                    v.zero_()
+                    p.grad = v
+            self._launch(bi)
+        for work, chunk in self._works:
+            work.wait()
+            if chunk is not None:
+                chunk.div_(self.world)
+        self._works = []
+        self._fired = set()
+        self._next = 0
+        self._pending = [len(b[2]) for b in self.buckets]
+
+    def zero_grad(self):
+        """Zero the flat buffer in one memset; gradients stay views into it."""
+        self.flat.zero_()
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
+def gather_grad(params, world_size=None):
+    """reference utils_dist.py:125-134 verbatim semantics (per-parameter SUM then divide) — kept for API parity and as
+    the slow baseline the flat-buffer path is checked against."""
+    world_size = world_size or get_dist_info()[1]
+    for p in params:
+        if p.grad is not None:
+            tdist.all_reduce(p.grad.data, op=tdist.ReduceOp.SUM)
+            p.grad.data.div_(world_size)
