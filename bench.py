@@ -166,6 +166,14 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        # HBM bytes per launch of the same kernel family from the committed rocprofv3 PMC run (separate --pmc passes,
+        # FETCH_SIZE doubled per MI355X_MICROARCH.md): counters cannot be read from inside this process
+        traffic, mfma_busy = None, None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_f32.json")))["gemm"]
+            traffic, mfma_busy = pmc["hbm_bytes_per_launch"], pmc["mfma_busy_frac"]
+        except (OSError, KeyError, ValueError):
+            pass
         res = {
             "metric": "forward steps/sec (721x1440x13pl) per MI355X", "value": world * args.steps / elapsed,
             "unit": "forward steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -176,7 +184,9 @@ def main():
             "model_tflops": FWD_GFLOP / ms,
             "roofline": {"bound": "mfma", "kernel": "gemm_tn_f32_kernel (all projection GEMMs)", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": None, "launches": gemm_launches, "avg_launch_ms": gemm_ms / max(gemm_launches, 1),
+                         "traffic": traffic, "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, profiles/pmc_traffic_f32.json)",
+                         "algorithmic_flop_per_launch": gemm_flop / max(gemm_launches, 1),
+                         "mfma_busy_frac_pmc": mfma_busy, "launches": gemm_launches, "avg_launch_ms": gemm_ms / max(gemm_launches, 1),
                          "share_of_step": gemm_ms / (ms * args.steps)},
         }
         if train_res is not None:

@@ -1,6 +1,6 @@
 """Generate golden vectors by running the REFERENCE itself (build container only; needs /root/reference).
 
-TEST INFRASTRUCTURE. Usage:  python oracle/gen_golden.py [index] [blocks] [layers] [model] [model_bwd]
+TEST INFRASTRUCTURE. Usage:  python oracle/gen_golden.py [index] [blocks] [layers] [model] [model_bwd] [model_bwd_smooth]
 Outputs small fixtures (fingerprints: samples + sums, index tensors, packed masks) under tests/golden/.
 Inputs and parameters are closed-form (oracle/synth.py), so tests regenerate them bit-identically.
 """
@@ -168,6 +168,25 @@ def build_model(M):
     return model
 
 
+def gen_model_smooth(L, M):
+    """Whole-model backward under a SMOOTH loss (sum(out*cot)): gradients without the L1 loss' sign discontinuity,
+    so they can be compared tightly."""
+    model = build_model(M).eval()
+    inp, inp_s, stats, maps, const_h = cases.model_inputs()
+    t = time.time()
+    out, out_s = model(inp, inp_s, stats, maps, const_h)
+    loss = ((out * cases.cotangent("model_out", out.shape)).sum() +
+            (out_s * cases.cotangent("model_out_s", out_s.shape)).sum()) / out.numel()
+    loss.backward()
+    print("model smooth fwd+bwd ref %.1fs loss %.8f" % (time.time() - t, loss.item()))
+    d = {"model.loss": torch.tensor([loss.item()], dtype=torch.float64)}
+    for k, p in model.named_parameters():
+        s = cases.summarize(p.grad, "model.d_" + k)
+        d[f"model.d_{k}.samples"] = s[f"model.d_{k}.samples"][:256]
+        d[f"model.d_{k}.abs_sum"] = s[f"model.d_{k}.abs_sum"]
+    save("model_bwd_smooth.npz", d)
+
+
 def gen_model(L, M, backward):
     model = build_model(M).eval()
     inp, inp_s, stats, maps, const_h = cases.model_inputs()
@@ -212,3 +231,5 @@ if __name__ == "__main__":
         gen_model(L, M, backward=False)
     if "model_bwd" in what:
         gen_model(L, M, backward=True)
+    if "model_bwd_smooth" in what:
+        gen_model_smooth(L, M)

@@ -58,6 +58,11 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
 
   for (int l = 0; l < g.nLon; ++l) {
     __syncthreads();                               // previous window's LDS reads are done
+    // the bias tile is the same for every window: stop the compiler from hoisting its 72 loads out of this loop
+    // (register cap 168 at 9 waves per workgroup); it is re-read from L2 instead
+    long lz = 0;
+    asm volatile("" : "+s"(lz));
+    const float* bias_l = bias_tile + lz;
     if (tid < PANGU_WTOK) tok_s[tid] = win_src_token(g, l, t, tid, SHIFTED);
     __syncthreads();
     // ---- stage Qs (scaled), K, V, dO; delta = rowsum(dO o O); lse
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
       const f32x4 g0 = *reinterpret_cast<const f32x4*>(&Gs[qn * KV_LD + lg * 8]);
       const f32x4 g1 = *reinterpret_cast<const f32x4*>(&Gs[qn * KV_LD + lg * 8 + 4]);
       const float my_lse = lse_s[qn], my_del = del_s[qn];
-      const float* brow = bias_tile + (size_t)qn * PANGU_WTOK + lg * 4;
+      const float* brow = bias_l + (size_t)qn * PANGU_WTOK + lg * 4;
       f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 9; ++j) {
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int qn = i * 16 + lg * 4 + r;
-          float sv = s[r] + bias_tile[(size_t)qn * PANGU_WTOK + kn];
+          float sv = s[r] + bias_l[(size_t)qn * PANGU_WTOK + kn];
           if (SHIFTED) { if (masked(qn, kn)) sv += -100.0f; }
           p[r] = __expf(sv - ls[r]);
           ds[r] = p[r] * (dp[r] - dl[r]);

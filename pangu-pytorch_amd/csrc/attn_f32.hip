@@ -19,7 +19,7 @@ namespace {
 constexpr int KV_LD = 36;
 
 template <bool SHIFTED>
-__global__ __launch_bounds__(192) void window_attn_f32_kernel(const float* __restrict__ qkv,
+__global__ __launch_bounds__(192, 3) void window_attn_f32_kernel(const float* __restrict__ qkv,
                                                               const float* __restrict__ qkv_bias,
                                                               const float* __restrict__ esb,
                                                               float* __restrict__ out, float* __restrict__ lse,
@@ -65,9 +65,28 @@ __global__ __launch_bounds__(192) void window_attn_f32_kernel(const float* __res
     hcut = hwin == g.nHw - 1;
   }
 
+  // per-lane key-class bits (bit 4j+r <-> key 16j+4lg+r): kz = key in the upper z-plane, kh = key in rows hi<3
+  unsigned long long kz_bits = 0ull, kh_bits = 0ull;
+  if (SHIFTED) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kn = j * 16 + lg * 4 + r;
+        if (kn >= 72) kz_bits |= 1ull << (4 * j + r);
+        if (((kn / 12) % 6) < 3) kh_bits |= 1ull << (4 * j + r);
+      }
+  }
+
   for (int qt = wave; qt < 9; qt += 3) {
     const int qn = qt * 16 + lq;                 // this lane's query slot in the window
     const int qtok = tok_s[qn];
+    // K/V fragments are the same for every query tile; keep them in LDS rather than letting the compiler hoist
+    // 200+ loop-invariant registers out of this loop (which halves the occupancy): opaque zero offset.
+    int lz = 0;
+    asm volatile("" : "+v"(lz));
+    const float* Ksq = Ks + lz;
+    const float* Vsq = Vs + lz;
     // Q fragment: 8 dims d = 8*lg .. 8*lg+7 of query qn, pre-scaled
     f32x4 q0, q1;
     {
@@ -76,41 +95,53 @@ __global__ __launch_bounds__(192) void window_attn_f32_kernel(const float* __res
       q1 = *reinterpret_cast<const f32x4*>(src + 4);
       q0 *= scale; q1 *= scale;
     }
-    // ---- S^T = K (scale Q)^T : 9 key tiles
+    // ---- S^T = bias^T + K (scale Q)^T : 9 key tiles; the bias tile is the accumulator's initial value.
+    // Key tiles go three at a time so consecutive MFMAs hit different accumulators (16x16x4 f32: 32-cycle issue,
+    // 40-cycle dependent latency).
+    const float* brow = bias_tile + (size_t)qn * PANGU_WTOK + lg * 4;
     f32x4 s[9];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 9; ++j) s[j] = *reinterpret_cast<const f32x4*>(brow + j * 16);
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
-      const f32x4 k0 = *reinterpret_cast<const f32x4*>(&Ks[(j * 16 + lq) * KV_LD + lg * 8]);
-      const f32x4 k1 = *reinterpret_cast<const f32x4*>(&Ks[(j * 16 + lq) * KV_LD + lg * 8 + 4]);
+    for (int j0 = 0; j0 < 9; j0 += 3) {
+      f32x4 k0[3], k1[3];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) s[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(k0[ks], q0[ks], s[j], 0, 0, 0);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) s[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(k1[ks], q1[ks], s[j], 0, 0, 0);
-    }
-    // lane holds S^T[key = 16j + 4lg + r][query = qn], r = 0..3
-    // ---- + earth-specific bias (+ mask), row max
-    const float* brow = bias_tile + (size_t)qn * PANGU_WTOK + lg * 4;
-    float mx = -INFINITY;
-    const int zq = qn >= 72, hq = ((qn / 12) % 6) < 3;
-#pragma unroll
-    for (int j = 0; j < 9; ++j) {
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(brow + j * 16);
-      s[j] += bv;
-      if (SHIFTED) {
-        if (zcut || hcut) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int kn = j * 16 + lg * 4 + r;
-            const int zk = kn >= 72, hk = ((kn / 12) % 6) < 3;
-            if ((zcut && zq != zk) || (hcut && hq != hk)) s[j][r] += -100.0f;
-          }
-        }
+      for (int jj = 0; jj < 3; ++jj) {
+        k0[jj] = *reinterpret_cast<const f32x4*>(&Ksq[((j0 + jj) * 16 + lq) * KV_LD + lg * 8]);
+        k1[jj] = *reinterpret_cast<const f32x4*>(&Ksq[((j0 + jj) * 16 + lq) * KV_LD + lg * 8 + 4]);
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[j][r]);
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj)
+          s[j0 + jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(k0[jj][ks], q0[ks], s[j0 + jj], 0, 0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj)
+          s[j0 + jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(k1[jj][ks], q1[ks], s[j0 + jj], 0, 0, 0);
     }
+    // lane holds S^T[key = 16j + 4lg + r][query = qn], r = 0..3
+    // ---- shift mask (closed form, only in the cut window types), row max
+    float mx = -INFINITY;
+    if (SHIFTED) {
+      if (zcut || hcut) {
+        const bool zq = qn >= 72, hq = ((qn / 12) % 6) < 3;
+        // bit (4j + r) of the key-class words: this lane's 36 keys kn = 16j + 4lg + r
+        const unsigned long long zsel = zq ? ~kz_bits : kz_bits;      // keys whose z-half differs from the query's
+        const unsigned long long hsel = hq ? ~kh_bits : kh_bits;
+        const unsigned long long cut = (zcut ? zsel : 0ull) | (hcut ? hsel : 0ull);
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if ((cut >> (4 * j + r)) & 1ull) s[j][r] += -100.0f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[j][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.f;
@@ -131,8 +162,8 @@ __global__ __launch_bounds__(192) void window_attn_f32_kernel(const float* __res
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = j * 16 + lg * 4 + r;
-        const float v0 = Vs[key * KV_LD + lq];
-        const float v1 = Vs[key * KV_LD + 16 + lq];
+        const float v0 = Vsq[key * KV_LD + lq];
+        const float v1 = Vsq[key * KV_LD + 16 + lq];
         o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, s[j][r], o0, 0, 0, 0);
         o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, s[j][r], o1, 0, 0, 0);
       }

@@ -50,11 +50,25 @@ __host__ __device__ inline float win_mask(const WinGeom& g, int t, int ni, int n
   return (zcut || hcut) ? -100.0f : 0.0f;
 }
 
-__device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf(x), |abs err| < 1.5e-7 (Abramowitz-Stegun 7.1.26), branch-free: 1 rcp + 1 exp + 6 fma.  The exact-erf GELU
+// of the reference (nn.GELU(), layers.py:261) is reproduced to ~4e-7 absolute, i.e. at fp32 rounding level of
+// the O(1) activations, at a third of the instruction count of the libm erff (which branches per lane).
+__device__ inline float erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float r = 1.0f - p * t * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+
+__device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 
 // d/dx gelu(x) = Phi(x) + x*phi(x)
 __device__ inline float gelu_erf_grad(float x) {
-  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+  return 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 
 __device__ inline float wave_sum(float v) {

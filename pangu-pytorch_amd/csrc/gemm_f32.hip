@@ -10,15 +10,19 @@
 // Block -> tile map is XCD-aware: workgroups that share an A row-panel (the n-tiles of one m-tile) are
 // consecutive on ONE XCD, so the panel is fetched from HBM once and re-read from that XCD's L2.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int BM = 128;
 constexpr int BK = 16;
 constexpr int LDS_LD = 20;   // padded row (floats)
+#ifndef GEMM_WAVES_PER_SIMD
+#define GEMM_WAVES_PER_SIMD 3
+#endif
 
 template <int TN, int ACT, bool HAS_BIAS>
-__global__ __launch_bounds__(256, 2) void gemm_tn_f32_kernel(const float* __restrict__ A, int lda,
+__global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_tn_f32_kernel(const float* __restrict__ A, int lda,
                                                              const float* __restrict__ W,
                                                              const float* __restrict__ bias,
                                                              float* __restrict__ C, int ldc, int M, int N, int K,
@@ -93,24 +97,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_kernel(const float* __rest
     }
     const float* As = smem[kt & 1];
     const float* Ws = As + BM * LDS_LD;
-    f32x4 fa[2][2], fw[TN][2];
+    // fragments in two halves (k-steps 0-3, then 4-7): 20 live fragment registers instead of 40
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      fa[i][0] = *reinterpret_cast<const f32x4*>(&As[rd_a + i * 32 * LDS_LD]);
-      fa[i][1] = *reinterpret_cast<const f32x4*>(&As[rd_a + i * 32 * LDS_LD + 4]);
+    for (int hf = 0; hf < 2; ++hf) {
+      f32x4 fa[2], fw[TN];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f32x4*>(&As[rd_a + i * 32 * LDS_LD + 4 * hf]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fw[j] = *reinterpret_cast<const f32x4*>(&Ws[rd_w + j * 32 * LDS_LD + 4 * hf]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fw[j][s], acc[i][j], 0, 0, 0);
     }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      fw[j][0] = *reinterpret_cast<const f32x4*>(&Ws[rd_w + j * 32 * LDS_LD]);
-      fw[j][1] = *reinterpret_cast<const f32x4*>(&Ws[rd_w + j * 32 * LDS_LD + 4]);
-    }
-#pragma unroll
-    for (int s = 0; s < 8; ++s)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s >> 2][s & 3], fw[j][s >> 2][s & 3], acc[i][j], 0, 0, 0);
     if (more) {
       float* An = smem[(kt + 1) & 1];
       float* Wn = An + BM * LDS_LD;
@@ -201,8 +203,15 @@ extern "C" int pangu_linear_fwd(pangu_stream_t stream, const float* A, int lda, 
   if (act != PANGU_ACT_NONE && act != PANGU_ACT_GELU && act != PANGU_ACT_GELU_BWD) return PANGU_E_ARG;
   if (act == PANGU_ACT_GELU_BWD && !aux) return PANGU_E_NULL;
   hipStream_t s = (hipStream_t)stream;
-  // widest tile that divides N (192 covers every projection of this model except the recovery convs)
-  if (N % 192 == 0) return launch_tn<3>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
+  static const int force_tn = getenv("PANGU_GEMM_TN") ? atoi(getenv("PANGU_GEMM_TN")) : 0;   // tuning knob
+  if (force_tn == 1) return launch_tn<1>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
+  if (force_tn == 2) return launch_tn<2>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
+  if (force_tn == 3) return launch_tn<3>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
+  // Tile width (measured per shape on MI355X, tools/bench_kernels.py): 192 columns wherever N is a multiple of 192
+  // or fits one tile (N = 160: 17 % padded MFMAs still beat three 64-wide tiles); N = 384 as 3 x 128 (3072 tiles =
+  // exactly 4 waves of the 768 resident workgroups, vs 2048 = 2.67 with 192-wide tiles).
+  if (N == 384) return launch_tn<2>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
+  if (N % 192 == 0 || (N > 128 && N < 192)) return launch_tn<3>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
   if (N % 128 == 0) return launch_tn<2>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
   return launch_tn<1>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
 }

@@ -161,10 +161,12 @@ def test_full_training_step_golden(P, golden_dir):
     loss.backward()
     assert abs(loss.item() - float(g["model.loss"][0])) / float(g["model.loss"][0]) < 1e-5
     # Tolerances.  The L1 loss' gradient is sign(o - t): an output within rounding distance of its target flips a
-    # +-w/N term between two correct fp32 implementations, so element-wise gradient samples carry O(1e-3) noise
-    # where sums cancel (measured: worst 2.2e-3 on _output_layer.conv.bias, <= 1.2e-3 on bias-table samples);
-    # the gradient MASS per tensor (sum |g|, no cancellation) must agree to 1e-3 (measured <= 2.1e-4).
-    SAMPLE_TOL, MASS_TOL = 5e-3, 1e-3
+    # +-w/N term between two correct fp32 implementations, so element-wise gradient samples carry O(1e-3..1e-2)
+    # noise where sums cancel (measured: 2.2e-3 on _output_layer.conv.bias, up to 8.4e-3 on single bias-table
+    # samples, changing with any last-bit change of the forward).  The sign-free check of the same backward is
+    # test_full_backward_smooth_golden below; here the gradient MASS per tensor (sum |g|, no cancellation) must
+    # agree to 1e-3 (measured <= 2.1e-4) and samples to 2e-2.
+    SAMPLE_TOL, MASS_TOL = 2e-2, 1e-3
     worst, worst_mass = ("", 0.0), ("", 0.0)
     for k, p in m.named_parameters():
         assert p.grad is not None, k
@@ -181,3 +183,34 @@ def test_full_training_step_golden(P, golden_dir):
             worst_mass = (k, mass)
     assert worst[1] < SAMPLE_TOL, worst
     assert worst_mass[1] < MASS_TOL, worst_mass
+
+
+def test_full_backward_smooth_golden(P, golden_dir):
+    """Whole-model backward under a smooth loss (sum(out * cotangent) / numel): all 223 gradients vs the reference's
+    autograd, without the L1 sign discontinuity -> tight tolerance."""
+    path = os.path.join(golden_dir, "model_bwd_smooth.npz")
+    if not os.path.exists(path):
+        pytest.skip("model_bwd_smooth.npz not generated")
+    g = np.load(path)
+    m = P.PanguModel(device="cuda").cuda().eval()
+    m.load_state_dict(synth.fill_state_dict(cases.model_param_shapes(), "cuda"))
+    inp, inp_s, stats, maps, const_h = cases.model_inputs("cuda")
+    out, out_s = m(inp, inp_s, stats, maps, const_h)
+    loss = ((out * cases.cotangent("model_out", out.shape, "cuda")).sum() +
+            (out_s * cases.cotangent("model_out_s", out_s.shape, "cuda")).sum()) / out.numel()
+    loss.backward()
+    ref_loss = float(g["model.loss"][0])
+    assert abs(loss.item() - ref_loss) < 1e-3 * max(abs(ref_loss), 1e-3)
+    worst, worst_mass = ("", 0.0), ("", 0.0)
+    for k, p in m.named_parameters():
+        flat = p.grad.detach().float().flatten()
+        pos = synth.sample_positions(flat.numel(), cases.NSAMP, synth.name_seed("pos_model.d_" + k), device=flat.device)[:256]
+        gs = torch.as_tensor(g[f"model.d_{k}.samples"])
+        gabs = float(g[f"model.d_{k}.abs_sum"][0])
+        scale = max(gs.abs().max().item(), gabs / flat.numel())
+        err = ((flat[pos].cpu() - gs).abs().max().item()) / scale
+        mass = abs(flat.double().abs().sum().item() - gabs) / gabs
+        worst = max(worst, (k, err), key=lambda t: t[1])
+        worst_mass = max(worst_mass, (k, mass), key=lambda t: t[1])
+    assert worst[1] < REL, worst
+    assert worst_mass[1] < REL, worst_mass
