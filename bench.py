@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bf16", action="store_true", help="skip the secondary bf16 forward measurement")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary DDP training-step measurement")
     ap.add_argument("--train-steps", type=int, default=3)
     args = ap.parse_args()
@@ -133,6 +134,26 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+
+    # ---- secondary metric: bf16 inference forward (BASELINE configs[2]/[4] precision), same inputs
+    bf16_res = None
+    if not args.no_bf16:
+        model.set_compute_dtype(torch.bfloat16)
+        for _ in range(2):
+            step()
+        barrier()
+        tb = time.perf_counter()
+        for _ in range(args.steps):
+            out_b = step()
+        barrier()
+        tb = time.perf_counter() - tb
+        ref = out[0].double()
+        drift = ((out_b[0].double() - ref).norm() / ref.norm()).item()
+        bf16_res = {"metric": "bf16 forward steps/s (bf16 activations+weights, fp32 LN/softmax/accumulate)",
+                    "value": world * args.steps / tb, "ms_per_step": tb / args.steps * 1e3,
+                    "rel_l2_drift_vs_f32": drift, "model_tflops": FWD_GFLOP / (tb / args.steps * 1e3)}
+        model.set_compute_dtype(torch.float32)
+        del out_b
 
     # ---- secondary metric: DDP finetune step (BASELINE configs[3] shape: 1 sample/GPU, fwd + bwd + bucketed RCCL
     # gradient all-reduce overlapped with backward + Adam), reported beside the headline number
@@ -189,6 +210,8 @@ def main():
                          "mfma_busy_frac_pmc": mfma_busy, "launches": gemm_launches, "avg_launch_ms": gemm_ms / max(gemm_launches, 1),
                          "share_of_step": gemm_ms / (ms * args.steps)},
         }
+        if bf16_res is not None:
+            res["bf16_forward"] = bf16_res
         if train_res is not None:
             res["ddp_train"] = train_res
         if world == 1 and not args.no_cpu_baseline:

@@ -152,6 +152,32 @@ int pangu_patch_recover_scatter(pangu_stream_t stream, const float* y_upper, con
 int pangu_patch_recover_gather_bwd(pangu_stream_t stream, const float* d_output, const float* d_output_surface,
                                    float* dy_upper, float* dy_surface, int LAT, int LON);
 
+/* ---- bf16 variants (BASELINE configs[2], [4]) --------------------------------------------------------------
+ * Activations and weight shadows are bf16 (raw uint16 bit patterns); biases, LayerNorm parameters, softmax and all
+ * accumulation stay fp32.  Same semantics and layouts as the fp32 entry points above. */
+
+/* C = act(A @ W^T + bias): A [M][K] bf16 (row stride lda), W [N][K] bf16, bias fp32 (may be NULL), C bf16 or fp32
+ * (out_dtype = PANGU_BF16 / PANGU_F32), aux bf16 [M][N].  K % 8 == 0, N % 8 == 0. */
+int pangu_linear_fwd_bf16(pangu_stream_t stream, const void* A, int lda, const void* W, const float* bias, void* C,
+                          int ldc, int M, int N, int K, int act, void* aux, int out_dtype);
+
+/* qkv, qkv_bias, esb, out bf16; lse fp32 (may be NULL). */
+int pangu_window_attn_fwd_bf16(pangu_stream_t stream, const void* qkv, const void* qkv_bias, const void* esb, void* out,
+                               float* lse, int Z, int H, int W, int C, int heads, int shifted);
+
+int pangu_ln_residual_fwd_bf16(pangu_stream_t stream, const void* y, const void* shortcut, int lds, const float* gamma,
+                               const float* beta, void* out, int ldo, int N, int C, float branch_scale);
+int pangu_downsample_ln_fwd_bf16(pangu_stream_t stream, const void* x, int ldx, const float* gamma, const float* beta,
+                                 void* out, int Z, int H, int W, int C);
+int pangu_upsample_ln_fwd_bf16(pangu_stream_t stream, const void* y, const float* gamma, const float* beta, void* out,
+                               int Z, int H2, int W2, int H, int Co);
+
+/* fp32 fields -> bf16 GEMM operands; a_surface is [H4*W4][128] (columns 112..127 zero: K padded to a multiple of 64). */
+int pangu_patch_embed_gather_bf16(pangu_stream_t stream, const float* input, const float* input_surface,
+                                  const float* surface_mean, const float* surface_std, const float* upper_mean,
+                                  const float* upper_std, const float* maps, const float* const_h, void* a_surface,
+                                  void* a_upper, int LAT, int LON);
+
 #ifdef __cplusplus
 }
 #endif

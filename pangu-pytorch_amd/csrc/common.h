@@ -55,7 +55,7 @@ __host__ __device__ inline float win_mask(const WinGeom& g, int t, int ni, int n
 // the O(1) activations, at a third of the instruction count of the libm erff (which branches per lane).
 __device__ inline float erf_fast(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));   // v_rcp_f32 (1 ulp), not an IEEE division
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);

@@ -1,0 +1,261 @@
+// bf16 projection GEMM for gfx950: C[M,N] = act(A[M,K] @ W[N,K]^T + bias), bf16 operands, fp32 accumulate.
+//
+// At this path's shapes (M = 65k..521k tokens, N,K <= 1536) a bf16 projection moves ~1 GB for ~0.15 TFLOP: it sits on
+// the HBM/MFMA ridge, so the kernel is built to stream: 128 x (64*TN) tile per 256-thread workgroup (4 waves 2x2,
+// wave tile 64 x 32*TN), BK = 64, two workgroups per CU (2 x 80 KB LDS) so one workgroup's barrier / epilogue hides
+// under the other's MFMAs.
+//   MFMA: v_mfma_f32_16x16x32_bf16 with SWAPPED operands (W fragment as A, activation fragment as B), so an
+//   accumulator lane holds 4 consecutive output COLUMNS of one row: bias/GELU act on float4s and the bf16 result
+//   packs to 8 bytes; the tile is then transposed through LDS and leaves as whole 16-B row segments.
+//   LDS image: [row][64 bf16] (128-B rows), 16-B chunk index XOR-swizzled with (row>>1)&7: conflict-free for the
+//   ds_read_b128 lane groups (each group holds 16 distinct rows with chunks c / c^1) and for the staging writes.
+//   Staging: global_load_dwordx4 -> registers -> ds_write_b128 one K-step ahead (double-buffered LDS).
+#include "common.h"
+
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int BBM = 128;
+constexpr int BBK = 64;
+
+__device__ inline u16 f2bf(float f) {   // round-to-nearest-even, NaN-preserving via the hardware convert
+  return __builtin_bit_cast(u16, (__bf16)f);
+}
+__device__ inline unsigned pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+
+__device__ inline int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }   // byte offset
+
+template <int TN, int ACT, bool HAS_BIAS, bool OUT_F32>
+__global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const u16* __restrict__ A, int lda,
+                                                              const u16* __restrict__ W, const float* __restrict__ bias,
+                                                              void* __restrict__ Cv, int ldc, int M, int N, int K,
+                                                              int m_tiles, int n_tiles, u16* __restrict__ aux) {
+  constexpr int BN = 64 * TN;
+  constexpr int STAGE = (BBM + BN) * 128;                 // bytes per LDS stage
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int b = blockIdx.x;
+  const int xcd = b & 7, local = b >> 3;
+  const int m_tile = (local / n_tiles) * 8 + xcd;
+  const int n_tile = local % n_tiles;
+  if (m_tile >= m_tiles) return;
+  const int m0 = m_tile * BBM, n0 = n_tile * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lc = lane & 15, lg = lane >> 4;
+
+  // staging: (BBM + BN) rows x 8 chunks of 16 B; chunk id f = tid + 256*i -> row f>>3, chunk f&7
+  constexpr int NCH = (BBM + BN) * 8 / 256;               // 4 + 2*TN chunks per thread
+  const u16* src[NCH];
+  int dst[NCH];
+  const int kchunk = tid & 7;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int row = (tid >> 3) + 32 * i;                   // 0 .. BBM+BN-1
+    if (row < BBM) {
+      int r = m0 + row;
+      r = r < M ? r : M - 1;
+      src[i] = A + (size_t)r * lda + kchunk * 8;
+    } else {
+      int r = n0 + row - BBM;
+      r = r < N ? r : N - 1;
+      src[i] = W + (size_t)r * K + kchunk * 8;
+    }
+    dst[i] = (row < BBM ? swz(row, kchunk) : BBM * 128 + swz(row - BBM, kchunk));
+  }
+  const int KT = (K + BBK - 1) / BBK;
+  u32x4 stg[NCH];
+  auto fetch = [&](int kt) {
+    const bool in = kt * BBK + kchunk * 8 < K;             // K % 8 == 0: a chunk is entirely inside or outside
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      stg[i] = in ? *reinterpret_cast<const u32x4*>(src[i] + (size_t)kt * BBK) : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) *reinterpret_cast<u32x4*>(smem + buf * STAGE + dst[i]) = stg[i];
+  };
+
+  f32x4 acc[4][2 * TN];                                    // [m tile 16][n tile 16], lane: 4 consecutive n of row m=lc
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2 * TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const bool more = kt + 1 < KT;
+    if (more) fetch(kt + 1);
+    const unsigned char* As = smem + (kt & 1) * STAGE;
+    const unsigned char* Ws = As + BBM * 128;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[4], fw[2 * TN];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        fa[i] = *reinterpret_cast<const bf16x8*>(As + swz(wm * 64 + i * 16 + lc, kk * 4 + lg));
+#pragma unroll
+      for (int j = 0; j < 2 * TN; ++j)
+        fw[j] = *reinterpret_cast<const bf16x8*>(Ws + swz(wn * 32 * TN + j * 16 + lc, kk * 4 + lg));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2 * TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);   // D[n][m]
+    }
+    if (more) stash((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue.  lane (lg, lc) of tile (i, j) holds C[m = wm*64 + 16i + lc][n = wn*32TN + 16j + 4lg + r], r = 0..3
+  const int wave_n0 = n0 + wn * 32 * TN;
+  const int wave_m0 = m0 + wm * 64;
+  if (OUT_F32) {
+    float* C = reinterpret_cast<float*>(Cv);
+    const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        C, 0, (int)(((size_t)(M - 1) * ldc + N) * sizeof(float)), 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 2 * TN; ++j) {
+      const int col = wave_n0 + j * 16 + lg * 4;
+      const bool ok = col < N;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (HAS_BIAS) bv = *reinterpret_cast<const f32x4*>(bias + (ok ? col : 0));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 v = acc[i][j] + bv;
+        if (ACT == PANGU_ACT_GELU) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = gelu_erf(v[c]);
+        }
+        const unsigned off = ok ? ((unsigned)(wave_m0 + i * 16 + lc) * (unsigned)ldc + (unsigned)col) * 4u : 0xFFFFFFFFu;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), c_rsrc, (int)off, 0, 0);
+      }
+    }
+    return;
+  }
+  // bf16 output: per-wave [64][32*TN] bf16 patch in LDS (row stride EP_LD bytes), written as 8-B packed quads,
+  // read back as 16-B row segments -> buffer stores (rows >= M and columns >= N dropped by the range check)
+  constexpr int ROWB = 32 * TN * 2;                        // bytes of payload per patch row
+  constexpr int EP_LD = ROWB + 16;
+  unsigned char* ep = smem + wave * (64 * EP_LD);
+  u16* C = reinterpret_cast<u16*>(Cv);
+  const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      C, 0, (int)(((size_t)(M - 1) * ldc + N) * sizeof(u16)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      aux, 0, aux ? (int)((size_t)M * N * sizeof(u16)) : 0, 0x00020000);
+  constexpr int CPR = ROWB / 16;                           // 16-B chunks per patch row
+  if (ACT == PANGU_ACT_GELU_BWD) {
+    // stage the saved pre-activation patch first (coalesced 16-B loads), so gelu' can be applied in the MFMA layout
+#pragma unroll
+    for (int it = 0; it < CPR; ++it) {
+      const int f = lane + 64 * it, row = f / CPR, ch = f - row * CPR;
+      const int col = wave_n0 + ch * 8;
+      const unsigned off = col < N ? ((unsigned)(wave_m0 + row) * (unsigned)N + (unsigned)col) * 2u : 0xFFFFFFFFu;
+      *reinterpret_cast<u32x4*>(ep + row * EP_LD + ch * 16) = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)off, 0, 0);
+    }
+  }
+  // 16-row groups: finish (bias/activation/pack -> LDS) one group, then read it back as whole 16-B row segments and
+  // store it, so the stores of group i overlap the activation VALU work of group i+1.
+  f32x4 bv[2 * TN];
+#pragma unroll
+  for (int j = 0; j < 2 * TN; ++j) {
+    const int col = wave_n0 + j * 16 + lg * 4;
+    bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (HAS_BIAS) bv[j] = *reinterpret_cast<const f32x4*>(bias + (col < N ? col : 0));
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2 * TN; ++j) {
+      const int col = wave_n0 + j * 16 + lg * 4;
+      f32x4 v = acc[i][j] + bv[j];
+      unsigned char* slot = ep + (i * 16 + lc) * EP_LD + (j * 16 + lg * 4) * 2;
+      if (ACT == PANGU_ACT_GELU_BWD) {
+        const u32x2 xp = *reinterpret_cast<const u32x2*>(slot);
+        v[0] *= gelu_erf_grad(__builtin_bit_cast(float, xp[0] << 16));
+        v[1] *= gelu_erf_grad(__builtin_bit_cast(float, xp[0] & 0xFFFF0000u));
+        v[2] *= gelu_erf_grad(__builtin_bit_cast(float, xp[1] << 16));
+        v[3] *= gelu_erf_grad(__builtin_bit_cast(float, xp[1] & 0xFFFF0000u));
+      }
+      if (ACT == PANGU_ACT_GELU) {
+        if (aux) {                                          // pre-activation out (rounded to bf16, as it will be re-read)
+          const unsigned xo = col < N ? ((unsigned)(wave_m0 + i * 16 + lc) * (unsigned)N + (unsigned)col) * 2u : 0xFFFFFFFFu;
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])}, x_rsrc, (int)xo, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = gelu_erf(v[c]);
+      }
+      *reinterpret_cast<u32x2*>(slot) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+    }
+    // read back rows 16i .. 16i+15 of the patch: 16 * CPR chunks of 16 B
+#pragma unroll
+    for (int it = 0; it < (16 * CPR + 63) / 64; ++it) {
+      const int f = lane + 64 * it;
+      const int row = i * 16 + f / CPR, ch = f % CPR;
+      const int col = wave_n0 + ch * 8;
+      if (f < 16 * CPR) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(ep + row * EP_LD + ch * 16);
+        const unsigned off = col < N ? ((unsigned)(wave_m0 + row) * (unsigned)ldc + (unsigned)col) * 2u : 0xFFFFFFFFu;
+        __builtin_amdgcn_raw_buffer_store_b128(v, c_rsrc, (int)off, 0, 0);
+      }
+    }
+  }
+}
+
+template <int TN, bool OUT_F32>
+int launch_bf16(hipStream_t s, const u16* A, int lda, const u16* W, const float* bias, void* C, int ldc, int M, int N,
+                int K, int act, u16* aux) {
+  constexpr int BN = 64 * TN;
+  const int m_tiles = (M + BBM - 1) / BBM, n_tiles = (N + BN - 1) / BN;
+  const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
+  const size_t shm = 2 * (size_t)(BBM + BN) * 128;
+  dim3 g(grid), blk(256);
+#define PANGU_BGEMM(ACT, HB)                                                                                          \
+  do {                                                                                                                \
+    auto kern = gemm_tn_bf16_kernel<TN, ACT, HB, OUT_F32>;                                                            \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);    \
+    hipLaunchKernelGGL(kern, g, blk, shm, s, A, lda, W, bias, C, ldc, M, N, K, m_tiles, n_tiles, aux);                \
+  } while (0)
+  if (act == PANGU_ACT_GELU) {
+    if (bias) PANGU_BGEMM(PANGU_ACT_GELU, true); else PANGU_BGEMM(PANGU_ACT_GELU, false);
+  } else if (act == PANGU_ACT_GELU_BWD) {
+    if (OUT_F32) return PANGU_E_ARG;
+    PANGU_BGEMM(PANGU_ACT_GELU_BWD, false);
+  } else {
+    if (bias) PANGU_BGEMM(PANGU_ACT_NONE, true); else PANGU_BGEMM(PANGU_ACT_NONE, false);
+  }
+#undef PANGU_BGEMM
+  return pangu_launch_status();
+}
+
+}  // namespace
+
+extern "C" int pangu_linear_fwd_bf16(pangu_stream_t stream, const void* A, int lda, const void* W, const float* bias,
+                                     void* C, int ldc, int M, int N, int K, int act, void* aux, int out_dtype) {
+  if (!A || !W || !C) return PANGU_E_NULL;
+  if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (N & 7) || lda < K || ldc < N || (lda & 7) || (ldc & 3)) return PANGU_E_SHAPE;
+  if (act != PANGU_ACT_NONE && act != PANGU_ACT_GELU && act != PANGU_ACT_GELU_BWD) return PANGU_E_ARG;
+  if (act == PANGU_ACT_GELU_BWD && (!aux || bias)) return PANGU_E_ARG;
+  if (out_dtype != PANGU_BF16 && out_dtype != PANGU_F32) return PANGU_E_DTYPE;
+  if (out_dtype == PANGU_BF16 && (ldc & 7)) return PANGU_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const u16* a = (const u16*)A;
+  const u16* w = (const u16*)W;
+  u16* x = (u16*)aux;
+  const bool wide = (N % 192 == 0) || (N > 128 && N < 192);
+  if (out_dtype == PANGU_F32) {
+    if (wide) return launch_bf16<3, true>(s, a, lda, w, bias, C, ldc, M, N, K, act, x);
+    if (N % 128 == 0) return launch_bf16<2, true>(s, a, lda, w, bias, C, ldc, M, N, K, act, x);
+    return launch_bf16<1, true>(s, a, lda, w, bias, C, ldc, M, N, K, act, x);
+  }
+  if (wide) return launch_bf16<3, false>(s, a, lda, w, bias, C, ldc, M, N, K, act, x);
+  if (N % 128 == 0) return launch_bf16<2, false>(s, a, lda, w, bias, C, ldc, M, N, K, act, x);
+  return launch_bf16<1, false>(s, a, lda, w, bias, C, ldc, M, N, K, act, x);
+}

@@ -1,0 +1,235 @@
+// bf16-I/O variants of the HBM-bound row kernels (fp32 statistics and arithmetic, bf16 loads/stores as 8-byte
+// quads per lane): post-norm residual, down/up-sample gather + LayerNorm, patch-embed gather.
+#include "common.h"
+
+namespace {
+
+typedef unsigned short u16;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr float LN_EPS = 1e-5f;
+constexpr int ROWS_PER_BLOCK = 4;
+
+__device__ inline u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
+__device__ inline f32x4 ld4(const u16* p) {
+  const u32x2 u = *reinterpret_cast<const u32x2*>(p);
+  return f32x4{__builtin_bit_cast(float, u[0] << 16), __builtin_bit_cast(float, u[0] & 0xFFFF0000u),
+               __builtin_bit_cast(float, u[1] << 16), __builtin_bit_cast(float, u[1] & 0xFFFF0000u)};
+}
+__device__ inline void st4(u16* p, f32x4 v) {
+  *reinterpret_cast<u32x2*>(p) = u32x2{(unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16),
+                                        (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16)};
+}
+
+template <int NV>
+__device__ inline void row_layernorm(f32x4 (&v)[NV], int nvec, int lane, int C, const float* gamma,
+                                     const float* beta) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (lane + 64 * i < nvec) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  const float mean = wave_sum(s) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (lane + 64 * i < nvec) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { const float d = v[i][c] - mean; q += d * d; }
+    }
+  const float rstd = rsqrtf(wave_sum(q) / C + LN_EPS);
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (lane + 64 * i < nvec) {
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 4 * (lane + 64 * i));
+      const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + 4 * (lane + 64 * i));
+      v[i] = (v[i] - mean) * rstd * gm + bt;
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_residual_bf16_kernel(const u16* __restrict__ y, const u16* __restrict__ shortcut,
+                                                               int lds, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, u16* __restrict__ out,
+                                                               int ldo, int N, int C, float branch_scale) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nvec = C >> 2;
+  for (int row = blockIdx.x * ROWS_PER_BLOCK + wave; row < N; row += gridDim.x * ROWS_PER_BLOCK) {
+    f32x4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < nvec) v[i] = ld4(y + (size_t)row * C + 4 * (lane + 64 * i));
+    row_layernorm<NV>(v, nvec, lane, C, gamma, beta);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < nvec) {
+        const f32x4 sc = ld4(shortcut + (size_t)row * lds + 4 * (lane + 64 * i));
+        st4(out + (size_t)row * ldo + 4 * (lane + 64 * i), sc + branch_scale * v[i]);
+      }
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void downsample_ln_bf16_kernel(const u16* __restrict__ x, int ldx,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, u16* __restrict__ out,
+                                                                 int Z, int H, int W, int C) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int H2 = (H + 1) / 2, W2 = W / 2, C4 = 4 * C, nvec = C4 >> 2, cvec = C >> 2;
+  const int N2 = Z * H2 * W2;
+  for (int row = blockIdx.x * ROWS_PER_BLOCK + wave; row < N2; row += gridDim.x * ROWS_PER_BLOCK) {
+    const int w2 = row % W2, h2 = (row / W2) % H2, z = row / (W2 * H2);
+    f32x4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = lane + 64 * i;
+      if (f < nvec) {
+        const int quad = f / cvec, c4 = f - quad * cvec;
+        const int h = 2 * h2 + (quad >> 1), w = 2 * w2 + (quad & 1);
+        v[i] = h < H ? ld4(x + ((size_t)(z * H + h) * W + w) * ldx + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    row_layernorm<NV>(v, nvec, lane, C4, gamma, beta);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < nvec) st4(out + (size_t)row * C4 + 4 * (lane + 64 * i), v[i]);
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void upsample_ln_bf16_kernel(const u16* __restrict__ y, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, u16* __restrict__ out,
+                                                               int Z, int H2, int W2, int H, int Co) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Wf = 2 * W2, nvec = Co >> 2;
+  const int N = Z * H * Wf;
+  for (int row = blockIdx.x * ROWS_PER_BLOCK + wave; row < N; row += gridDim.x * ROWS_PER_BLOCK) {
+    const int w = row % Wf, h = (row / Wf) % H, z = row / (Wf * H);
+    const u16* src = y + ((size_t)(z * H2 + (h >> 1)) * W2 + (w >> 1)) * (4 * Co) + ((h & 1) * 2 + (w & 1)) * Co;
+    f32x4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < nvec) v[i] = ld4(src + 4 * (lane + 64 * i));
+    row_layernorm<NV>(v, nvec, lane, Co, gamma, beta);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < nvec) st4(out + (size_t)row * Co + 4 * (lane + 64 * i), v[i]);
+  }
+}
+
+// patch embed gather, bf16 out; the surface matrix is zero-padded from 112 to 128 columns (K multiple of 64 for the
+// bf16 GEMM; the weight shadow is padded the same way).
+constexpr int EMB_TOK = 64;
+
+__global__ __launch_bounds__(256) void patch_embed_gather_bf16_kernel(
+    const float* __restrict__ input, const float* __restrict__ input_surface, const float* __restrict__ s_mean,
+    const float* __restrict__ s_std, const float* __restrict__ u_mean, const float* __restrict__ u_std,
+    const float* __restrict__ maps, const float* __restrict__ const_h, u16* __restrict__ a_surface,
+    u16* __restrict__ a_upper, int LAT, int LON, int H4, int W4, int chunks) {
+  __shared__ u16 tile[EMB_TOK * 194];
+  const int chunk = blockIdx.x % chunks, h4 = (blockIdx.x / chunks) % H4, zp = blockIdx.x / (chunks * H4);
+  const int w0 = chunk * EMB_TOK;
+  const int ntok = min(EMB_TOK, W4 - w0);
+  const int tid = threadIdx.x;
+  const int ncol = zp == 0 ? 112 : 192;
+  const int nrun = ncol / 4;
+  const size_t plane = (size_t)LAT * LON;
+  for (int run = tid >> 6; run < nrun; run += 4) {
+    int c, pz, ph;
+    if (zp == 0) { c = run >> 2; pz = 0; ph = run & 3; } else { c = run >> 3; pz = (run >> 2) & 1; ph = run & 3; }
+    const int lat = 4 * h4 + ph;
+    const float* src = nullptr;
+    float mean = 0.f, sd = 1.f;
+    bool valid = lat < LAT;
+    if (zp == 0) {
+      if (c < 4) { src = input_surface + c * plane + (size_t)lat * LON; mean = s_mean[c]; sd = s_std[c]; }
+      else { src = maps + (size_t)(c - 4) * (4 * H4) * LON + (size_t)lat * LON; valid = true; }
+    } else {
+      const int lev = 2 * (zp - 1) + pz;
+      valid = valid && lev < 13;
+      if (valid) {
+        if (c < 5) {
+          src = input + ((size_t)c * 13 + lev) * plane + (size_t)lat * LON;
+          mean = u_mean[(12 - lev) * 5 + c]; sd = u_std[(12 - lev) * 5 + c];
+        } else {
+          src = const_h + (size_t)lev * plane + (size_t)lat * LON;
+        }
+      }
+    }
+    const bool norm = (zp == 0) ? (c < 4) : (c < 5);
+    for (int i = (tid & 63); i < 4 * ntok; i += 64) {
+      float v = 0.f;
+      if (valid) {
+        v = src[4 * w0 + i];
+        if (norm) v = (v - mean) / sd;
+      }
+      tile[(i >> 2) * 194 + run * 4 + (i & 3)] = f2bf(v);
+    }
+  }
+  __syncthreads();
+  const int ocol = zp == 0 ? 128 : 192;
+  u16* dst = zp == 0 ? a_surface + ((size_t)h4 * W4 + w0) * 128 : a_upper + (((size_t)(zp - 1) * H4 + h4) * W4 + w0) * 192;
+  for (int i = tid; i < ntok * ocol; i += 256) {
+    const int tk = i / ocol, col = i - tk * ocol;
+    dst[i] = col < ncol ? tile[tk * 194 + col] : (u16)0;
+  }
+}
+
+int row_grid(int rows) {
+  int blocks = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  return blocks < 8192 ? blocks : 8192;
+}
+
+}  // namespace
+
+#define PANGU_NVB(C_, KERNEL, ...)                                                   \
+  do {                                                                               \
+    if ((C_) <= 256) hipLaunchKernelGGL(KERNEL<1>, g, b, 0, s, __VA_ARGS__);         \
+    else if ((C_) <= 512) hipLaunchKernelGGL(KERNEL<2>, g, b, 0, s, __VA_ARGS__);    \
+    else hipLaunchKernelGGL(KERNEL<4>, g, b, 0, s, __VA_ARGS__);                     \
+  } while (0)
+
+extern "C" int pangu_ln_residual_fwd_bf16(pangu_stream_t stream, const void* y, const void* shortcut, int lds,
+                                          const float* gamma, const float* beta, void* out, int ldo, int N, int C,
+                                          float branch_scale) {
+  if (!y || !shortcut || !gamma || !beta || !out) return PANGU_E_NULL;
+  if (N <= 0 || C <= 0 || (C & 3) || C > 1024 || lds < C || ldo < C || (lds & 3) || (ldo & 3)) return PANGU_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g(row_grid(N)), b(256);
+  PANGU_NVB(C, ln_residual_bf16_kernel, (const u16*)y, (const u16*)shortcut, lds, gamma, beta, (u16*)out, ldo, N, C, branch_scale);
+  return pangu_launch_status();
+}
+
+extern "C" int pangu_downsample_ln_fwd_bf16(pangu_stream_t stream, const void* x, int ldx, const float* gamma,
+                                            const float* beta, void* out, int Z, int H, int W, int C) {
+  if (!x || !gamma || !beta || !out) return PANGU_E_NULL;
+  if (Z <= 0 || H <= 0 || W <= 0 || (W & 1) || (C & 3) || 4 * C > 1024 || ldx < C || (ldx & 3)) return PANGU_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g(row_grid(Z * ((H + 1) / 2) * (W / 2))), b(256);
+  PANGU_NVB(4 * C, downsample_ln_bf16_kernel, (const u16*)x, ldx, gamma, beta, (u16*)out, Z, H, W, C);
+  return pangu_launch_status();
+}
+
+extern "C" int pangu_upsample_ln_fwd_bf16(pangu_stream_t stream, const void* y, const float* gamma, const float* beta,
+                                          void* out, int Z, int H2, int W2, int H, int Co) {
+  if (!y || !gamma || !beta || !out) return PANGU_E_NULL;
+  if (Z <= 0 || H2 <= 0 || W2 <= 0 || H <= 0 || H > 2 * H2 || (Co & 3) || Co > 1024) return PANGU_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g(row_grid(Z * H * 2 * W2)), b(256);
+  PANGU_NVB(Co, upsample_ln_bf16_kernel, (const u16*)y, gamma, beta, (u16*)out, Z, H2, W2, H, Co);
+  return pangu_launch_status();
+}
+
+extern "C" int pangu_patch_embed_gather_bf16(pangu_stream_t stream, const float* input, const float* input_surface,
+                                             const float* surface_mean, const float* surface_std,
+                                             const float* upper_mean, const float* upper_std, const float* maps,
+                                             const float* const_h, void* a_surface, void* a_upper, int LAT, int LON) {
+  if (!input || !input_surface || !surface_mean || !surface_std || !upper_mean || !upper_std || !maps || !const_h ||
+      !a_surface || !a_upper)
+    return PANGU_E_NULL;
+  if (LAT <= 0 || LON <= 0 || (LON & 3)) return PANGU_E_SHAPE;
+  const int H4 = (LAT + 3) / 4, W4 = LON / 4, chunks = (W4 + EMB_TOK - 1) / EMB_TOK;
+  hipLaunchKernelGGL(patch_embed_gather_bf16_kernel, dim3(8 * H4 * chunks), dim3(256), 0, (hipStream_t)stream, input,
+                     input_surface, surface_mean, surface_std, upper_mean, upper_std, maps, const_h, (u16*)a_surface,
+                     (u16*)a_upper, LAT, LON, H4, W4, chunks);
+  return pangu_launch_status();
+}

@@ -1,0 +1,87 @@
+"""bf16 inference forward of the whole model (BASELINE configs[2]/[4]): bf16 activations + bf16 weight shadows,
+fp32 LayerNorm / softmax / accumulation, fp32 output fields.  Same launch sequence as the fp32 path."""
+import torch
+
+from . import ops, ops_bf16 as ob
+
+
+class WeightShadow:
+    """bf16 copies of the projection weights and bias tables, re-cast only when a parameter changed
+    (`Tensor._version` bumps on every in-place update).  Plain tensors in a dict: deepcopy / pickle safe."""
+
+    def __init__(self):
+        self.cache = {}
+
+    def get(self, p, pad_k=None):
+        key = id(p)
+        hit = self.cache.get(key)
+        if hit is not None and hit[0] == p._version and hit[1].device == p.device:
+            return hit[1]
+        w = p.detach().reshape(p.shape[0], -1) if p.dim() == 3 else p.detach()
+        if p.dim() == 5:
+            w = w[0]
+        if pad_k is not None and w.shape[1] < pad_k:
+            w = torch.nn.functional.pad(w, (0, pad_k - w.shape[1]))
+        w = w.to(torch.bfloat16).contiguous()
+        self.cache[key] = (p._version, w)
+        return w
+
+
+def _block(blk, sh, x, Z, H, W, roll, out=None):
+    """x (N,C) bf16 -> (N,C) bf16 (eval: DropPath is the identity)."""
+    att = blk.attention
+    qkv = ob.linear(x, sh.get(att.linear1.weight), att.linear1.bias)
+    o = ob.window_attention(qkv, sh.get(att.linear1.bias), sh.get(att.earth_specific_bias), Z, H, W, att.head_number, roll)
+    y = ob.linear(o, sh.get(att.linear2.weight), att.linear2.bias)
+    x1 = ob.ln_residual(y, x, blk.norm1.weight, blk.norm1.bias)
+    h = ob.linear(x1, sh.get(blk.linear.linear1.weight), blk.linear.linear1.bias, act=ob.ACT_GELU)
+    m = ob.linear(h, sh.get(blk.linear.linear2.weight), blk.linear.linear2.bias)
+    return ob.ln_residual(m, x1, blk.norm2.weight, blk.norm2.bias, out=out)
+
+
+def _layer(layer, sh, x, Z, H, W, out=None):
+    n = len(layer.blocks)
+    for i, blk in enumerate(layer.blocks):
+        x = _block(blk, sh, x, Z, H, W, i % 2 == 1, out=out if i == n - 1 else None)
+    return x
+
+
+def forward(model, inp, inp_surface, statistics, maps, const_h):
+    sh = model._shadow
+    s_mean, s_std, u_mean, u_std = statistics
+    B = inp.shape[0]
+    LAT, LON = inp.shape[-2], inp.shape[-1]
+    H4, W4 = (LAT + 3) // 4, LON // 4
+    dev = inp.device
+    f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
+    s_mean, s_std = f32(s_mean).reshape(-1), f32(s_std).reshape(-1)
+    u_mean, u_std = f32(u_mean).reshape(13, 5), f32(u_std).reshape(13, 5)
+    maps_c, const_c = f32(maps).reshape(3, 4 * H4, LON), f32(const_h).reshape(13, LAT, LON)
+    emb, rec = model._input_layer, model._output_layer
+    outs, outs_s = [], []
+    n_s = H4 * W4
+    N = 8 * n_s
+    C = emb.conv.weight.shape[0]
+    for b in range(B):
+        a_s, a_u = ob.patch_embed_gather(inp[b].contiguous(), inp_surface[b].contiguous(), s_mean, s_std, u_mean, u_std,
+                                         maps_c, const_c)
+        x = torch.empty((N, C), dtype=torch.bfloat16, device=dev)
+        ob.linear(a_s, sh.get(emb.conv_surface.weight, pad_k=128), emb.conv_surface.bias, out=x[:n_s])
+        ob.linear(a_u, sh.get(emb.conv.weight), emb.conv.bias, out=x[n_s:])
+        cat = torch.empty((N, 2 * C), dtype=torch.bfloat16, device=dev)
+        skip = _layer(model.layers[0], sh, x, 8, H4, W4, out=cat[:, :C])
+        g = ob.downsample_ln(skip, model.downsample.norm.weight, model.downsample.norm.bias, 8, H4, W4)
+        x = ob.linear(g, sh.get(model.downsample.linear.weight))
+        H2, W2 = (H4 + 1) // 2, W4 // 2
+        x = _layer(model.layers[1], sh, x, 8, H2, W2)
+        x = _layer(model.layers[2], sh, x, 8, H2, W2)
+        y = ob.linear(x, sh.get(model.upsample.linear1.weight))
+        g = ob.upsample_ln(y, model.upsample.norm.weight, model.upsample.norm.bias, 8, H2, W2, H4)
+        x = ob.linear(g, sh.get(model.upsample.linear2.weight))
+        _layer(model.layers[3], sh, x, 8, H4, W4, out=cat[:, C:])
+        y_s = ob.linear(cat[:n_s], sh.get(rec.conv_surface.weight), rec.conv_surface.bias, out_dtype=torch.float32)
+        y_u = ob.linear(cat[n_s:], sh.get(rec.conv.weight), rec.conv.bias, out_dtype=torch.float32)
+        o, os_ = ops.patch_recover_scatter(y_u, y_s, LAT, LON)
+        outs.append(o)
+        outs_s.append(os_)
+    return torch.stack(outs, 0), torch.stack(outs_s, 0)

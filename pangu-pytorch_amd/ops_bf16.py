@@ -1,0 +1,100 @@
+"""bf16 op wrappers (activations and weight shadows bf16; bias / LayerNorm parameters / softmax fp32)."""
+import torch
+
+from . import _lib
+from .ops import _stream, _timed
+
+ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
+BF16, F32 = 1, 0
+
+
+def _p(t, name, dtype=torch.bfloat16):
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous CUDA {dtype} tensor (got {t.dtype}, {t.device})")
+    return t.data_ptr()
+
+
+def _rows(t, name):
+    if not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
+        raise RuntimeError(f"{name}: expected a CUDA 2-D tensor with unit inner stride")
+    return t.data_ptr(), t.stride(0)
+
+
+def linear(a, weight, bias=None, act=ACT_NONE, out=None, aux=None, out_dtype=torch.bfloat16):
+    lib = _lib.load()
+    ap, lda = _rows(a, "linear.a")
+    M, K = a.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K or a.dtype != torch.bfloat16:
+        raise RuntimeError(f"linear_bf16: a {tuple(a.shape)} {a.dtype} vs weight {tuple(weight.shape)}")
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    op, ldc = _rows(out, "linear.out")
+    with _timed("linear_bf16", 2.0 * M * N * K):
+        _lib.check(lib.pangu_linear_fwd_bf16(_stream(), ap, lda, _p(weight, "weight"),
+                                             _p(bias, "bias", torch.float32) if bias is not None else None, op, ldc, M,
+                                             N, K, act, _p(aux, "aux") if aux is not None else None,
+                                             BF16 if out.dtype == torch.bfloat16 else F32), "linear_fwd_bf16")
+    return out
+
+
+def window_attention(qkv, qkv_bias, esb, Z, H, W, heads, shifted, want_lse=False):
+    lib = _lib.load()
+    N, C3 = qkv.shape
+    C = C3 // 3
+    out = torch.empty((N, C), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((N, heads), dtype=torch.float32, device=qkv.device) if want_lse else None
+    Np = (Z // 2) * ((H + 5) // 6) * (W // 12) * 144
+    with _timed("attn_bf16", 4.0 * Np * 144 * C):
+        _lib.check(lib.pangu_window_attn_fwd_bf16(_stream(), _p(qkv, "qkv"), _p(qkv_bias, "qkv_bias"), _p(esb, "esb"),
+                                                  out.data_ptr(), lse.data_ptr() if want_lse else None, Z, H, W, C, heads,
+                                                  int(shifted)), "window_attn_fwd_bf16")
+    return (out, lse) if want_lse else out
+
+
+def ln_residual(y, shortcut, gamma, beta, out=None, branch_scale=1.0):
+    lib = _lib.load()
+    N, C = y.shape
+    sp, lds = _rows(shortcut, "shortcut")
+    if out is None:
+        out = torch.empty((N, C), dtype=torch.bfloat16, device=y.device)
+    op, ldo = _rows(out, "out")
+    _lib.check(lib.pangu_ln_residual_fwd_bf16(_stream(), _p(y, "y"), sp, lds, _p(gamma, "gamma", torch.float32),
+                                              _p(beta, "beta", torch.float32), op, ldo, N, C, float(branch_scale)),
+               "ln_residual_fwd_bf16")
+    return out
+
+
+def downsample_ln(x, gamma, beta, Z, H, W):
+    lib = _lib.load()
+    xp, ldx = _rows(x, "x")
+    C = x.shape[1]
+    out = torch.empty((Z * ((H + 1) // 2) * (W // 2), 4 * C), dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.pangu_downsample_ln_fwd_bf16(_stream(), xp, ldx, _p(gamma, "gamma", torch.float32),
+                                                _p(beta, "beta", torch.float32), out.data_ptr(), Z, H, W, C),
+               "downsample_ln_fwd_bf16")
+    return out
+
+
+def upsample_ln(y, gamma, beta, Z, H2, W2, H):
+    lib = _lib.load()
+    Co = y.shape[1] // 4
+    out = torch.empty((Z * H * 2 * W2, Co), dtype=torch.bfloat16, device=y.device)
+    _lib.check(lib.pangu_upsample_ln_fwd_bf16(_stream(), _p(y, "y"), _p(gamma, "gamma", torch.float32),
+                                              _p(beta, "beta", torch.float32), out.data_ptr(), Z, H2, W2, H, Co),
+               "upsample_ln_fwd_bf16")
+    return out
+
+
+def patch_embed_gather(inp, inp_surface, s_mean, s_std, u_mean, u_std, maps, const_h):
+    lib = _lib.load()
+    LAT, LON = inp.shape[-2], inp.shape[-1]
+    H4, W4 = (LAT + 3) // 4, LON // 4
+    a_s = torch.empty((H4 * W4, 128), dtype=torch.bfloat16, device=inp.device)
+    a_u = torch.empty((7 * H4 * W4, 192), dtype=torch.bfloat16, device=inp.device)
+    f = torch.float32
+    _lib.check(lib.pangu_patch_embed_gather_bf16(_stream(), _p(inp, "input", f), _p(inp_surface, "input_surface", f),
+                                                 _p(s_mean, "s_mean", f), _p(s_std, "s_std", f), _p(u_mean, "u_mean", f),
+                                                 _p(u_std, "u_std", f), _p(maps, "maps", f), _p(const_h, "const_h", f),
+                                                 a_s.data_ptr(), a_u.data_ptr(), LAT, LON), "patch_embed_gather_bf16")
+    return a_s, a_u

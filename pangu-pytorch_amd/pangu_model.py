@@ -40,6 +40,18 @@ class PanguModel(nn.Module):
         self.register_buffer("_c_upper_std", None, persistent=False)
         self.register_buffer("_c_maps", None, persistent=False)
         self.register_buffer("_c_const_h", None, persistent=False)
+        self.compute_dtype = torch.float32
+        self._shadow = None
+
+    def set_compute_dtype(self, dtype):
+        """torch.float32 (default; parity <= 1e-3 with the reference) or torch.bfloat16 (inference: bf16 activations and
+        weight shadows, fp32 LayerNorm/softmax/accumulation).  bf16 is also selected by an enclosing
+        `torch.autocast("cuda", dtype=torch.bfloat16)` — the switch the reference leaves commented out at
+        models/pangu_sample.py:46-47."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+        self.compute_dtype = dtype
+        return self
 
     def _init_weights(self, m):                                                # reference pangu_model.py:41-48
         if isinstance(m, nn.Linear):
@@ -70,12 +82,20 @@ class PanguModel(nn.Module):
         if not (input.is_cuda and input_surface.is_cuda):
             raise RuntimeError("PanguModel (MI355X build) needs its inputs on a HIP device; there is no CPU fallback "
                                f"(got {input.device})")
+        grad_path = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        want_bf16 = self.compute_dtype == torch.bfloat16 or (
+            torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+        if want_bf16 and not grad_path:
+            from . import fused_bf16
+            if self._shadow is None:
+                self._shadow = fused_bf16.WeightShadow()
+            return fused_bf16.forward(self, input, input_surface, statistics, maps, const_h)
         B = input.shape[0]
         x = self._input_layer(input, input_surface, statistics, maps, const_h)             # (B,521280,192)
         N, C = x.shape[1], x.shape[2]
         # skip connection: layer 0 writes its result into the left half, layer 3 into the right half of one
         # (B,N,2C) buffer, so the channel concat of reference pangu_model.py:81 costs no copy
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if grad_path:
             skip = self.layers[0](x, 8, 181, 360)                 # autograd path: plain concat
             x = self.downsample(skip, 8, 181, 360)
             x = self.layers[1](x, 8, 91, 180)

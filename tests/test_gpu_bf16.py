@@ -1,0 +1,144 @@
+"""bf16 path (BASELINE configs[2]/[4]): kernels vs fp32 references computed from the SAME bf16-rounded operands
+(tolerance = bf16 output rounding, 2^-8), and whole-model drift vs the fp32 reference goldens (reported, bounded)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import pangu_oracle as O
+import synth
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+ROUND = 1.0 / 128        # bf16 has 8 significant bits: one output rounding <= 2^-8 relative, x2 margin
+
+
+@pytest.fixture(scope="module")
+def P():
+    import pangu_pytorch_amd as P
+    assert torch.cuda.is_available()
+    P._lib.load()
+    return P
+
+
+def rel_err(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("M,N,K,act,bias", [
+    (1000, 192, 192, 0, True), (4099, 576, 192, 0, True), (2048, 768, 192, 1, True), (777, 192, 768, 0, True),
+    (1531, 1152, 384, 0, True), (513, 1536, 384, 1, True), (300, 384, 1536, 0, True), (999, 384, 768, 0, False),
+    (1234, 160, 384, 0, True), (321, 64, 384, 0, True), (650, 192, 128, 0, True), (128, 128, 64, 0, False),
+    (700, 384, 160, 0, False), (500, 192, 576, 0, False),
+])
+@pytest.mark.parametrize("out_f32", [False, True])
+def test_linear_bf16(P, M, N, K, act, bias, out_f32):
+    from pangu_pytorch_amd import ops_bf16 as ob
+    a = synth.uniform((M, K), 11).to(BF)
+    w = synth.uniform((N, K), 12, 1.0 / K ** 0.5).to(BF)
+    b = synth.uniform((N,), 13, 0.5) if bias else None
+    ref = a.float() @ w.float().t()
+    if bias:
+        ref = ref + b
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    got = ob.linear(a.cuda(), w.cuda(), b.cuda() if bias else None, act=act,
+                    out_dtype=torch.float32 if out_f32 else BF)
+    assert got.dtype == (torch.float32 if out_f32 else BF)
+    assert rel_err(got, ref) < (2e-4 if out_f32 else ROUND)
+
+
+def test_linear_bf16_gelu_aux_and_bwd(P):
+    from pangu_pytorch_amd import ops_bf16 as ob
+    M, N, K = 1500, 768, 192
+    a, w, b = synth.uniform((M, K), 65).to(BF), synth.uniform((N, K), 66, 0.1).to(BF), synth.uniform((N,), 67, 0.3)
+    pre = torch.empty((M, N), device="cuda", dtype=BF)
+    h = ob.linear(a.cuda(), w.cuda(), b.cuda(), act=ob.ACT_GELU, aux=pre)
+    ref_pre = a.float() @ w.float().t() + b
+    assert rel_err(pre, ref_pre) < ROUND and rel_err(h, torch.nn.functional.gelu(ref_pre)) < ROUND
+    dm, w2t = synth.uniform((M, 192), 68).to(BF), synth.uniform((N, 192), 69, 0.05).to(BF)
+    got = ob.linear(dm.cuda(), w2t.cuda(), None, act=ob.ACT_GELU_BWD, aux=pre)
+    x = pre.float().cpu().requires_grad_(True)
+    (torch.nn.functional.gelu(x) * (dm.float() @ w2t.float().t())).sum().backward()
+    assert rel_err(got, x.grad) < ROUND
+
+
+@pytest.mark.parametrize("C", [192, 384])
+@pytest.mark.parametrize("shifted", [False, True])
+def test_window_attention_bf16(P, C, shifted):
+    from pangu_pytorch_amd import ops_bf16 as ob
+    st = cases.STAGES[C]
+    Z, H, W, heads = st["Z"], st["H"], 24, st["heads"]
+    N = Z * H * W
+    qkv = synth.uniform((1, N, 3 * C), 31, 1.5).to(BF)
+    b1 = synth.uniform((3 * C,), 32, 0.5).to(BF)
+    esb = synth.uniform((1, st["types"], heads, 144, 144), 33, 0.5).to(BF)
+    ref, ref_lse = O.window_attention_core(qkv.float(), b1.float(), esb.float(), Z, H, W, heads, shifted)
+    got, lse = ob.window_attention(qkv[0].cuda(), b1.cuda(), esb[0].cuda(), Z, H, W, heads, shifted, want_lse=True)
+    # P is rounded to bf16 before P.V (as every bf16 flash kernel does): 2^-9 per term, averaged by the sum
+    assert rel_err(got, ref[0]) < ROUND
+    assert rel_err(lse, ref_lse[0]) < 1e-4
+
+
+@pytest.mark.parametrize("C", [192, 384])
+def test_ln_residual_bf16(P, C):
+    from pangu_pytorch_amd import ops_bf16 as ob
+    N = 1003
+    y, sc = synth.uniform((N, C), 41, 2.0, 0.3).to(BF), synth.uniform((N, C), 42).to(BF)
+    g, b = synth.uniform((C,), 43, 0.1, 1.0), synth.uniform((C,), 44, 0.1)
+    ref = sc.float() + torch.nn.functional.layer_norm(y.float(), (C,), g, b)
+    got = ob.ln_residual(y.cuda(), sc.cuda(), g.cuda(), b.cuda())
+    assert rel_err(got, ref) < ROUND
+
+
+def test_downsample_upsample_embed_bf16(P):
+    from pangu_pytorch_amd import ops_bf16 as ob
+    Z, H, W, C = 8, 181, 24, 192
+    x = synth.uniform((Z * H * W, C), 51).to(BF)
+    g, b = synth.uniform((4 * C,), 52, 0.1, 1.0), synth.uniform((4 * C,), 53, 0.1)
+    xr = torch.nn.functional.pad(x.float().view(Z, H, W, C), (0, 0, 0, 0, 0, 1)).view(Z, 91, 2, 12, 2, C)
+    ref = torch.nn.functional.layer_norm(xr.permute(0, 1, 3, 2, 4, 5).reshape(-1, 4 * C), (4 * C,), g, b)
+    assert rel_err(ob.downsample_ln(x.cuda(), g.cuda(), b.cuda(), Z, H, W), ref) < ROUND
+    H2, W2, Co = 91, 12, 192
+    y = synth.uniform((Z * H2 * W2, 4 * Co), 54).to(BF)
+    g, b = synth.uniform((Co,), 55, 0.1, 1.0), synth.uniform((Co,), 56, 0.1)
+    yr = y.float().view(Z, H2, W2, 2, 2, Co).permute(0, 1, 3, 2, 4, 5).reshape(Z, 2 * H2, 2 * W2, Co)[:, :H]
+    ref = torch.nn.functional.layer_norm(yr.reshape(-1, Co), (Co,), g, b)
+    assert rel_err(ob.upsample_ln(y.cuda(), g.cuda(), b.cuda(), Z, H2, W2, H), ref) < ROUND
+    LAT, LON, H4, W4 = 41, 280, 11, 70
+    gg = lambda n, s, sc=1.0, sh=0.0: synth.uniform(s, synth.name_seed(n), sc, sh)
+    inp, inp_s = gg("i", (1, 5, 13, LAT, LON)), gg("is", (1, 4, LAT, LON))
+    stats = (gg("sm", (4,), 0.3), gg("ss", (4,), 0.2, 1.2), gg("um", (13, 1, 1, 5), 0.3), gg("us", (13, 1, 1, 5), 0.2, 1.2))
+    maps, const_h = gg("m", (1, 3, 4 * H4, LON)), gg("c", (1, 1, 1, 13, LAT, LON))
+    ra_s, ra_u = O.patch_embed_matrices(inp, inp_s, stats, maps, const_h)
+    a_s, a_u = ob.patch_embed_gather(inp[0].cuda(), inp_s[0].cuda(), stats[0].cuda(), stats[1].cuda(),
+                                     stats[2].reshape(13, 5).cuda(), stats[3].reshape(13, 5).cuda(), maps[0].cuda(),
+                                     const_h.reshape(13, LAT, LON).cuda())
+    assert a_s.shape == (H4 * W4, 128) and float(a_s[:, 112:].float().abs().max()) == 0.0
+    assert torch.equal(a_s[:, :112].cpu(), ra_s[0].to(BF)) and torch.equal(a_u.cpu(), ra_u[0].to(BF))
+
+
+def test_full_model_bf16_drift(P, golden_dir):
+    """bf16 forward vs the fp32 reference golden: drift is reported and bounded (the reference's own bf16 autocast
+    drifts 3.8e-3 rel-L2 PER BLOCK; 16 blocks)."""
+    g = np.load(os.path.join(golden_dir, "model_fwd.npz"))
+    m = P.PanguModel(device="cuda").cuda().eval()
+    m.load_state_dict(synth.fill_state_dict(cases.model_param_shapes(), "cuda"))
+    inp, inp_s, stats, maps, const_h = cases.model_inputs("cuda")
+    with torch.no_grad():
+        ref, ref_s = m(inp, inp_s, stats, maps, const_h)                       # fp32 HIP path (parity-tested)
+        m.set_compute_dtype(BF)
+        out, out_s = m(inp, inp_s, stats, maps, const_h)
+        m.set_compute_dtype(torch.float32)
+        with torch.autocast("cuda", dtype=BF):
+            out2, _ = m(inp, inp_s, stats, maps, const_h)
+    assert out.dtype == torch.float32 and torch.isfinite(out).all()
+    assert torch.equal(out, out2)                                             # autocast selects the same path
+    l2 = ((out - ref).double().norm() / ref.double().norm()).item()
+    l2s = ((out_s - ref_s).double().norm() / ref_s.double().norm()).item()
+    print(f"bf16 vs fp32 rel-L2 drift: upper {l2:.3e} surface {l2s:.3e}")
+    assert l2 < 5e-2 and l2s < 5e-2
+    assert cases.compare_summary(out, g, "model.out", 1.0) < 0.2

@@ -51,6 +51,41 @@ def gemm(lib_compare):
         print(line)
 
 
+def gemm_bf16(lib_compare):
+    from pangu_pytorch_amd import ops_bf16 as ob
+    bf = torch.bfloat16
+    for M, N, K, act, name in GEMM_SHAPES:
+        a = torch.randn(M, K, device="cuda").to(bf)
+        w = (torch.randn(N, K, device="cuda") / K ** 0.5).to(bf)
+        b = torch.randn(N, device="cuda")
+        out = torch.empty(M, N, device="cuda", dtype=bf)
+        ms = timeit(lambda: ob.linear(a, w, b, act=act, out=out))
+        by = (M * K + M * N + N * K) * 2.0
+        line = f"{name:14s} M={M:6d} N={N:4d} K={K:4d}  {ms:7.3f} ms  {2.0 * M * N * K / ms / 1e9:6.1f} TF/s {by / ms / 1e6:7.1f} GB/s"
+        if lib_compare:
+            bb = b.to(bf)
+            f = (lambda: torch.nn.functional.gelu(torch.addmm(bb, a, w.t()))) if act else (lambda: torch.addmm(bb, a, w.t()))
+            ms2 = timeit(f)
+            line += f"   | torch {ms2:7.3f} ms {2.0 * M * N * K / ms2 / 1e9:6.1f} TF/s"
+        print(line)
+
+
+def attn_bf16():
+    from pangu_pytorch_amd import ops_bf16 as ob
+    bf = torch.bfloat16
+    for C, Z, H, W, heads, types in ((192, 8, 181, 360, 6, 124), (384, 8, 91, 180, 12, 64)):
+        N = Z * H * W
+        qkv = torch.randn(N, 3 * C, device="cuda").to(bf)
+        b1 = torch.randn(3 * C, device="cuda").to(bf)
+        esb = (torch.randn(types, heads, 144, 144, device="cuda") * 0.1).to(bf)
+        for sh in (False, True):
+            ms = timeit(lambda: ob.window_attention(qkv, b1, esb, Z, H, W, heads, sh))
+            Np = (Z // 2) * ((H + 5) // 6) * (W // 12) * 144
+            fl = 4.0 * Np * 144 * C
+            by = (N * 4 * C + esb.numel()) * 2.0
+            print(f"attn_bf16 C={C} shifted={int(sh)}: {ms:7.3f} ms  {fl / ms / 1e9:6.1f} TF/s  {by / ms / 1e6:7.1f} GB/s (algorithmic)")
+
+
 def attn():
     for C, Z, H, W, heads, types in ((192, 8, 181, 360, 6, 124), (384, 8, 91, 180, 12, 64)):
         N = Z * H * W
@@ -76,4 +111,5 @@ def rows():
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
-    {"gemm": lambda: gemm("--lib-compare" in sys.argv), "attn": attn, "rows": rows}[what]()
+    {"gemm": lambda: gemm("--lib-compare" in sys.argv), "attn": attn, "rows": rows,
+     "gemm_bf16": lambda: gemm_bf16("--lib-compare" in sys.argv), "attn_bf16": attn_bf16}[what]()
