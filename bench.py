@@ -149,11 +149,33 @@ def main():
         tb = time.perf_counter() - tb
         ref = out[0].double()
         drift = ((out_b[0].double() - ref).norm() / ref.norm()).item()
-        bf16_res = {"metric": "bf16 forward steps/s (bf16 activations+weights, fp32 LN/softmax/accumulate)",
-                    "value": world * args.steps / tb, "ms_per_step": tb / args.steps * 1e3,
-                    "rel_l2_drift_vs_f32": drift, "model_tflops": FWD_GFLOP / (tb / args.steps * 1e3)}
+        # the same step captured in a hipGraph (one launch per step), and the 7 x 24 h rollout of configs[4]
+        from pangu_pytorch_amd import rollout as R
+        gs = R.GraphedStep(model, inp, inp_s, stats, maps, const_h)
+        gs.step()
+        barrier()
+        tg = time.perf_counter()
+        for _ in range(args.steps):
+            gs.step()
+        barrier()
+        tg = time.perf_counter() - tg
+        sl = (stats[0].view(1, 4, 1, 1), stats[1].view(1, 4, 1, 1),
+              stats[2].reshape(13, 5).flip(0).t().reshape(1, 5, 13, 1, 1).contiguous(),
+              stats[3].reshape(13, 5).flip(0).t().reshape(1, 5, 13, 1, 1).contiguous())
+        gr = R.GraphedStep(model, inp, inp_s, stats, maps, const_h, stats_last=sl, feed_back=True)
+        barrier()
+        tr = time.perf_counter()
+        for _ in range(7):
+            gr.step()
+        barrier()
+        tr = time.perf_counter() - tr
+        bf16_res = {"metric": "bf16 forward steps/s (bf16 activations+weights, fp32 LN/softmax/accumulate), hipGraph replay",
+                    "value": world * args.steps / tg, "ms_per_step": tg / args.steps * 1e3,
+                    "eager_ms_per_step": tb / args.steps * 1e3, "rel_l2_drift_vs_f32": drift,
+                    "model_tflops": FWD_GFLOP / (tg / args.steps * 1e3),
+                    "rollout_7x24h_ms": tr * 1e3}
         model.set_compute_dtype(torch.float32)
-        del out_b
+        del out_b, gs, gr
 
     # ---- secondary metric: DDP finetune step (BASELINE configs[3] shape: 1 sample/GPU, fwd + bwd + bucketed RCCL
     # gradient all-reduce overlapped with backward + Adam), reported beside the headline number

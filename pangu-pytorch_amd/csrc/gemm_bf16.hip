@@ -220,7 +220,11 @@ int launch_bf16(hipStream_t s, const u16* A, int lda, const u16* W, const float*
 #define PANGU_BGEMM(ACT, HB)                                                                                          \
   do {                                                                                                                \
     auto kern = gemm_tn_bf16_kernel<TN, ACT, HB, OUT_F32>;                                                            \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);    \
+    static bool attr_set = false; /* once per instantiation, outside any later graph capture */                       \
+    if (!attr_set) {                                                                                                  \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+      attr_set = true;                                                                                                \
+    }                                                                                                                 \
     hipLaunchKernelGGL(kern, g, blk, shm, s, A, lda, W, bias, C, ldc, M, N, K, m_tiles, n_tiles, aux);                \
   } while (0)
   if (act == PANGU_ACT_GELU) {
