@@ -101,7 +101,10 @@ class FlatGradSync:
     # -- per-parameter hook: move the fresh gradient into its flat slot; launch every bucket that became complete
     def _on_grad(self, p):
         bi, view = self._slot[p]
-        if p.grad.data_ptr() != view.data_ptr():
+        if p.grad is None:              # a custom Function returned None (DropPath-dropped branch): contributes zeros
+            view.zero_()
+            p.grad = view
+        elif p.grad.data_ptr() != view.data_ptr():
             view.copy_(p.grad)
             p.grad = view
         self._fired.add(p)

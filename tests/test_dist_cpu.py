@@ -20,6 +20,18 @@ def _free_port():
     return port
 
 
+class _NoneGrad(torch.autograd.Function):
+    """Like the HIP block function with a DropPath-dropped branch: the weight takes part in the graph but gets None."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        return x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
 class _Tiny(torch.nn.Module):
     """Same naming structure as PanguModel (so default_buckets groups per block), tiny sizes."""
 
@@ -40,6 +52,8 @@ class _Tiny(torch.nn.Module):
             for bi, blk in layer["blocks"].items():
                 if drop != (li, bi):
                     x = x + blk(x)
+                else:
+                    x = _NoneGrad.apply(x, blk[0].weight)
         return self._output_layer(x)
 
 
@@ -74,7 +88,7 @@ def _worker(rank, world, port, drop_on_rank1, q):
     for (k, p) in m2.named_parameters():
         assert torch.allclose(grads[k], p.grad, rtol=1e-6, atol=1e-7), k
     if rank == 0:
-        q.put({k: v for k, v in grads.items()})
+        q.put({k: v.numpy() for k, v in grads.items()})      # plain bytes: no fd hand-off racing with process exit
     torch.distributed.destroy_process_group()
 
 
@@ -86,7 +100,7 @@ def test_flat_grad_sync_matches_single_process_mean(drop):
     procs = [ctx.Process(target=_worker, args=(r, world, port, drop, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=120)
+    got = {k: torch.from_numpy(v) for k, v in q.get(timeout=120).items()}
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
