@@ -185,7 +185,7 @@ def main():
 
     # ---- secondary metric: DDP finetune step (BASELINE configs[3] shape: 1 sample/GPU, fwd + bwd + bucketed RCCL
     # gradient all-reduce overlapped with backward + Adam), reported beside the headline number
-    train_res = None
+    train_res = {}
     if not args.no_train:
         from pangu_pytorch_amd import train
         from pangu_pytorch_amd.dist import FlatGradSync
@@ -195,22 +195,28 @@ def main():
         opt = torch.optim.Adam(model.parameters(), lr=5e-6, weight_decay=3e-6)      # reference finetune_fully.py:121
         sync = FlatGradSync(model) if world > 1 else None
         batch = (inp, inp_s, tgt, tgt_s)
-        torch.manual_seed(1234 + rank)            # DropPath draws (host RNG)
-        for _ in range(1):
+        for tag, dt in (("ddp_train", torch.float32), ("ddp_train_bf16", torch.bfloat16)):
+            model.set_compute_dtype(dt)
+            torch.manual_seed(1234 + rank)            # DropPath draws (host RNG)
+            torch.cuda.reset_peak_memory_stats()
             train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=sync.finish if sync else None)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.train_steps):
-            loss = train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=sync.finish if sync else None)
-        barrier()
-        t_train = time.perf_counter() - t1
-        if dist is not None:
-            t = torch.tensor([t_train], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            t_train = t.item()
-        train_res = {"metric": "DDP finetune samples/s (fwd+bwd+grad all-reduce+Adam, fp32, 1 sample/GPU, DropPath on)",
-                     "value": world * args.train_steps / t_train, "ms_per_step": t_train / args.train_steps * 1e3,
-                     "steps": args.train_steps, "loss": float(loss), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2**30}
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.train_steps):
+                loss = train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=sync.finish if sync else None)
+            barrier()
+            t_train = time.perf_counter() - t1
+            if dist is not None:
+                t = torch.tensor([t_train], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                t_train = t.item()
+            train_res[tag] = {
+                "metric": "DDP finetune samples/s (fwd+bwd+bucketed grad all-reduce+Adam, 1 sample/GPU, DropPath on), "
+                          + ("fp32" if dt == torch.float32 else "bf16 compute / fp32 master weights+grads"),
+                "value": world * args.train_steps / t_train, "ms_per_step": t_train / args.train_steps * 1e3,
+                "steps": args.train_steps, "loss": float(loss), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2**30,
+                "model_tflops": 3 * FWD_GFLOP / (t_train / args.train_steps * 1e3)}
+        model.set_compute_dtype(torch.float32)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -240,8 +246,7 @@ def main():
         }
         if bf16_res is not None:
             res["bf16_forward"] = bf16_res
-        if train_res is not None:
-            res["ddp_train"] = train_res
+        res.update(train_res)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))

@@ -178,6 +178,22 @@ int pangu_patch_embed_gather_bf16(pangu_stream_t stream, const float* input, con
                                   const float* upper_std, const float* maps, const float* const_h, void* a_surface,
                                   void* a_upper, int LAT, int LON);
 
+/* bf16 backward (configs[2]): operands / saved activations / activation gradients bf16; parameter gradients,
+ * statistics and all accumulation fp32 (they feed the fp32 master weights).  Semantics as the fp32 entry points. */
+int pangu_linear_wgrad_bf16(pangu_stream_t stream, const void* dC, int lddc, const void* A, int lda, float* dW,
+                            float* db, int M, int N, int K);
+int pangu_window_attn_bwd_bf16(pangu_stream_t stream, const void* qkv, const void* qkv_bias, const void* esb,
+                               const void* out, const float* lse, const void* dout, void* dqkv, float* dqkv_bias,
+                               float* d_esb, int Z, int H, int W, int C, int heads, int shifted);
+int pangu_ln_residual_bwd_bf16(pangu_stream_t stream, const void* dout, int lddo, const void* y, const float* gamma,
+                               void* dy, float* dgamma, float* dbeta, int N, int C, float branch_scale);
+int pangu_downsample_ln_bwd_bf16(pangu_stream_t stream, const void* dout, const void* x, int ldx, const float* gamma,
+                                 void* dx, float* dgamma, float* dbeta, int Z, int H, int W, int C);
+int pangu_upsample_ln_bwd_bf16(pangu_stream_t stream, const void* dout, const void* y, const float* gamma, void* dy,
+                               float* dgamma, float* dbeta, int Z, int H2, int W2, int H, int Co);
+int pangu_patch_recover_gather_bwd_bf16(pangu_stream_t stream, const float* d_output, const float* d_output_surface,
+                                        void* dy_upper, void* dy_surface, int LAT, int LON);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,210 @@
+"""bf16 mixed-precision training path (BASELINE configs[2]): fp32 master parameters and fp32 parameter gradients,
+bf16 weight shadows / activations / activation gradients, fp32 LayerNorm + softmax + accumulation.
+
+Same kernel sequence as autograd.py on the bf16 entry points; saved activations are bf16 (32 GB instead of 64 GB)."""
+import torch
+
+from . import ops
+from . import ops_bf16 as ob
+
+
+class EarthBlockFnBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, n2w, n2b, m1w, m1b, m2w, m2b, esb, a1w, a1b, a2w, a2b, geom, s1, s2, sh):
+        Z, H, W, heads, shifted = geom
+        ctx.geom, ctx.s1, ctx.s2, ctx.sh = geom, s1, s2, sh
+        ctx.params = (n1w, n2w, m1w, m2w, esb, a1w, a1b, a2w)
+        saved = [x]
+        x1 = x
+        if s1 != 0.0:
+            qkv = ob.linear(x, sh.get(a1w), a1b)
+            o, lse = ob.window_attention(qkv, sh.get(a1b), sh.get(esb), Z, H, W, heads, shifted, want_lse=True)
+            y = ob.linear(o, sh.get(a2w), a2b)
+            x1 = ob.ln_residual(y, x, n1w, n1b, branch_scale=s1)
+            saved += [qkv, o, lse, y]
+        if s2 != 0.0:
+            pre = torch.empty((x.shape[0], m1w.shape[0]), dtype=torch.bfloat16, device=x.device)
+            h = ob.linear(x1, sh.get(m1w), m1b, act=ob.ACT_GELU, aux=pre)
+            m = ob.linear(h, sh.get(m2w), m2b)
+            x2 = ob.ln_residual(m, x1, n2w, n2b, branch_scale=s2)
+            saved += [x1, pre, h, m]
+        else:
+            x2 = x1
+        ctx.save_for_backward(*saved)
+        return x2
+
+    @staticmethod
+    def backward(ctx, dout):
+        Z, H, W, heads, shifted = ctx.geom
+        s1, s2, sh = ctx.s1, ctx.s2, ctx.sh
+        n1w, n2w, m1w, m2w, esb, a1w, a1b, a2w = ctx.params
+        sv = list(ctx.saved_tensors)
+        x, rest = sv[0], sv[1:]
+        if s1 != 0.0:
+            qkv, o, lse, y = rest[:4]
+            rest = rest[4:]
+        g = {k: None for k in ("n1w", "n1b", "n2w", "n2b", "m1w", "m1b", "m2w", "m2b", "esb", "a1w", "a1b", "a2w", "a2b")}
+        dx1 = dout
+        if s2 != 0.0:
+            x1, pre, h, m = rest
+            dm, g["n2w"], g["n2b"] = ob.ln_residual_bwd(dout, m, n2w, s2)
+            g["m2w"], g["m2b"] = ob.linear_wgrad(dm, h)
+            dpre = ob.linear(dm, sh.get_t(m2w), None, act=ob.ACT_GELU_BWD, aux=pre)
+            del dm
+            g["m1w"], g["m1b"] = ob.linear_wgrad(dpre, x1)
+            dx1 = ob.linear(dpre, sh.get_t(m1w))
+            del dpre
+            dx1 += dout
+        dx = dx1
+        if s1 != 0.0:
+            dy, g["n1w"], g["n1b"] = ob.ln_residual_bwd(dx1, y, n1w, s1)
+            g["a2w"], g["a2b"] = ob.linear_wgrad(dy, o)
+            do = ob.linear(dy, sh.get_t(a2w))
+            del dy
+            dqkv, dqb_pad, desb = ob.window_attention_bwd(qkv, sh.get(a1b), sh.get(esb), o, lse, do, Z, H, W, heads, shifted)
+            del do
+            g["esb"] = desb.unsqueeze(0)
+            g["a1w"], g["a1b"] = ob.linear_wgrad(dqkv, x)
+            g["a1b"] += dqb_pad
+            dx = ob.linear(dqkv, sh.get_t(a1w))
+            dx += dx1
+        elif not dx.is_contiguous():
+            dx = dx.contiguous()
+        return (dx, g["n1w"], g["n1b"], g["n2w"], g["n2b"], g["m1w"], g["m1b"], g["m2w"], g["m2b"], g["esb"],
+                g["a1w"], g["a1b"], g["a2w"], g["a2b"], None, None, None, None)
+
+
+class PatchEmbedFnBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cw, cb, sw, sb, inp, inp_s, s_mean, s_std, u_mean, u_std, maps, const_h, sh):
+        a_s, a_u = ob.patch_embed_gather(inp, inp_s, s_mean, s_std, u_mean, u_std, maps, const_h)
+        n_s = a_s.shape[0]
+        x = torch.empty((n_s + a_u.shape[0], cw.shape[0]), dtype=torch.bfloat16, device=inp.device)
+        ob.linear(a_s, sh.get(sw, pad_k=128), sb, out=x[:n_s])
+        ob.linear(a_u, sh.get(cw), cb, out=x[n_s:])
+        ctx.save_for_backward(a_s, a_u)
+        ctx.shapes = (cw.shape, sw.shape)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        a_s, a_u = ctx.saved_tensors
+        n_s = a_s.shape[0]
+        dsw, dsb = ob.linear_wgrad(dx[:n_s], a_s)                 # (192, 128): columns 112.. are padding
+        dcw, dcb = ob.linear_wgrad(dx[n_s:], a_u)
+        k_s = ctx.shapes[1][1]
+        return (dcw.reshape(ctx.shapes[0]), dcb, dsw[:, :k_s].reshape(ctx.shapes[1]), dsb) + (None,) * 9
+
+
+class DownSampleFnBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, lw, nw, nb, geom, sh):
+        Z, H, W = geom
+        g = ob.downsample_ln(x, nw, nb, Z, H, W)
+        ctx.save_for_backward(x, g)
+        ctx.geom, ctx.sh, ctx.params = geom, sh, (lw, nw)
+        return ob.linear(g, sh.get(lw))
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, g = ctx.saved_tensors
+        lw, nw = ctx.params
+        Z, H, W = ctx.geom
+        dout = dout.contiguous()
+        dlw, _ = ob.linear_wgrad(dout, g, want_bias=False)
+        dg = ob.linear(dout, ctx.sh.get_t(lw))
+        dx, dnw, dnb = ob.downsample_ln_bwd(dg, x, nw, Z, H, W)
+        return dx, dlw, dnw, dnb, None, None
+
+
+class UpSampleFnBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, l1w, l2w, nw, nb, geom, sh):
+        Z, H2, W2, H = geom
+        y = ob.linear(x, sh.get(l1w))
+        g = ob.upsample_ln(y, nw, nb, Z, H2, W2, H)
+        ctx.save_for_backward(x, y, g)
+        ctx.geom, ctx.sh, ctx.params = geom, sh, (l1w, l2w, nw)
+        return ob.linear(g, sh.get(l2w))
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y, g = ctx.saved_tensors
+        l1w, l2w, nw = ctx.params
+        Z, H2, W2, H = ctx.geom
+        dout = dout.contiguous()
+        dl2w, _ = ob.linear_wgrad(dout, g, want_bias=False)
+        dg = ob.linear(dout, ctx.sh.get_t(l2w))
+        dy, dnw, dnb = ob.upsample_ln_bwd(dg, y, nw, Z, H2, W2, H)
+        dl1w, _ = ob.linear_wgrad(dy, x, want_bias=False)
+        dx = ob.linear(dy, ctx.sh.get_t(l1w))
+        return dx, dl1w, dl2w, dnw, dnb, None, None
+
+
+class PatchRecoverFnBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cw, cb, sw, sb, geom, sh):
+        n_s, LAT, LON = geom
+        y_s = ob.linear(x[:n_s], sh.get(sw), sb, out_dtype=torch.float32)
+        y_u = ob.linear(x[n_s:], sh.get(cw), cb, out_dtype=torch.float32)
+        ctx.save_for_backward(x)
+        ctx.geom, ctx.sh, ctx.params = geom, sh, (cw, sw)
+        return ops.patch_recover_scatter(y_u, y_s, LAT, LON)
+
+    @staticmethod
+    def backward(ctx, d_out, d_out_s):
+        (x,) = ctx.saved_tensors
+        cw, sw = ctx.params
+        n_s, LAT, LON = ctx.geom
+        dy_u, dy_s = ob.patch_recover_gather_bwd(d_out.contiguous(), d_out_s.contiguous())
+        dcw, dcb = ob.linear_wgrad(dy_u, x[n_s:])
+        dsw, dsb = ob.linear_wgrad(dy_s, x[:n_s])
+        dx = torch.empty_like(x)
+        ob.linear(dy_s, ctx.sh.get_t(sw), out=dx[:n_s])
+        ob.linear(dy_u, ctx.sh.get_t(cw), out=dx[n_s:])
+        return dx, dcw.reshape(cw.shape), dcb, dsw.reshape(sw.shape), dsb, None, None
+
+
+def forward_train(model, inp, inp_surface, statistics, maps, const_h):
+    """Autograd-enabled bf16 forward of the whole model (B looped; the reference is B = 1 per rank)."""
+    sh = model._shadow
+    s_mean, s_std, u_mean, u_std = statistics
+    B = inp.shape[0]
+    LAT, LON = inp.shape[-2], inp.shape[-1]
+    H4, W4 = (LAT + 3) // 4, LON // 4
+    dev = inp.device
+    f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
+    s_mean, s_std = f32(s_mean).reshape(-1), f32(s_std).reshape(-1)
+    u_mean, u_std = f32(u_mean).reshape(13, 5), f32(u_std).reshape(13, 5)
+    maps_c, const_c = f32(maps).reshape(3, 4 * H4, LON), f32(const_h).reshape(13, LAT, LON)
+    emb, rec, dn, up = model._input_layer, model._output_layer, model.downsample, model.upsample
+    H2, W2 = (H4 + 1) // 2, W4 // 2
+
+    def run_layer(layer, x, Z, H, W):
+        for i, blk in enumerate(layer.blocks):
+            att, dp = blk.attention, blk.drop_path
+            s1 = dp.sample_scale(blk.training) if hasattr(dp, "sample_scale") else 1.0
+            s2 = dp.sample_scale(blk.training) if hasattr(dp, "sample_scale") else 1.0
+            x = EarthBlockFnBF16.apply(
+                x, blk.norm1.weight, blk.norm1.bias, blk.norm2.weight, blk.norm2.bias, blk.linear.linear1.weight,
+                blk.linear.linear1.bias, blk.linear.linear2.weight, blk.linear.linear2.bias, att.earth_specific_bias,
+                att.linear1.weight, att.linear1.bias, att.linear2.weight, att.linear2.bias,
+                (Z, H, W, att.head_number, i % 2 == 1), s1, s2, sh)
+        return x
+
+    outs, outs_s = [], []
+    for b in range(B):
+        x = PatchEmbedFnBF16.apply(emb.conv.weight, emb.conv.bias, emb.conv_surface.weight, emb.conv_surface.bias,
+                                   inp[b].contiguous(), inp_surface[b].contiguous(), s_mean, s_std, u_mean, u_std, maps_c,
+                                   const_c, sh)
+        skip = run_layer(model.layers[0], x, 8, H4, W4)
+        x = DownSampleFnBF16.apply(skip, dn.linear.weight, dn.norm.weight, dn.norm.bias, (8, H4, W4), sh)
+        x = run_layer(model.layers[1], x, 8, H2, W2)
+        x = run_layer(model.layers[2], x, 8, H2, W2)
+        x = UpSampleFnBF16.apply(x, up.linear1.weight, up.linear2.weight, up.norm.weight, up.norm.bias, (8, H2, W2, H4), sh)
+        x = run_layer(model.layers[3], x, 8, H4, W4)
+        o, os_ = PatchRecoverFnBF16.apply(torch.cat((skip, x), dim=-1), rec.conv.weight, rec.conv.bias,
+                                          rec.conv_surface.weight, rec.conv_surface.bias, (H4 * W4, LAT, LON), sh)
+        outs.append(o)
+        outs_s.append(os_)
+    return torch.stack(outs, 0), torch.stack(outs_s, 0)

@@ -1,0 +1,279 @@
+// Backward of the Earth-specific window attention, bf16 operands / fp32 softmax + accumulation, gfx950.
+//
+// Same decomposition as attn_bwd_f32.hip: one 9-wave workgroup per (window type, head) walks the longitude windows and
+// keeps d_esb[t][head] = sum_l dS in registers; wave w owns query tile w (dQ, d_esb; scores as S^T) and key tile w
+// (dK, dV; scores as S), so every accumulator is directly the operand of the next v_mfma_f32_16x16x32_bf16.
+// A 16x16 score tile is ONE MFMA (K = head_dim = 32); products that contract over tokens take two adjacent tiles'
+// accumulator quads as one 8-element operand (k index permuted identically on both sides) against TRANSPOSED
+// token-major images K^T, Q^T, dO^T ([32 d][160 tokens], 336-B rows) that the staging pass writes next to the
+// row-major ones.  66 MFMAs per wave and window: the kernel is bound by the exp/softmax VALU work and HBM.
+#include "common.h"
+
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16;
+
+constexpr int NW = 9, NT = NW * 64;
+constexpr int T_LD = 336;                      // bytes per row of a transposed image (160 tokens + pad)
+constexpr int ROWIMG = PANGU_WTOK * 64;        // bytes of a row-major [144][32] bf16 image
+constexpr int TIMG = 32 * T_LD;
+
+__device__ inline u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
+__device__ inline unsigned pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+__device__ inline float bflo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ inline float bfhi(unsigned u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
+__device__ inline float bf1(u16 h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+__device__ inline int kswz(int row, int chunk) {
+  const int f = (0x78 >> (((row >> 2) & 3) * 2)) & 3;
+  return row * 64 + ((chunk ^ f) << 4);
+}
+__device__ inline bf16x8 pack8(const f32x4& a, const f32x4& b) {
+  return __builtin_bit_cast(bf16x8, u32x4{pack2(a[0], a[1]), pack2(a[2], a[3]), pack2(b[0], b[1]), pack2(b[2], b[3])});
+}
+// 8-token fragment of a transposed image: tokens {32u + 4lg + e} and {32u + 16 + 4lg + e}, e = 0..3, of row `row`
+__device__ inline bf16x8 tfrag(const unsigned char* img, int row, int u, int lg) {
+  const unsigned char* p = img + row * T_LD + (32 * u + 4 * lg) * 2;
+  const u32x2 a = *reinterpret_cast<const u32x2*>(p);
+  const u32x2 b = *reinterpret_cast<const u32x2*>(p + 32);
+  return __builtin_bit_cast(bf16x8, u32x4{a[0], a[1], b[0], b[1]});
+}
+
+template <bool SHIFTED>
+__global__ __launch_bounds__(NT) void window_attn_bwd_bf16_kernel(
+    const u16* __restrict__ qkv, const u16* __restrict__ qkv_bias, const u16* __restrict__ esb,
+    const u16* __restrict__ out, const float* __restrict__ lse, const u16* __restrict__ dout, u16* __restrict__ dqkv,
+    float* __restrict__ dqkv_bias, float* __restrict__ d_esb, WinGeom g, int C, int heads) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Kr = smem;
+  unsigned char* Vr = Kr + ROWIMG;
+  unsigned char* Qr = Vr + ROWIMG;
+  unsigned char* Gr = Qr + ROWIMG;
+  unsigned char* Kt = Gr + ROWIMG;
+  unsigned char* Qt = Kt + TIMG;
+  unsigned char* Gt = Qt + TIMG;
+  float* lse_s = reinterpret_cast<float*>(Gt + TIMG);
+  float* del_s = lse_s + PANGU_WTOK;
+  int* tok_s = reinterpret_cast<int*>(del_s + PANGU_WTOK);
+
+  const int pair = blockIdx.x;
+  const int t = pair / heads, hd = pair - t * heads;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 15, lg = lane >> 4;
+  const int C3 = 3 * C;
+  const float scale = 0.17677669529663687f;
+  const u16* bias_tile = esb + (size_t)pair * PANGU_WTOK * PANGU_WTOK;
+
+  bool zcut = false, hcut = false;
+  if (SHIFTED) {
+    const int zwin = t / g.nHw, hwin = t - zwin * g.nHw;
+    zcut = zwin == g.nZw - 1;
+    hcut = hwin == g.nHw - 1;
+  }
+  auto masked = [&](int nq, int nk) -> bool {
+    const bool zd = (nq >= 72) != (nk >= 72);
+    const bool hdiff = (((nq / 12) % 6) < 3) != (((nk / 12) % 6) < 3);
+    return (zcut && zd) || (hcut && hdiff);
+  };
+
+  // zero the 16 pad tokens (144..159) of the three transposed images once: they meet zero probabilities but must be finite
+  for (int i = tid; i < 3 * 32 * 2; i += NT) {
+    const int img = i / 64, row = (i >> 1) & 31, half = i & 1;
+    *reinterpret_cast<u32x4*>(Kt + img * TIMG + row * T_LD + 288 + 16 * half) = u32x4{0u, 0u, 0u, 0u};
+  }
+
+  f32x4 dbias[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) dbias[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int l = 0; l < g.nLon; ++l) {
+    __syncthreads();
+    long lz = 0;
+    asm volatile("" : "+s"(lz));                  // keep the (window-invariant) bias loads inside the loop
+    const u16* bias_l = bias_tile + lz;
+    if (tid < PANGU_WTOK) tok_s[tid] = win_src_token(g, l, t, tid, SHIFTED);
+    __syncthreads();
+    // ---- stage: one 16-B chunk (8 dims) of q, k, v, dO, O per thread
+    {
+      const int n = tid >> 2, ch = tid & 3;
+      const int tok = tok_s[n];
+      const u16* src = tok >= 0 ? qkv + (size_t)tok * C3 : qkv_bias;
+      const u32x4 qv = *reinterpret_cast<const u32x4*>(src + hd * 32 + ch * 8);
+      const u32x4 kv = *reinterpret_cast<const u32x4*>(src + C + hd * 32 + ch * 8);
+      const u32x4 vv = *reinterpret_cast<const u32x4*>(src + 2 * C + hd * 32 + ch * 8);
+      u32x4 gv = {0u, 0u, 0u, 0u}, ov = {0u, 0u, 0u, 0u};
+      if (tok >= 0) {
+        gv = *reinterpret_cast<const u32x4*>(dout + (size_t)tok * C + hd * 32 + ch * 8);
+        ov = *reinterpret_cast<const u32x4*>(out + (size_t)tok * C + hd * 32 + ch * 8);
+      }
+      const int ro = kswz(n, ch);
+      *reinterpret_cast<u32x4*>(Qr + ro) = qv;
+      *reinterpret_cast<u32x4*>(Kr + ro) = kv;
+      *reinterpret_cast<u32x4*>(Vr + ro) = vv;
+      *reinterpret_cast<u32x4*>(Gr + ro) = gv;
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int d0 = (ch * 8 + 2 * e) * T_LD + n * 2;
+        *reinterpret_cast<u16*>(Kt + d0) = (u16)(kv[e] & 0xFFFFu);
+        *reinterpret_cast<u16*>(Kt + d0 + T_LD) = (u16)(kv[e] >> 16);
+        *reinterpret_cast<u16*>(Qt + d0) = (u16)(qv[e] & 0xFFFFu);
+        *reinterpret_cast<u16*>(Qt + d0 + T_LD) = (u16)(qv[e] >> 16);
+        *reinterpret_cast<u16*>(Gt + d0) = (u16)(gv[e] & 0xFFFFu);
+        *reinterpret_cast<u16*>(Gt + d0 + T_LD) = (u16)(gv[e] >> 16);
+        d += bflo(gv[e]) * bflo(ov[e]) + bfhi(gv[e]) * bfhi(ov[e]);
+      }
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      if (ch == 0) {
+        del_s[n] = d;
+        lse_s[n] = tok >= 0 ? lse[(size_t)tok * heads + hd] : 1e30f;     // pad query: exp(S - lse) = 0
+      }
+    }
+    __syncthreads();
+
+    // =========================== phase A: query tile `wave`, S^T orientation ===========================
+    {
+      const int qn = wave * 16 + lq;
+      const int qtok = tok_s[qn];
+      const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qr + kswz(qn, lg));
+      const bf16x8 gf = *reinterpret_cast<const bf16x8*>(Gr + kswz(qn, lg));
+      const float my_lse = lse_s[qn], my_del = del_s[qn];
+      const u16* brow = bias_l + (size_t)qn * PANGU_WTOK + lg * 4;
+      f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 dsp[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int j = 2 * u + h;
+          dsp[h] = zero;
+          if (j < 9) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kr + kswz(j * 16 + lq, lg));
+            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vr + kswz(j * 16 + lq, lg));
+            const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, zero, 0, 0, 0);
+            const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, gf, zero, 0, 0, 0);
+            const u32x2 bq = *reinterpret_cast<const u32x2*>(brow + j * 16);
+            const float bb[4] = {bflo(bq[0]), bfhi(bq[0]), bflo(bq[1]), bfhi(bq[1])};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float sv = fmaf(s[r], scale, bb[r]);
+              if (SHIFTED) { if (masked(qn, j * 16 + lg * 4 + r)) sv += -100.0f; }
+              const float p = __expf(sv - my_lse);
+              dsp[h][r] = p * (dp[r] - my_del);
+            }
+            dbias[j] += dsp[h];
+          }
+        }
+        // dQ^T[d][query] += K^T[d][keys of tiles 2u, 2u+1] . dS^T
+        const bf16x8 dsf = pack8(dsp[0], dsp[1]);
+        dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(Kt, lq, u, lg), dsf, dq0, 0, 0, 0);
+        dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(Kt, 16 + lq, u, lg), dsf, dq1, 0, 0, 0);
+      }
+      if (qtok >= 0) {        // lane: dQ^T[d = 16dt + 4lg + r][query qn]
+        u16* dst = dqkv + (size_t)qtok * C3 + hd * 32 + lg * 4;
+        *reinterpret_cast<u32x2*>(dst) = u32x2{pack2(dq0[0] * scale, dq0[1] * scale), pack2(dq0[2] * scale, dq0[3] * scale)};
+        *reinterpret_cast<u32x2*>(dst + 16) = u32x2{pack2(dq1[0] * scale, dq1[1] * scale), pack2(dq1[2] * scale, dq1[3] * scale)};
+      }
+    }
+
+    // =========================== phase B: key tile `wave`, S orientation ===========================
+    {
+      const int kn = wave * 16 + lq;
+      const int ktok = tok_s[kn];
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kr + kswz(kn, lg));
+      const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vr + kswz(kn, lg));
+      f32x4 dv0 = {0.f, 0.f, 0.f, 0.f}, dv1 = dv0, dk0 = dv0, dk1 = dv0;
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+      for (int u = 0; u < 5; ++u) {
+        f32x4 pp[2], dsp[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int i = 2 * u + h;
+          pp[h] = zero; dsp[h] = zero;
+          if (i < 9) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(Qr + kswz(i * 16 + lq, lg));
+            const bf16x8 bf = *reinterpret_cast<const bf16x8*>(Gr + kswz(i * 16 + lq, lg));
+            const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, kf, zero, 0, 0, 0);     // S[query 4lg+r][key lq]
+            const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, vf, zero, 0, 0, 0);
+            const f32x4 ls = *reinterpret_cast<const f32x4*>(&lse_s[i * 16 + lg * 4]);
+            const f32x4 dl = *reinterpret_cast<const f32x4*>(&del_s[i * 16 + lg * 4]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int qn = i * 16 + lg * 4 + r;
+              float sv = fmaf(s[r], scale, bf1(bias_l[(size_t)qn * PANGU_WTOK + kn]));
+              if (SHIFTED) { if (masked(qn, kn)) sv += -100.0f; }
+              const float p = __expf(sv - ls[r]);
+              pp[h][r] = p;
+              dsp[h][r] = p * (dp[r] - dl[r]);
+            }
+          }
+        }
+        // dV^T[d][key] += dO^T[d][queries] . P ;  dK^T[d][key] += Q^T[d][queries] . dS   (queries of tiles 2u, 2u+1)
+        const bf16x8 pf = pack8(pp[0], pp[1]);
+        const bf16x8 dsf = pack8(dsp[0], dsp[1]);
+        dv0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(Gt, lq, u, lg), pf, dv0, 0, 0, 0);
+        dv1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(Gt, 16 + lq, u, lg), pf, dv1, 0, 0, 0);
+        dk0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(Qt, lq, u, lg), dsf, dk0, 0, 0, 0);
+        dk1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(Qt, 16 + lq, u, lg), dsf, dk1, 0, 0, 0);
+      }
+      // lane: dK^T / dV^T [d = 16dt + 4lg + r][key kn]
+      dk0 *= scale; dk1 *= scale;
+      if (ktok >= 0) {
+        u16* dst = dqkv + (size_t)ktok * C3 + hd * 32 + lg * 4;
+        *reinterpret_cast<u32x2*>(dst + C) = u32x2{pack2(dk0[0], dk0[1]), pack2(dk0[2], dk0[3])};
+        *reinterpret_cast<u32x2*>(dst + C + 16) = u32x2{pack2(dk1[0], dk1[1]), pack2(dk1[2], dk1[3])};
+        *reinterpret_cast<u32x2*>(dst + 2 * C) = u32x2{pack2(dv0[0], dv0[1]), pack2(dv0[2], dv0[3])};
+        *reinterpret_cast<u32x2*>(dst + 2 * C + 16) = u32x2{pack2(dv1[0], dv1[1]), pack2(dv1[2], dv1[3])};
+      } else {
+        float* dst = dqkv_bias + hd * 32 + lg * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          atomicAdd(dst + C + r, dk0[r]);
+          atomicAdd(dst + C + 16 + r, dk1[r]);
+          atomicAdd(dst + 2 * C + r, dv0[r]);
+          atomicAdd(dst + 2 * C + 16 + r, dv1[r]);
+        }
+      }
+    }
+  }
+  float* drow = d_esb + (size_t)pair * PANGU_WTOK * PANGU_WTOK + (size_t)(wave * 16 + lq) * PANGU_WTOK + lg * 4;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) *reinterpret_cast<f32x4*>(drow + j * 16) = dbias[j];
+}
+
+}  // namespace
+
+extern "C" int pangu_window_attn_bwd_bf16(pangu_stream_t stream, const void* qkv, const void* qkv_bias, const void* esb,
+                                          const void* out, const float* lse, const void* dout, void* dqkv,
+                                          float* dqkv_bias, float* d_esb, int Z, int H, int W, int C, int heads,
+                                          int shifted) {
+  if (!qkv || !qkv_bias || !esb || !out || !lse || !dout || !dqkv || !dqkv_bias || !d_esb) return PANGU_E_NULL;
+  if (Z <= 0 || H <= 0 || W <= 0 || Z % PANGU_WZ || (H + PANGU_PAD_H) % PANGU_WH || W % PANGU_WW) return PANGU_E_SHAPE;
+  if (heads <= 0 || C != heads * PANGU_HEAD_DIM) return PANGU_E_SHAPE;
+  const WinGeom g = make_geom(Z, H, W);
+  const int n_pairs = g.types * heads;
+  const size_t shm = 4 * (size_t)ROWIMG + 3 * (size_t)TIMG + 3 * PANGU_WTOK * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_bwd_bf16_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_bwd_bf16_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    attr_set = true;
+  }
+  if (shifted)
+    hipLaunchKernelGGL(window_attn_bwd_bf16_kernel<true>, dim3(n_pairs), dim3(NT), shm, s, (const u16*)qkv,
+                       (const u16*)qkv_bias, (const u16*)esb, (const u16*)out, lse, (const u16*)dout, (u16*)dqkv, dqkv_bias,
+                       d_esb, g, C, heads);
+  else
+    hipLaunchKernelGGL(window_attn_bwd_bf16_kernel<false>, dim3(n_pairs), dim3(NT), shm, s, (const u16*)qkv,
+                       (const u16*)qkv_bias, (const u16*)esb, (const u16*)out, lse, (const u16*)dout, (u16*)dqkv, dqkv_bias,
+                       d_esb, g, C, heads);
+  return pangu_launch_status();
+}

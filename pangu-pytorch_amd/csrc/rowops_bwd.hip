@@ -10,6 +10,21 @@ namespace {
 constexpr float LN_EPS = 1e-5f;
 constexpr int ROWS_PER_BLOCK = 4;
 
+typedef unsigned short u16;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ inline f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ inline void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ inline u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
+__device__ inline f32x4 ld4(const u16* p) {
+  const u32x2 u = *reinterpret_cast<const u32x2*>(p);
+  return f32x4{__builtin_bit_cast(float, u[0] << 16), __builtin_bit_cast(float, u[0] & 0xFFFF0000u),
+               __builtin_bit_cast(float, u[1] << 16), __builtin_bit_cast(float, u[1] & 0xFFFF0000u)};
+}
+__device__ inline void st4(u16* p, f32x4 v) {
+  *reinterpret_cast<u32x2*>(p) = u32x2{(unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16),
+                                        (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16)};
+}
+
 // y: pre-norm row (in), g: upstream gradient row already multiplied by the branch scale (in) -> dy (out, in y)
 template <int NV>
 __device__ inline void row_ln_bwd(f32x4 (&y)[NV], const f32x4 (&g)[NV], int nvec, int lane, int C,
@@ -64,10 +79,10 @@ __device__ inline void flush_param_grads(const f32x4 (&dg)[NV], const f32x4 (&db
   }
 }
 
-template <int NV>
-__global__ __launch_bounds__(256) void ln_residual_bwd_kernel(const float* __restrict__ dout, int lddo,
-                                                              const float* __restrict__ yin,
-                                                              const float* __restrict__ gamma, float* __restrict__ dy,
+template <int NV, typename T>
+__global__ __launch_bounds__(256) void ln_residual_bwd_kernel(const T* __restrict__ dout, int lddo,
+                                                              const T* __restrict__ yin,
+                                                              const float* __restrict__ gamma, T* __restrict__ dy,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               int N, int C, float branch_scale) {
   extern __shared__ __attribute__((aligned(16))) float red[];
@@ -81,21 +96,21 @@ __global__ __launch_bounds__(256) void ln_residual_bwd_kernel(const float* __res
 #pragma unroll
     for (int i = 0; i < NV; ++i)
       if (lane + 64 * i < nvec) {
-        y[i] = *reinterpret_cast<const f32x4*>(yin + (size_t)row * C + 4 * (lane + 64 * i));
-        g[i] = *reinterpret_cast<const f32x4*>(dout + (size_t)row * lddo + 4 * (lane + 64 * i)) * branch_scale;
+        y[i] = ld4(yin + (size_t)row * C + 4 * (lane + 64 * i));
+        g[i] = ld4(dout + (size_t)row * lddo + 4 * (lane + 64 * i)) * branch_scale;
       }
     row_ln_bwd<NV>(y, g, nvec, lane, C, gamma, dg, db);
 #pragma unroll
     for (int i = 0; i < NV; ++i)
-      if (lane + 64 * i < nvec) *reinterpret_cast<f32x4*>(dy + (size_t)row * C + 4 * (lane + 64 * i)) = y[i];
+      if (lane + 64 * i < nvec) st4(dy + (size_t)row * C + 4 * (lane + 64 * i), y[i]);
   }
   flush_param_grads<NV>(dg, db, nvec, lane, wave, dgamma, dbeta, red);
 }
 
-template <int NV>
-__global__ __launch_bounds__(256) void downsample_ln_bwd_kernel(const float* __restrict__ dout,
-                                                                const float* __restrict__ x, int ldx,
-                                                                const float* __restrict__ gamma, float* __restrict__ dx,
+template <int NV, typename T>
+__global__ __launch_bounds__(256) void downsample_ln_bwd_kernel(const T* __restrict__ dout,
+                                                                const T* __restrict__ x, int ldx,
+                                                                const float* __restrict__ gamma, T* __restrict__ dx,
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                 int Z, int H, int W, int C) {
   extern __shared__ __attribute__((aligned(16))) float red[];
@@ -118,23 +133,23 @@ __global__ __launch_bounds__(256) void downsample_ln_bwd_kernel(const float* __r
         const int h = 2 * h2 + (quad >> 1), w = 2 * w2 + (quad & 1);
         real[i] = h < H;
         src[i] = (size_t)(z * H + h) * W + w;
-        y[i] = real[i] ? *reinterpret_cast<const f32x4*>(x + src[i] * ldx + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        g[i] = *reinterpret_cast<const f32x4*>(dout + (size_t)row * C4 + 4 * f);
+        y[i] = real[i] ? ld4(x + src[i] * ldx + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        g[i] = ld4(dout + (size_t)row * C4 + 4 * f);
         src[i] = src[i] * C + 4 * c4;
       }
     }
     row_ln_bwd<NV>(y, g, nvec, lane, C4, gamma, dg, db);
 #pragma unroll
     for (int i = 0; i < NV; ++i)
-      if (lane + 64 * i < nvec && real[i]) *reinterpret_cast<f32x4*>(dx + src[i]) = y[i];
+      if (lane + 64 * i < nvec && real[i]) st4(dx + src[i], y[i]);
   }
   flush_param_grads<NV>(dg, db, nvec, lane, wave, dgamma, dbeta, red);
 }
 
-template <int NV>
-__global__ __launch_bounds__(256) void upsample_ln_bwd_kernel(const float* __restrict__ dout,
-                                                              const float* __restrict__ yin,
-                                                              const float* __restrict__ gamma, float* __restrict__ dy,
+template <int NV, typename T>
+__global__ __launch_bounds__(256) void upsample_ln_bwd_kernel(const T* __restrict__ dout,
+                                                              const T* __restrict__ yin,
+                                                              const float* __restrict__ gamma, T* __restrict__ dy,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               int Z, int H2, int W2, int H, int Co) {
   extern __shared__ __attribute__((aligned(16))) float red[];
@@ -151,20 +166,20 @@ __global__ __launch_bounds__(256) void upsample_ln_bwd_kernel(const float* __res
     if (h >= H) {
 #pragma unroll
       for (int i = 0; i < NV; ++i)
-        if (lane + 64 * i < nvec) *reinterpret_cast<f32x4*>(dy + src + 4 * (lane + 64 * i)) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (lane + 64 * i < nvec) st4(dy + src + 4 * (lane + 64 * i), f32x4{0.f, 0.f, 0.f, 0.f});
       continue;
     }
     const size_t orow = ((size_t)z * H + h) * Wf + w;
 #pragma unroll
     for (int i = 0; i < NV; ++i)
       if (lane + 64 * i < nvec) {
-        y[i] = *reinterpret_cast<const f32x4*>(yin + src + 4 * (lane + 64 * i));
-        g[i] = *reinterpret_cast<const f32x4*>(dout + orow * Co + 4 * (lane + 64 * i));
+        y[i] = ld4(yin + src + 4 * (lane + 64 * i));
+        g[i] = ld4(dout + orow * Co + 4 * (lane + 64 * i));
       }
     row_ln_bwd<NV>(y, g, nvec, lane, Co, gamma, dg, db);
 #pragma unroll
     for (int i = 0; i < NV; ++i)
-      if (lane + 64 * i < nvec) *reinterpret_cast<f32x4*>(dy + src + 4 * (lane + 64 * i)) = y[i];
+      if (lane + 64 * i < nvec) st4(dy + src + 4 * (lane + 64 * i), y[i]);
   }
   flush_param_grads<NV>(dg, db, nvec, lane, wave, dgamma, dbeta, red);
 }
@@ -172,10 +187,11 @@ __global__ __launch_bounds__(256) void upsample_ln_bwd_kernel(const float* __res
 // gradient of patch_recover_scatter: gather the field gradients back into GEMM-output layout
 constexpr int EMB_TOK = 64;
 
+template <typename T>
 __global__ __launch_bounds__(256) void patch_recover_gather_bwd_kernel(const float* __restrict__ d_output,
                                                                        const float* __restrict__ d_output_surface,
-                                                                       float* __restrict__ dy_upper,
-                                                                       float* __restrict__ dy_surface, int LAT, int LON,
+                                                                       T* __restrict__ dy_upper,
+                                                                       T* __restrict__ dy_surface, int LAT, int LON,
                                                                        int H4, int W4, int chunks) {
   __shared__ float tile[EMB_TOK * 161];
   const int chunk = blockIdx.x % chunks, h4 = (blockIdx.x / chunks) % H4, zp = blockIdx.x / (chunks * H4);
@@ -197,11 +213,11 @@ __global__ __launch_bounds__(256) void patch_recover_gather_bwd_kernel(const flo
       tile[(i >> 2) * 161 + run * 4 + (i & 3)] = valid ? src[4 * w0 + i] : 0.f;
   }
   __syncthreads();
-  float* dst = zp == 0 ? dy_surface + ((size_t)h4 * W4 + w0) * 64
-                       : dy_upper + (((size_t)(zp - 1) * H4 + h4) * W4 + w0) * 160;
+  T* dst = zp == 0 ? dy_surface + ((size_t)h4 * W4 + w0) * 64 : dy_upper + (((size_t)(zp - 1) * H4 + h4) * W4 + w0) * 160;
   for (int i = tid; i < ntok * ncol; i += 256) {
     const int tk = i / ncol, col = i - tk * ncol;
-    dst[i] = tile[tk * 161 + col];
+    if constexpr (sizeof(T) == 2) dst[i] = f2bf(tile[tk * 161 + col]);
+    else dst[i] = tile[tk * 161 + col];
   }
 }
 
@@ -212,12 +228,12 @@ int row_grid(int rows) {
 
 }  // namespace
 
-#define PANGU_NV_DISPATCH(C_, KERNEL, ...)                                                                           \
+#define PANGU_NV_DISPATCH(C_, KERNEL, T, ...)                                                                        \
   do {                                                                                                               \
     const size_t shm = (size_t)8 * (C_) * sizeof(float);                                                             \
-    if ((C_) <= 256) hipLaunchKernelGGL(KERNEL<1>, g, b, shm, s, __VA_ARGS__);                                       \
-    else if ((C_) <= 512) hipLaunchKernelGGL(KERNEL<2>, g, b, shm, s, __VA_ARGS__);                                  \
-    else hipLaunchKernelGGL(KERNEL<4>, g, b, shm, s, __VA_ARGS__);                                                   \
+    if ((C_) <= 256) hipLaunchKernelGGL((KERNEL<1, T>), g, b, shm, s, __VA_ARGS__);                                  \
+    else if ((C_) <= 512) hipLaunchKernelGGL((KERNEL<2, T>), g, b, shm, s, __VA_ARGS__);                             \
+    else hipLaunchKernelGGL((KERNEL<4, T>), g, b, shm, s, __VA_ARGS__);                                              \
   } while (0)
 
 extern "C" int pangu_ln_residual_bwd(pangu_stream_t stream, const float* dout, int lddo, const float* y,
@@ -227,7 +243,7 @@ extern "C" int pangu_ln_residual_bwd(pangu_stream_t stream, const float* dout, i
   if (N <= 0 || C <= 0 || (C & 3) || C > 1024 || lddo < C || (lddo & 3)) return PANGU_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   dim3 g(row_grid(N)), b(256);
-  PANGU_NV_DISPATCH(C, ln_residual_bwd_kernel, dout, lddo, y, gamma, dy, dgamma, dbeta, N, C, branch_scale);
+  PANGU_NV_DISPATCH(C, ln_residual_bwd_kernel, float, dout, lddo, y, gamma, dy, dgamma, dbeta, N, C, branch_scale);
   return pangu_launch_status();
 }
 
@@ -238,7 +254,7 @@ extern "C" int pangu_downsample_ln_bwd(pangu_stream_t stream, const float* dout,
   if (Z <= 0 || H <= 0 || W <= 0 || (W & 1) || (C & 3) || 4 * C > 1024 || ldx < C || (ldx & 3)) return PANGU_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   dim3 g(row_grid(Z * ((H + 1) / 2) * (W / 2))), b(256);
-  PANGU_NV_DISPATCH(4 * C, downsample_ln_bwd_kernel, dout, x, ldx, gamma, dx, dgamma, dbeta, Z, H, W, C);
+  PANGU_NV_DISPATCH(4 * C, downsample_ln_bwd_kernel, float, dout, x, ldx, gamma, dx, dgamma, dbeta, Z, H, W, C);
   return pangu_launch_status();
 }
 
@@ -248,7 +264,7 @@ extern "C" int pangu_upsample_ln_bwd(pangu_stream_t stream, const float* dout, c
   if (Z <= 0 || H2 <= 0 || W2 <= 0 || H <= 0 || H > 2 * H2 || (Co & 3) || Co > 1024) return PANGU_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   dim3 g(row_grid(Z * 2 * H2 * 2 * W2)), b(256);
-  PANGU_NV_DISPATCH(Co, upsample_ln_bwd_kernel, dout, y, gamma, dy, dgamma, dbeta, Z, H2, W2, H, Co);
+  PANGU_NV_DISPATCH(Co, upsample_ln_bwd_kernel, float, dout, y, gamma, dy, dgamma, dbeta, Z, H2, W2, H, Co);
   return pangu_launch_status();
 }
 
@@ -258,7 +274,55 @@ extern "C" int pangu_patch_recover_gather_bwd(pangu_stream_t stream, const float
   if (!d_output || !d_output_surface || !dy_upper || !dy_surface) return PANGU_E_NULL;
   if (LAT <= 0 || LON <= 0 || (LON & 3)) return PANGU_E_SHAPE;
   const int H4 = (LAT + 3) / 4, W4 = LON / 4, chunks = (W4 + EMB_TOK - 1) / EMB_TOK;
-  hipLaunchKernelGGL(patch_recover_gather_bwd_kernel, dim3(8 * H4 * chunks), dim3(256), 0, (hipStream_t)stream, d_output,
+  hipLaunchKernelGGL(patch_recover_gather_bwd_kernel<float>, dim3(8 * H4 * chunks), dim3(256), 0, (hipStream_t)stream, d_output,
                      d_output_surface, dy_upper, dy_surface, LAT, LON, H4, W4, chunks);
+  return pangu_launch_status();
+}
+
+// ---- bf16 I/O variants (dout / saved activations / outputs bf16; statistics, dgamma, dbeta fp32) ----------------
+
+extern "C" int pangu_ln_residual_bwd_bf16(pangu_stream_t stream, const void* dout, int lddo, const void* y,
+                                          const float* gamma, void* dy, float* dgamma, float* dbeta, int N, int C,
+                                          float branch_scale) {
+  if (!dout || !y || !gamma || !dy || !dgamma || !dbeta) return PANGU_E_NULL;
+  if (N <= 0 || C <= 0 || (C & 3) || C > 1024 || lddo < C || (lddo & 3)) return PANGU_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g(row_grid(N)), b(256);
+  PANGU_NV_DISPATCH(C, ln_residual_bwd_kernel, u16, (const u16*)dout, lddo, (const u16*)y, gamma, (u16*)dy, dgamma, dbeta, N,
+                    C, branch_scale);
+  return pangu_launch_status();
+}
+
+extern "C" int pangu_downsample_ln_bwd_bf16(pangu_stream_t stream, const void* dout, const void* x, int ldx,
+                                            const float* gamma, void* dx, float* dgamma, float* dbeta, int Z, int H, int W,
+                                            int C) {
+  if (!dout || !x || !gamma || !dx || !dgamma || !dbeta) return PANGU_E_NULL;
+  if (Z <= 0 || H <= 0 || W <= 0 || (W & 1) || (C & 3) || 4 * C > 1024 || ldx < C || (ldx & 3)) return PANGU_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g(row_grid(Z * ((H + 1) / 2) * (W / 2))), b(256);
+  PANGU_NV_DISPATCH(4 * C, downsample_ln_bwd_kernel, u16, (const u16*)dout, (const u16*)x, ldx, gamma, (u16*)dx, dgamma,
+                    dbeta, Z, H, W, C);
+  return pangu_launch_status();
+}
+
+extern "C" int pangu_upsample_ln_bwd_bf16(pangu_stream_t stream, const void* dout, const void* y, const float* gamma,
+                                          void* dy, float* dgamma, float* dbeta, int Z, int H2, int W2, int H, int Co) {
+  if (!dout || !y || !gamma || !dy || !dgamma || !dbeta) return PANGU_E_NULL;
+  if (Z <= 0 || H2 <= 0 || W2 <= 0 || H <= 0 || H > 2 * H2 || (Co & 3) || Co > 1024) return PANGU_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g(row_grid(Z * 2 * H2 * 2 * W2)), b(256);
+  PANGU_NV_DISPATCH(Co, upsample_ln_bwd_kernel, u16, (const u16*)dout, (const u16*)y, gamma, (u16*)dy, dgamma, dbeta, Z, H2,
+                    W2, H, Co);
+  return pangu_launch_status();
+}
+
+extern "C" int pangu_patch_recover_gather_bwd_bf16(pangu_stream_t stream, const float* d_output,
+                                                   const float* d_output_surface, void* dy_upper, void* dy_surface,
+                                                   int LAT, int LON) {
+  if (!d_output || !d_output_surface || !dy_upper || !dy_surface) return PANGU_E_NULL;
+  if (LAT <= 0 || LON <= 0 || (LON & 3)) return PANGU_E_SHAPE;
+  const int H4 = (LAT + 3) / 4, W4 = LON / 4, chunks = (W4 + EMB_TOK - 1) / EMB_TOK;
+  hipLaunchKernelGGL(patch_recover_gather_bwd_kernel<u16>, dim3(8 * H4 * chunks), dim3(256), 0, (hipStream_t)stream,
+                     d_output, d_output_surface, (u16*)dy_upper, (u16*)dy_surface, LAT, LON, H4, W4, chunks);
   return pangu_launch_status();
 }

@@ -26,6 +26,16 @@ class WeightShadow:
         self.cache[key] = (p._version, w)
         return w
 
+    def get_t(self, p):
+        """Transposed bf16 shadow (in, out): the `W` operand of the input-gradient GEMM dA = dC @ W."""
+        key = ("t", id(p))
+        hit = self.cache.get(key)
+        if hit is not None and hit[0] == p._version and hit[1].device == p.device:
+            return hit[1]
+        w = p.detach().reshape(p.shape[0], -1).t().to(torch.bfloat16).contiguous()
+        self.cache[key] = (p._version, w)
+        return w
+
 
 def _block(blk, sh, x, Z, H, W, roll, out=None):
     """x (N,C) bf16 -> (N,C) bf16 (eval: DropPath is the identity)."""

@@ -98,3 +98,85 @@ def patch_embed_gather(inp, inp_surface, s_mean, s_std, u_mean, u_std, maps, con
                                                  _p(u_std, "u_std", f), _p(maps, "maps", f), _p(const_h, "const_h", f),
                                                  a_s.data_ptr(), a_u.data_ptr(), LAT, LON), "patch_embed_gather_bf16")
     return a_s, a_u
+
+
+# ---------------------------------------------------------------- backward
+def linear_wgrad(dc, a, want_bias=True):
+    """dW[N,K] (fp32) = dc[M,N]^T @ a[M,K], db[N] = colsum(dc); bf16 operands (row-strided views allowed)."""
+    lib = _lib.load()
+    dp, lddc = _rows(dc, "wgrad.dc")
+    ap, lda = _rows(a, "wgrad.a")
+    M, N = dc.shape
+    K = a.shape[1]
+    dw = torch.zeros((N, K), dtype=torch.float32, device=dc.device)
+    db = torch.zeros((N,), dtype=torch.float32, device=dc.device) if want_bias else None
+    with _timed("wgrad_bf16", 2.0 * M * N * K):
+        _lib.check(lib.pangu_linear_wgrad_bf16(_stream(), dp, lddc, ap, lda, dw.data_ptr(),
+                                               db.data_ptr() if want_bias else None, M, N, K), "linear_wgrad_bf16")
+    return dw, db
+
+
+def window_attention_bwd(qkv, qkv_bias, esb, out, lse, dout, Z, H, W, heads, shifted):
+    lib = _lib.load()
+    N, C3 = qkv.shape
+    C = C3 // 3
+    dqkv = torch.empty_like(qkv)
+    dqb = torch.zeros((C3,), dtype=torch.float32, device=qkv.device)
+    desb = torch.empty(esb.shape, dtype=torch.float32, device=qkv.device)
+    Np = (Z // 2) * ((H + 5) // 6) * (W // 12) * 144
+    with _timed("attn_bwd_bf16", 14.0 * Np * 144 * C):
+        _lib.check(lib.pangu_window_attn_bwd_bf16(_stream(), _p(qkv, "qkv"), _p(qkv_bias, "qkv_bias"), _p(esb, "esb"),
+                                                  _p(out, "out"), _p(lse, "lse", torch.float32), _p(dout, "dout"),
+                                                  dqkv.data_ptr(), dqb.data_ptr(), desb.data_ptr(), Z, H, W, C, heads,
+                                                  int(shifted)), "window_attn_bwd_bf16")
+    return dqkv, dqb, desb
+
+
+def ln_residual_bwd(dout, y, gamma, branch_scale=1.0):
+    lib = _lib.load()
+    N, C = y.shape
+    dp, lddo = _rows(dout, "ln_bwd.dout")
+    dy = torch.empty_like(y)
+    dg = torch.zeros((C,), dtype=torch.float32, device=y.device)
+    db = torch.zeros((C,), dtype=torch.float32, device=y.device)
+    _lib.check(lib.pangu_ln_residual_bwd_bf16(_stream(), dp, lddo, _p(y, "y"), _p(gamma, "gamma", torch.float32),
+                                              dy.data_ptr(), dg.data_ptr(), db.data_ptr(), N, C, float(branch_scale)),
+               "ln_residual_bwd_bf16")
+    return dy, dg, db
+
+
+def downsample_ln_bwd(dout, x, gamma, Z, H, W):
+    lib = _lib.load()
+    xp, ldx = _rows(x, "x")
+    C = x.shape[1]
+    dx = torch.empty((Z * H * W, C), dtype=torch.bfloat16, device=x.device)
+    dg = torch.zeros((4 * C,), dtype=torch.float32, device=x.device)
+    db = torch.zeros((4 * C,), dtype=torch.float32, device=x.device)
+    _lib.check(lib.pangu_downsample_ln_bwd_bf16(_stream(), _p(dout, "dout"), xp, ldx, _p(gamma, "gamma", torch.float32),
+                                                dx.data_ptr(), dg.data_ptr(), db.data_ptr(), Z, H, W, C),
+               "downsample_ln_bwd_bf16")
+    return dx, dg, db
+
+
+def upsample_ln_bwd(dout, y, gamma, Z, H2, W2, H):
+    lib = _lib.load()
+    Co = y.shape[1] // 4
+    dy = torch.empty_like(y)
+    dg = torch.zeros((Co,), dtype=torch.float32, device=y.device)
+    db = torch.zeros((Co,), dtype=torch.float32, device=y.device)
+    _lib.check(lib.pangu_upsample_ln_bwd_bf16(_stream(), _p(dout, "dout"), _p(y, "y"), _p(gamma, "gamma", torch.float32),
+                                              dy.data_ptr(), dg.data_ptr(), db.data_ptr(), Z, H2, W2, H, Co),
+               "upsample_ln_bwd_bf16")
+    return dy, dg, db
+
+
+def patch_recover_gather_bwd(d_out, d_out_s):
+    lib = _lib.load()
+    LAT, LON = d_out.shape[-2], d_out.shape[-1]
+    H4, W4 = (LAT + 3) // 4, LON // 4
+    dy_u = torch.empty((7 * H4 * W4, 160), dtype=torch.bfloat16, device=d_out.device)
+    dy_s = torch.empty((H4 * W4, 64), dtype=torch.bfloat16, device=d_out.device)
+    _lib.check(lib.pangu_patch_recover_gather_bwd_bf16(_stream(), _p(d_out, "d_output", torch.float32),
+                                                       _p(d_out_s, "d_output_surface", torch.float32), dy_u.data_ptr(),
+                                                       dy_s.data_ptr(), LAT, LON), "patch_recover_gather_bwd_bf16")
+    return dy_u, dy_s

@@ -85,10 +85,12 @@ class PanguModel(nn.Module):
         grad_path = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         want_bf16 = self.compute_dtype == torch.bfloat16 or (
             torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16)
-        if want_bf16 and not grad_path:
-            from . import fused_bf16
+        if want_bf16:
+            from . import autograd_bf16, fused_bf16
             if self._shadow is None:
                 self._shadow = fused_bf16.WeightShadow()
+            if grad_path:
+                return autograd_bf16.forward_train(self, input, input_surface, statistics, maps, const_h)
             return fused_bf16.forward(self, input, input_surface, statistics, maps, const_h)
         B = input.shape[0]
         x = self._input_layer(input, input_surface, statistics, maps, const_h)             # (B,521280,192)

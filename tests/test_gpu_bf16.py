@@ -142,3 +142,116 @@ def test_full_model_bf16_drift(P, golden_dir):
     print(f"bf16 vs fp32 rel-L2 drift: upper {l2:.3e} surface {l2s:.3e}")
     assert l2 < 5e-2 and l2s < 5e-2
     assert cases.compare_summary(out, g, "model.out", 1.0) < 0.2
+
+
+# ------------------------------------------------------------------------------------------------ bf16 backward
+@pytest.mark.parametrize("M,N,K", [(4096, 192, 192), (5000, 576, 192), (3001, 768, 192), (2500, 192, 768),
+                                   (4111, 1152, 384), (2222, 384, 1536), (3333, 160, 384), (1999, 64, 384),
+                                   (2777, 192, 128), (100, 384, 768)])
+def test_linear_wgrad_bf16(P, M, N, K):
+    from pangu_pytorch_amd import ops_bf16 as ob
+    dc, a = synth.uniform((M, N), 61).to(BF), synth.uniform((M, K), 62).to(BF)
+    dw, db = ob.linear_wgrad(dc.cuda(), a.cuda())
+    assert dw.dtype == torch.float32
+    assert rel_err(dw, dc.double().t() @ a.double()) < 2e-4          # exact bf16 products, fp32 accumulation
+    assert rel_err(db, dc.double().sum(0)) < 2e-4
+
+
+@pytest.mark.parametrize("C", [192, 384])
+def test_ln_residual_bwd_bf16(P, C):
+    from pangu_pytorch_amd import ops_bf16 as ob
+    N = 2051
+    y = synth.uniform((N, C), 71, 2.0, 0.3).to(BF)
+    dout = synth.uniform((N, C), 74).to(BF)
+    yr = y.float().requires_grad_(True)
+    g = synth.uniform((C,), 72, 0.1, 1.0).requires_grad_(True)
+    b = synth.uniform((C,), 73, 0.1).requires_grad_(True)
+    (1.25 * torch.nn.functional.layer_norm(yr, (C,), g, b) * dout.float()).sum().backward()
+    dy, dg, db = ob.ln_residual_bwd(dout.cuda(), y.cuda(), g.detach().cuda(), 1.25)
+    assert rel_err(dy, yr.grad) < ROUND and rel_err(dg, g.grad) < 1e-3 and rel_err(db, b.grad) < 1e-3
+
+
+@pytest.mark.parametrize("C", [192, 384])
+@pytest.mark.parametrize("shifted", [False, True])
+def test_window_attention_bwd_bf16(P, C, shifted):
+    from pangu_pytorch_amd import ops_bf16 as ob
+    st = cases.STAGES[C]
+    Z, H, W, heads = st["Z"], st["H"], 24, st["heads"]
+    N = Z * H * W
+    qkv = synth.uniform((1, N, 3 * C), 81, 1.5).to(BF)
+    b1 = synth.uniform((3 * C,), 82, 0.5).to(BF)
+    esb = synth.uniform((1, st["types"], heads, 144, 144), 83, 0.5).to(BF)
+    do = synth.uniform((1, N, C), 84).to(BF)
+    q32, b32, e32 = qkv.float().requires_grad_(True), b1.float().requires_grad_(True), esb.float().requires_grad_(True)
+    ref, _ = O.window_attention_core(q32, b32, e32, Z, H, W, heads, shifted)
+    (ref * do.float()).sum().backward()
+    o, lse = ob.window_attention(qkv[0].cuda(), b1.cuda(), esb[0].cuda(), Z, H, W, heads, shifted, want_lse=True)
+    dqkv, dqb, desb = ob.window_attention_bwd(qkv[0].cuda(), b1.cuda(), esb[0].cuda(), o, lse, do[0].cuda(), Z, H, W,
+                                              heads, shifted)
+    # P and dS are rounded to bf16 before the second products, dqkv is stored as bf16: a few 2^-9 steps
+    assert rel_err(dqkv, q32.grad[0]) < 2 * ROUND
+    assert rel_err(desb, e32.grad[0]) < 2 * ROUND
+    assert rel_err(dqb, b32.grad) < 2 * ROUND
+
+
+def test_block_backward_bf16_vs_fp32(P, golden_dir):
+    """One block fwd+bwd in bf16 vs the reference's fp32 gradients: rel-L2 per tensor reported, bounded at 2e-2."""
+    C, roll = 192, True
+    tag = f"block_{C}_{int(roll)}"
+    st = cases.STAGES[C]
+    from pangu_pytorch_amd import autograd_bf16 as AB, fused_bf16
+    blk = P.layers.EarthSpecificBlock(C, 0.0, st["heads"], device="cuda").cuda().eval()
+    pre = cases.block_prefix(C, roll)
+    blk.load_state_dict({k: synth.synth_param(pre + k, s, "cuda") for k, s in cases.block_param_shapes(C).items()})
+    x = cases.block_input(C, 24, "cuda")
+    # fp32 HIP path = reference-accurate (tests/test_gpu_backward.py)
+    x32 = x.clone().requires_grad_(True)
+    y32 = blk(x32, st["Z"], st["H"], 24, roll)
+    cot = cases.cotangent(tag, y32.shape, "cuda")
+    (y32 * cot).sum().backward()
+    ref = {k: p.grad.clone() for k, p in blk.named_parameters()}
+    ref_dx = x32.grad.clone()
+    blk.zero_grad()
+    att = blk.attention
+    sh = fused_bf16.WeightShadow()
+    xb = x[0].to(BF).requires_grad_(True)
+    yb = AB.EarthBlockFnBF16.apply(xb, blk.norm1.weight, blk.norm1.bias, blk.norm2.weight, blk.norm2.bias,
+                                   blk.linear.linear1.weight, blk.linear.linear1.bias, blk.linear.linear2.weight,
+                                   blk.linear.linear2.bias, att.earth_specific_bias, att.linear1.weight, att.linear1.bias,
+                                   att.linear2.weight, att.linear2.bias, (st["Z"], st["H"], 24, st["heads"], roll), 1.0,
+                                   1.0, sh)
+    (yb.float() * cot[0]).sum().backward()
+    l2 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()
+    worst = max((l2(p.grad, ref[k]), k) for k, p in blk.named_parameters())
+    dxe = l2(xb.grad.float(), ref_dx[0])
+    print(f"bf16 block backward rel-L2: dx {dxe:.3e}, worst param {worst[1]} {worst[0]:.3e}")
+    assert dxe < 2e-2 and worst[0] < 2e-2
+
+
+def test_full_training_step_bf16(P):
+    """Whole bf16 training step runs, loss close to the fp32 step's, gradients finite and close in rel-L2."""
+    from pangu_pytorch_amd import train
+    m = P.PanguModel(device="cuda").cuda().eval()
+    m.load_state_dict(synth.fill_state_dict(cases.model_param_shapes(), "cuda"))
+    inp, inp_s, stats, maps, const_h = cases.model_inputs("cuda")
+    tgt, tgt_s = cases.model_targets("cuda")
+    out, out_s = m(inp, inp_s, stats, maps, const_h)
+    l32 = train.weighted_l1_loss(out, out_s, tgt, tgt_s)
+    l32.backward()
+    ref = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.zero_grad(set_to_none=True)
+    del out, out_s
+    m.set_compute_dtype(BF)
+    out, out_s = m(inp, inp_s, stats, maps, const_h)
+    assert out.dtype == torch.float32
+    lb = train.weighted_l1_loss(out, out_s, tgt, tgt_s)
+    lb.backward()
+    assert abs(lb.item() - l32.item()) / l32.item() < 2e-2
+    errs = []
+    for k, p in m.named_parameters():
+        assert p.grad is not None and p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all(), k
+        errs.append((((p.grad.double() - ref[k].double()).norm() / ref[k].double().norm().clamp_min(1e-30)).item(), k))
+    errs.sort(reverse=True)
+    print("bf16 training step: loss fp32 %.6f bf16 %.6f; worst grad rel-L2:" % (l32.item(), lb.item()), errs[:3])
+    med = errs[len(errs) // 2][0]
+    assert med < 0.1, med
