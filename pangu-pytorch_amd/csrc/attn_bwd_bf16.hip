@@ -56,6 +56,8 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_bf16_kernel(
   float* lse_s = reinterpret_cast<float*>(Gt + TIMG);
   float* del_s = lse_s + PANGU_WTOK;
   int* tok_s = reinterpret_cast<int*>(del_s + PANGU_WTOK);
+  float* pad_s = reinterpret_cast<float*>(tok_s + PANGU_WTOK);     // [2][32]: dK, dV summed over the zero-pad keys
+  u16* Bs = reinterpret_cast<u16*>(pad_s + 64);                    // [144][144] bf16 bias tile (window-invariant)
 
   const int pair = blockIdx.x;
   const int t = pair / heads, hd = pair - t * heads;
@@ -83,15 +85,19 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_bf16_kernel(
     *reinterpret_cast<u32x4*>(Kt + img * TIMG + row * T_LD + 288 + 16 * half) = u32x4{0u, 0u, 0u, 0u};
   }
 
+  if (tid < 64) pad_s[tid] = 0.f;
+  for (int i = tid; i < PANGU_WTOK * PANGU_WTOK / 8; i += NT)
+    reinterpret_cast<u32x4*>(Bs)[i] = reinterpret_cast<const u32x4*>(bias_tile)[i];
+
   f32x4 dbias[9];
 #pragma unroll
   for (int j = 0; j < 9; ++j) dbias[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   for (int l = 0; l < g.nLon; ++l) {
     __syncthreads();
-    long lz = 0;
-    asm volatile("" : "+s"(lz));                  // keep the (window-invariant) bias loads inside the loop
-    const u16* bias_l = bias_tile + lz;
+    int lz = 0;
+    asm volatile("" : "+v"(lz));                  // keep the (window-invariant) bias reads inside the loop
+    const u16* bias_l = Bs + lz;
     if (tid < PANGU_WTOK) tok_s[tid] = win_src_token(g, l, t, tid, SHIFTED);
     __syncthreads();
     // ---- stage: one 16-B chunk (8 dims) of q, k, v, dO, O per thread
@@ -229,18 +235,31 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_bf16_kernel(
         *reinterpret_cast<u32x2*>(dst + C + 16) = u32x2{pack2(dk1[0], dk1[1]), pack2(dk1[2], dk1[3])};
         *reinterpret_cast<u32x2*>(dst + 2 * C) = u32x2{pack2(dv0[0], dv0[1]), pack2(dv0[2], dv0[3])};
         *reinterpret_cast<u32x2*>(dst + 2 * C + 16) = u32x2{pack2(dv1[0], dv1[1]), pack2(dv1[2], dv1[3])};
-      } else {
-        float* dst = dqkv_bias + hd * 32 + lg * 4;
+      }
+      // zero-pad keys all carry linear1.bias: their gradients are summed (lanes of a pad key, then LDS, then ONE
+      // global atomic per value at the end) instead of 64 same-address global atomics per pad key and window
+      if (__any(ktok < 0)) {
+        const float keep = ktok < 0 ? 1.f : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          atomicAdd(dst + C + r, dk0[r]);
-          atomicAdd(dst + C + 16 + r, dk1[r]);
-          atomicAdd(dst + 2 * C + r, dv0[r]);
-          atomicAdd(dst + 2 * C + 16 + r, dv1[r]);
+          float a0 = dk0[r] * keep, a1 = dk1[r] * keep, b0 = dv0[r] * keep, b1 = dv1[r] * keep;
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) {
+            a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64);
+            b0 += __shfl_xor(b0, o, 64); b1 += __shfl_xor(b1, o, 64);
+          }
+          if (lq == 0) {
+            atomicAdd(&pad_s[lg * 4 + r], a0);
+            atomicAdd(&pad_s[16 + lg * 4 + r], a1);
+            atomicAdd(&pad_s[32 + lg * 4 + r], b0);
+            atomicAdd(&pad_s[48 + lg * 4 + r], b1);
+          }
         }
       }
     }
   }
+  __syncthreads();
+  if (tid < 64 && pad_s[tid] != 0.f) atomicAdd(dqkv_bias + (tid < 32 ? C : 2 * C) + hd * 32 + (tid & 31), pad_s[tid]);
   float* drow = d_esb + (size_t)pair * PANGU_WTOK * PANGU_WTOK + (size_t)(wave * 16 + lq) * PANGU_WTOK + lg * 4;
 #pragma unroll
   for (int j = 0; j < 9; ++j) *reinterpret_cast<f32x4*>(drow + j * 16) = dbias[j];
@@ -257,7 +276,8 @@ extern "C" int pangu_window_attn_bwd_bf16(pangu_stream_t stream, const void* qkv
   if (heads <= 0 || C != heads * PANGU_HEAD_DIM) return PANGU_E_SHAPE;
   const WinGeom g = make_geom(Z, H, W);
   const int n_pairs = g.types * heads;
-  const size_t shm = 4 * (size_t)ROWIMG + 3 * (size_t)TIMG + 3 * PANGU_WTOK * sizeof(float);
+  const size_t shm = 4 * (size_t)ROWIMG + 3 * (size_t)TIMG + 3 * PANGU_WTOK * sizeof(float) + 64 * sizeof(float) +
+                     (size_t)PANGU_WTOK * PANGU_WTOK * sizeof(u16);
   hipStream_t s = (hipStream_t)stream;
   static bool attr_set = false;
   if (!attr_set) {

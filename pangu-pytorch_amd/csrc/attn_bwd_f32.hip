@@ -31,6 +31,7 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
   __shared__ __attribute__((aligned(16))) float lse_s[PANGU_WTOK];
   __shared__ __attribute__((aligned(16))) float del_s[PANGU_WTOK];
   __shared__ int tok_s[PANGU_WTOK];
+  __shared__ float pad_s[64];            // [2][32]: dK, dV summed over the zero-pad keys of this (type, head)
 
   const int pair = blockIdx.x;
   const int t = pair / heads, hd = pair - t * heads;
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
     return (zcut && zd) || (hcut && hdiff);
   };
 
+  if (tid < 64) pad_s[tid] = 0.f;
   f32x4 dbias[9];
 #pragma unroll
   for (int j = 0; j < 9; ++j) dbias[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -201,6 +203,7 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
         }
       }
       // lane: dK/dV[key = 16*wave + 4lg + r][d = 16dt + lq]
+      bool any_pad = false;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ktok = tok_s[wave * 16 + lg * 4 + r];
@@ -211,15 +214,29 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
           dst[2 * C] = dv0[r];
           dst[2 * C + 16] = dv1[r];
         } else {
-          float* dst = dqkv_bias + hd * 32 + lq;
-          atomicAdd(dst + C, dk0[r]);
-          atomicAdd(dst + C + 16, dk1[r]);
-          atomicAdd(dst + 2 * C, dv0[r]);
-          atomicAdd(dst + 2 * C + 16, dv1[r]);
+          any_pad = true;
+        }
+      }
+      // zero-pad keys all carry linear1.bias: sum their gradients over the keys this lane holds, then over the four
+      // key groups, then in LDS; ONE global atomic per value at the end (instead of 64 per pad key and window)
+      if (__any(any_pad)) {
+        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (tok_s[wave * 16 + lg * 4 + r] < 0) { a0 += dk0[r]; a1 += dk1[r]; b0 += dv0[r]; b1 += dv1[r]; }
+        a0 += __shfl_xor(a0, 16, 64); a1 += __shfl_xor(a1, 16, 64); b0 += __shfl_xor(b0, 16, 64); b1 += __shfl_xor(b1, 16, 64);
+        a0 += __shfl_xor(a0, 32, 64); a1 += __shfl_xor(a1, 32, 64); b0 += __shfl_xor(b0, 32, 64); b1 += __shfl_xor(b1, 32, 64);
+        if (lg == 0) {
+          atomicAdd(&pad_s[lq], a0);
+          atomicAdd(&pad_s[16 + lq], a1);
+          atomicAdd(&pad_s[32 + lq], b0);
+          atomicAdd(&pad_s[48 + lq], b1);
         }
       }
     }
   }
+  __syncthreads();
+  if (tid < 64 && pad_s[tid] != 0.f) atomicAdd(dqkv_bias + (tid < 32 ? C : 2 * C) + hd * 32 + (tid & 31), pad_s[tid]);
   // ---- bias gradient tile: lane holds sum_l dS^T[key = 16j + 4lg + r][query = 16*wave + lq]
   float* drow = d_esb + (size_t)pair * PANGU_WTOK * PANGU_WTOK + (size_t)(wave * 16 + lq) * PANGU_WTOK + lg * 4;
 #pragma unroll
