@@ -1,40 +1,42 @@
 // bf16 weight-gradient GEMM for gfx950:  dW[N,K] (fp32) += dC[M,N]^T @ A[M,K],  db[N] += colsum(dC), bf16 operands.
 //
 // Contraction over the token dimension M: both operands are stored token-major, but v_mfma_f32_16x16x32_bf16 wants 8
-// consecutive contraction indices (tokens) per lane.  The staging loader therefore TRANSPOSES on the fly: a thread
-// loads an 8-token x 8-column block (eight 16-B loads, coalesced across threads along the columns), transposes it in
-// registers with v_perm_b32, and writes eight 16-B chunks "column c, tokens t..t+7" into the same swizzled
-// [row][64] LDS image the forward GEMM uses; fragment reads are then plain conflict-free ds_read_b128.
+// contraction indices (tokens) per lane for one output row/column.  Instead of transposing in registers, the 64-token
+// slabs of dC and A are copied into LDS exactly as they lie in memory ([token][column], straight 16-B chunk copies) and
+// the fragments are fetched with gfx950's transposing LDS read ds_read_b64_tr_b16 (4 tokens x 16 columns per 16-lane
+// group, column-major out): two reads give a lane its 8 tokens {4g..4g+3} and {16+4g..16+4g+3} of one column (the MFMA
+// k index is permuted identically for both operands).  Row strides of 288 / 416 / 160 B (= 32 B mod 256) x this token
+// assignment make every transposing read conflict-free in its 32-lane half.
 // Grid = (128 x 64*TK output tiles) x (M splits); each workgroup adds its tile to dW with fp32 no-return atomics.
 #include "common.h"
 
 namespace {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
 
 constexpr int WB_N = 128;      // output rows (n) per tile
-constexpr int WB_M = 64;       // tokens per K-step
+constexpr int D_LD = 288;      // bytes per token row of the dC slab image (256 payload)
 
-__device__ inline int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
-// 8x8 transpose of 16-bit elements: r[i] = row i (8 elements in 4 dwords) -> c[j] = column j (rows 0..7)
-__device__ inline void transpose8x8(const u32x4 (&r)[8], u32x4 (&c)[8]) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j)
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-      c[j][p] = __builtin_amdgcn_perm(r[2 * p + 1][j >> 1], r[2 * p][j >> 1], (j & 1) ? 0x07060302u : 0x05040100u);
+__device__ inline bf16x8 tr_frag(const unsigned char* img, int ld, int row0, int col0, int lg, int lc) {
+  const unsigned char* p = img + (row0 + 4 * lg + (lc >> 2)) * ld + (col0 + 4 * (lc & 3)) * 2;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 16 * ld));
+  return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
-template <int TK>
+// WB_M = tokens per K-step: 64 (TK <= 2: 74 KB of LDS, two workgroups per CU) or 32 (TK = 3: 45 KB)
+template <int TK, int WB_M>
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const u16* __restrict__ dC, int lddc, const u16* __restrict__ A,
                                                             int lda, float* __restrict__ dW, float* __restrict__ db, int M,
                                                             int N, int K, int n_tiles, int k_tiles, int rows_per_split) {
   constexpr int BKC = 64 * TK;
-  constexpr int STAGE = (WB_N + BKC) * 128;
-  constexpr int NBLK = (WB_N + BKC) / 8 * (WB_M / 8);     // 8x8 blocks per K-step: (16 + 8TK) * 8
-  constexpr int BPT = (NBLK + 255) / 256;                  // blocks per thread
+  constexpr int A_LD = BKC * 2 + (TK == 3 ? 32 : (TK == 2 ? 32 : 32));     // 416 / 288 / 160 bytes
+  constexpr int STAGE = WB_M * (D_LD + A_LD);
+  constexpr int ACH = BKC / 8;                              // 16-B chunks per A row
+  constexpr int NA = WB_M * ACH / 256;                      // A chunks per thread
+  constexpr int ND = WB_M / 16;                             // dC chunks per thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tile = blockIdx.x % (n_tiles * k_tiles), split = blockIdx.x / (n_tiles * k_tiles);
@@ -53,67 +55,48 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const u16* __restric
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<u16*>(A), 0, (int)(((size_t)(M - 1) * lda + K) * sizeof(u16)), 0x00020000);
 
-  // block assignment: block b = tid + 256*i.  b < 128: dC block (token block mb = b>>4, column chunk b&15), i.e.
-  // threads 0..127 at i = 0 (waves 0,1: wave-uniform); every other block is an A block
-  // (b' = b-128: mb = b' / (8TK), column chunk b' % (8TK)).  Descriptor choice is made wave-uniform explicitly.
-  const bool wave_d = __builtin_amdgcn_readfirstlane(tid) < 128;
-  bool live[BPT], col_ok[BPT];
-  int mb[BPT], cc[BPT];
+  // staging: dC slab 64 rows x 16 chunks (4 per thread: row = (tid>>4) + 16 i, chunk tid&15),
+  //          A slab 64 rows x ACH chunks (NA per thread: f = tid + 256 i -> row f / ACH, chunk f % ACH)
+  const int d_row = tid >> 4, d_ch = tid & 15;
+  const bool d_ok = n0 + d_ch * 8 < N;
+  int a_row[NA], a_ch[NA];
+  bool a_ok[NA];
 #pragma unroll
-  for (int i = 0; i < BPT; ++i) {
-    const int b = tid + 256 * i;
-    live[i] = b < NBLK;
-    if (i == 0 && b < 128) { mb[i] = b >> 4; cc[i] = b & 15; col_ok[i] = n0 + cc[i] * 8 < N; }
-    else { const int bb = b - 128; mb[i] = bb / (8 * TK); cc[i] = bb - mb[i] * (8 * TK); col_ok[i] = k0 + cc[i] * 8 < K; }
+  for (int i = 0; i < NA; ++i) {
+    const int f = tid + 256 * i;
+    a_row[i] = f / ACH;
+    a_ch[i] = f - a_row[i] * ACH;
+    a_ok[i] = k0 + a_ch[i] * 8 < K;
   }
-
-  u32x4 blk[BPT][8];
-  float dbacc[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) dbacc[j] = 0.f;
+  u32x4 rd[ND], ra[NA];
+  f32x4 dbacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 
   auto fetch = [&](int m) {
 #pragma unroll
-    for (int i = 0; i < BPT; ++i) {
-      const bool from_d = (i == 0) && wave_d;
+    for (int i = 0; i < ND; ++i) {
+      const unsigned off = d_ok ? ((unsigned)(m + d_row + 16 * i) * (unsigned)lddc + (unsigned)(n0 + d_ch * 8)) * 2u : 0xFFFFFFFFu;
+      rd[i] = __builtin_amdgcn_raw_buffer_load_b128(d_rsrc, (int)off, 0, 0);
+    }
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const unsigned row = (unsigned)(m + mb[i] * 8 + r);
-        if (from_d) {
-          const unsigned off = col_ok[i] ? (row * (unsigned)lddc + (unsigned)(n0 + cc[i] * 8)) * 2u : 0xFFFFFFFFu;
-          blk[i][r] = __builtin_amdgcn_raw_buffer_load_b128(d_rsrc, (int)off, 0, 0);
-        } else {
-          const unsigned off = (col_ok[i] && live[i]) ? (row * (unsigned)lda + (unsigned)(k0 + cc[i] * 8)) * 2u : 0xFFFFFFFFu;
-          blk[i][r] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)off, 0, 0);
-        }
-      }
+    for (int i = 0; i < NA; ++i) {
+      const unsigned off = a_ok[i] ? ((unsigned)(m + a_row[i]) * (unsigned)lda + (unsigned)(k0 + a_ch[i] * 8)) * 2u : 0xFFFFFFFFu;
+      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)off, 0, 0);
     }
   };
   auto stash = [&](int buf) {
-    unsigned char* base = smem + buf * STAGE;
+    unsigned char* Ds = smem + buf * STAGE;
+    unsigned char* As = Ds + WB_M * D_LD;
 #pragma unroll
-    for (int i = 0; i < BPT; ++i) {
-      const bool from_d = (i == 0) && wave_d;
-      u32x4 col[8];
-      transpose8x8(blk[i], col);
-      if (live[i]) {
+    for (int i = 0; i < ND; ++i) {
+      *reinterpret_cast<u32x4*>(Ds + (d_row + 16 * i) * D_LD + d_ch * 16) = rd[i];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          *reinterpret_cast<u32x4*>(base + (from_d ? 0 : WB_N * 128) + swz(cc[i] * 8 + j, mb[i])) = col[j];
-      }
-      if (from_d && db != nullptr) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float sm = 0.f;
-#pragma unroll
-          for (int p = 0; p < 4; ++p) {
-            sm += __builtin_bit_cast(float, col[j][p] << 16);
-            sm += __builtin_bit_cast(float, col[j][p] & 0xFFFF0000u);
-          }
-          dbacc[j] += sm;
-        }
+      for (int c = 0; c < 4; ++c) {      // column sums for the bias gradient: columns 8 d_ch .. 8 d_ch + 7
+        dbacc[0][c] += __builtin_bit_cast(float, (c & 1) ? (rd[i][c >> 1] & 0xFFFF0000u) : (rd[i][c >> 1] << 16));
+        dbacc[1][c] += __builtin_bit_cast(float, (c & 1) ? (rd[i][2 + (c >> 1)] & 0xFFFF0000u) : (rd[i][2 + (c >> 1)] << 16));
       }
     }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<u32x4*>(As + a_row[i] * A_LD + a_ch[i] * 16) = ra[i];
   };
 
   f32x4 acc[4][2 * TK];
@@ -130,14 +113,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const u16* __restric
     const bool more = st + 1 < steps;
     if (more) fetch(m_begin + (st + 1) * WB_M);
     const unsigned char* Ds = smem + (st & 1) * STAGE;
-    const unsigned char* As = Ds + WB_N * 128;
+    const unsigned char* As = Ds + WB_M * D_LD;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < WB_M / 32; ++kk) {
       bf16x8 fd[4], fa[2 * TK];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fd[i] = *reinterpret_cast<const bf16x8*>(Ds + swz(wn * 64 + i * 16 + lc, kk * 4 + lg));
+      for (int i = 0; i < 4; ++i) fd[i] = tr_frag(Ds, D_LD, kk * 32, wn * 64 + i * 16, lg, lc);
 #pragma unroll
-      for (int j = 0; j < 2 * TK; ++j) fa[j] = *reinterpret_cast<const bf16x8*>(As + swz(wk * 32 * TK + j * 16 + lc, kk * 4 + lg));
+      for (int j = 0; j < 2 * TK; ++j) fa[j] = tr_frag(As, A_LD, kk * 32, wk * 32 * TK + j * 16, lg, lc);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -161,17 +144,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const u16* __restric
       }
     }
   if (db != nullptr && k_tile == 0) {
-    float* red = reinterpret_cast<float*>(smem);        // [8 token blocks][128 columns]
+    float* red = reinterpret_cast<float*>(smem);        // [16 row groups][128 columns]
     __syncthreads();
-    if (tid < 128) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) red[(tid >> 4) * WB_N + (tid & 15) * 8 + j] = dbacc[j];
+    for (int c = 0; c < 4; ++c) {
+      // dbacc[0][c] = column 8 d_ch + {0,1,2,3}[c] ... see stash(): element order within the 16-B chunk
+      red[d_row * WB_N + d_ch * 8 + c] = dbacc[0][c];
+      red[d_row * WB_N + d_ch * 8 + 4 + c] = dbacc[1][c];
     }
     __syncthreads();
     if (tid < WB_N) {
       float v = 0.f;
 #pragma unroll
-      for (int gq = 0; gq < 8; ++gq) v += red[gq * WB_N + tid];
+      for (int gq = 0; gq < 16; ++gq) v += red[gq * WB_N + tid];
       if (n0 + tid < N) atomicAdd(&db[n0 + tid], v);
     }
   }
@@ -181,14 +166,16 @@ template <int TK>
 int launch_wgrad_bf16(hipStream_t s, const u16* dC, int lddc, const u16* A, int lda, float* dW, float* db, int M, int N,
                       int K) {
   constexpr int BKC = 64 * TK;
+  constexpr int WB_M = TK == 3 ? 32 : 64;
   const int n_tiles = (N + WB_N - 1) / WB_N, k_tiles = (K + BKC - 1) / BKC;
   const int tiles = n_tiles * k_tiles;
+  // ~2 rounds of the 512 resident workgroups: long token slabs keep the fp32 atomic tail (98 KB per workgroup) small
   int split = (1024 + tiles - 1) / tiles;
-  int rows = ((M + split - 1) / split + WB_M - 1) / WB_M * WB_M;
-  if (rows < 4 * WB_M) rows = 4 * WB_M;
+  int rows = ((M + split - 1) / split + 63) / 64 * 64;
+  if (rows < 256) rows = 256;
   split = (M + rows - 1) / rows;
-  const size_t shm = 2 * (size_t)(WB_N + BKC) * 128;
-  auto kern = wgrad_bf16_kernel<TK>;
+  const size_t shm = 2 * (size_t)WB_M * (D_LD + BKC * 2 + 32);
+  auto kern = wgrad_bf16_kernel<TK, WB_M>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);

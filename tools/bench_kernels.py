@@ -70,6 +70,19 @@ def gemm_bf16(lib_compare):
         print(line)
 
 
+def wgrad(bf16):
+    from pangu_pytorch_amd import ops_bf16 as ob
+    dt = torch.bfloat16 if bf16 else torch.float32
+    for M, N, K, act, name in GEMM_SHAPES:
+        if bf16 and K % 8:
+            continue
+        dc = torch.randn(M, N, device="cuda").to(dt)
+        a = torch.randn(M, K, device="cuda").to(dt)
+        f = (lambda: ob.linear_wgrad(dc, a)) if bf16 else (lambda: ops.linear_wgrad(dc, a))
+        ms = timeit(f)
+        print(f"wgrad {'bf16' if bf16 else 'f32 '} {name:14s} M={M:6d} N={N:4d} K={K:4d}  {ms:7.3f} ms  {2.0 * M * N * K / ms / 1e9:6.1f} TF/s")
+
+
 def attn_bf16():
     from pangu_pytorch_amd import ops_bf16 as ob
     bf = torch.bfloat16
@@ -112,4 +125,5 @@ def rows():
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
     {"gemm": lambda: gemm("--lib-compare" in sys.argv), "attn": attn, "rows": rows,
-     "gemm_bf16": lambda: gemm_bf16("--lib-compare" in sys.argv), "attn_bf16": attn_bf16}[what]()
+     "gemm_bf16": lambda: gemm_bf16("--lib-compare" in sys.argv), "attn_bf16": attn_bf16,
+     "wgrad_bf16": lambda: wgrad(True), "wgrad": lambda: wgrad(False)}[what]()
