@@ -152,6 +152,14 @@ int pangu_patch_recover_scatter(pangu_stream_t stream, const float* y_upper, con
 int pangu_patch_recover_gather_bwd(pangu_stream_t stream, const float* d_output, const float* d_output_surface,
                                    float* dy_upper, float* dy_surface, int LAT, int LON);
 
+/* ---- evaluation ---------------------------------------------------------------------------- */
+
+/* Latitude-weighted sums behind RMSE / ACC (reference era5_data/score.py:92-105,123-135), per plane of pred/target
+ * [planes][H][W]:  out[plane] = { sum w (p-t)^2, sum w p t, sum w p^2, sum w t^2 } with lat_weight w[H].
+ * ACCUMULATES (atomics) into a zero-initialised out[planes][4].  W % 4 == 0. */
+int pangu_lat_weighted_sums(pangu_stream_t stream, const float* pred, const float* target, const float* lat_weight,
+                            float* out, int planes, int H, int W);
+
 /* ---- bf16 variants (BASELINE configs[2], [4]) --------------------------------------------------------------
  * Activations and weight shadows are bf16 (raw uint16 bit patterns); biases, LayerNorm parameters, softmax and all
  * accumulation stay fp32.  Same semantics and layouts as the fp32 entry points above. */

@@ -168,6 +168,29 @@ def build_model(M):
     return model
 
 
+def gen_extras(L, M):
+    """Goldens for the SURVEY 8(f) widenings: device scores (reference era5_data/score.py, imported standalone) and the
+    compact -> expanded bias gather (reference layers.py:384-391 run with the reference's own position_index)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_score", os.path.join(ref_import.REF_ROOT, "era5_data", "score.py"))
+    sc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sc)
+    d = {}
+    pred = synth.uniform((2, 5, 721, 1440), synth.name_seed("score_pred"))
+    tgt = pred * 0.7 + 0.5 * synth.uniform((2, 5, 721, 1440), synth.name_seed("score_tgt"))
+    d["rmse"] = sc.weighted_rmse_torch_channels(pred, tgt)
+    d["acc"] = sc.weighted_acc_torch_channels(pred, tgt)
+    d["rmse_mean"] = sc.weighted_rmse_torch(pred, tgt)
+    d["acc_mean"] = sc.weighted_acc_torch(pred, tgt)
+    att = L.EarthAttention3D(384, 12, 0, (2, 6, 12), device="cpu")
+    compact = synth.uniform((3312, 64, 12), synth.name_seed("compact_bias"), 0.5)
+    eb = compact[att.position_index]                                   # layers.py:384
+    eb = eb.view(144, 144, 64, 12)                                     # :388
+    eb = torch.permute(eb, (2, 3, 0, 1)).unsqueeze(0)                  # :390-391
+    d.update(cases.summarize(eb, "expanded_bias"))
+    save("extras.npz", d)
+
+
 def gen_model_smooth(L, M):
     """Whole-model backward under a SMOOTH loss (sum(out*cot)): gradients without the L1 loss' sign discontinuity,
     so they can be compared tightly."""
@@ -231,5 +254,7 @@ if __name__ == "__main__":
         gen_model(L, M, backward=False)
     if "model_bwd" in what:
         gen_model(L, M, backward=True)
+    if "extras" in what:
+        gen_extras(L, M)
     if "model_bwd_smooth" in what:
         gen_model_smooth(L, M)

@@ -259,3 +259,33 @@ def gather_grad_mean(grads_per_rank):
     """Intended DP semantics of era5_data/utils_dist.py:125-134: all_reduce(SUM) then / world_size."""
     world = len(grads_per_rank)
     return {k: sum(g[k] for g in grads_per_rank) / world for k in grads_per_rank[0]}
+
+
+# ----------------------------------------------------------------------------------------------
+# SURVEY 8(f) widenings: evaluation scores and the compact bias table
+# ----------------------------------------------------------------------------------------------
+def latitude_weights(num_lat):
+    """reference era5_data/score.py:82-88 (torch versions; note the 3.1416 literal)."""
+    j = torch.arange(0, num_lat)
+    lat = 90.0 - j * 180.0 / float(num_lat - 1)
+    c = torch.cos(3.1416 / 180.0 * lat)
+    return num_lat * c / torch.sum(c)
+
+
+def weighted_rmse_channels(pred, target):
+    """reference score.py:92-105."""
+    w = latitude_weights(pred.shape[-2]).view(-1, 1)
+    return torch.sqrt(torch.mean(w * (pred - target) ** 2.0, dim=(-1, -2)))
+
+
+def weighted_acc_channels(pred, target):
+    """reference score.py:123-135."""
+    w = latitude_weights(pred.shape[-2]).view(-1, 1)
+    return torch.sum(w * pred * target, dim=(-1, -2)) / torch.sqrt(
+        torch.sum(w * pred * pred, dim=(-1, -2)) * torch.sum(w * target * target, dim=(-1, -2)))
+
+
+def expand_bias(compact):
+    """(3312, types, heads) -> (1, types, heads, 144, 144), reference layers.py:384-391."""
+    idx = position_index()
+    return compact[idx].view(WTOK, WTOK, compact.shape[1], compact.shape[2]).permute(2, 3, 0, 1).unsqueeze(0)

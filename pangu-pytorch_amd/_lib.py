@@ -29,6 +29,7 @@ SIGNATURES = {
     "pangu_downsample_ln_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I],
     "pangu_upsample_ln_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I],
     "pangu_patch_recover_gather_bwd": [_P, _P, _P, _P, _P, _I, _I],
+    "pangu_lat_weighted_sums": [_P, _P, _P, _P, _P, _I, _I, _I],
     "pangu_linear_fwd_bf16": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I],
     "pangu_window_attn_fwd_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I],
     "pangu_ln_residual_fwd_bf16": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _F],

@@ -286,3 +286,52 @@ extern "C" int pangu_patch_recover_scatter(pangu_stream_t stream, const float* y
                      y_surface, output, output_surface, LAT, LON, H4, W4, chunks);
   return pangu_launch_status();
 }
+
+// ---- latitude-weighted evaluation sums (reference era5_data/score.py:92-105,123-135) ------------------------------
+// For every (sample, channel) plane [H][W]: S0 = sum w (p-t)^2, S1 = sum w p t, S2 = sum w p^2, S3 = sum w t^2, with the
+// per-latitude weight vector w[H] supplied by the caller.  One workgroup per (plane, 8-row slab); fp32 atomics.
+namespace {
+constexpr int SC_ROWS = 8;
+__global__ __launch_bounds__(256) void lat_weighted_sums_kernel(const float* __restrict__ pred,
+                                                                const float* __restrict__ target,
+                                                                const float* __restrict__ w, float* __restrict__ out,
+                                                                int H, int W, int slabs) {
+  __shared__ float red[4][4];
+  const int plane = blockIdx.x / slabs, slab = blockIdx.x - plane * slabs;
+  const size_t base = (size_t)plane * H * W;
+  const int h0 = slab * SC_ROWS, h1 = min(H, h0 + SC_ROWS);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const int w4 = W >> 2;
+  for (int h = h0; h < h1; ++h) {
+    const float wt = w[h];
+    const f32x4* pr = reinterpret_cast<const f32x4*>(pred + base + (size_t)h * W);
+    const f32x4* tr = reinterpret_cast<const f32x4*>(target + base + (size_t)h * W);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int i = threadIdx.x; i < w4; i += 256) {
+      const f32x4 p = pr[i], t = tr[i];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float d = p[c] - t[c];
+        a0 += d * d; a1 += p[c] * t[c]; a2 += p[c] * p[c]; a3 += t[c] * t[c];
+      }
+    }
+    s0 += wt * a0; s1 += wt * a1; s2 += wt * a2; s3 += wt * a3;
+  }
+  s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[wave][0] = s0; red[wave][1] = s1; red[wave][2] = s2; red[wave][3] = s3; }
+  __syncthreads();
+  if (threadIdx.x < 4)
+    atomicAdd(&out[plane * 4 + threadIdx.x], (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+}  // namespace
+
+extern "C" int pangu_lat_weighted_sums(pangu_stream_t stream, const float* pred, const float* target,
+                                       const float* lat_weight, float* out, int planes, int H, int W) {
+  if (!pred || !target || !lat_weight || !out) return PANGU_E_NULL;
+  if (planes <= 0 || H <= 0 || W <= 0 || (W & 3)) return PANGU_E_SHAPE;
+  const int slabs = (H + SC_ROWS - 1) / SC_ROWS;
+  hipLaunchKernelGGL(lat_weighted_sums_kernel, dim3(planes * slabs), dim3(256), 0, (hipStream_t)stream, pred, target,
+                     lat_weight, out, H, W, slabs);
+  return pangu_launch_status();
+}

@@ -1,0 +1,48 @@
+"""SURVEY.md 8(f) widenings on the GPU: device-side latitude-weighted scores and the double-buffered input pipeline."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import pangu_oracle as O
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P():
+    import pangu_pytorch_amd as P
+    P._lib.load()
+    return P
+
+
+def test_scores_match_reference_golden(P, golden_dir):
+    g = np.load(os.path.join(golden_dir, "extras.npz"))
+    pred = synth.uniform((2, 5, 721, 1440), synth.name_seed("score_pred"), device="cuda")
+    tgt = pred * 0.7 + 0.5 * synth.uniform((2, 5, 721, 1440), synth.name_seed("score_tgt"), device="cuda")
+    rm, ac = P.score.weighted_rmse_channels(pred, tgt), P.score.weighted_acc_channels(pred, tgt)
+    assert rm.shape == (2, 5) and np.allclose(rm.cpu().numpy(), g["rmse"], rtol=2e-5)
+    assert np.allclose(ac.cpu().numpy(), g["acc"], rtol=2e-5)
+    assert np.allclose(P.score.weighted_rmse(pred, tgt).cpu().numpy(), g["rmse_mean"], rtol=2e-5)
+    assert np.allclose(P.score.weighted_acc(pred, tgt).cpu().numpy(), g["acc_mean"], rtol=2e-5)
+    # 5-D upper-air fields and ragged shapes against the oracle
+    p5 = synth.uniform((1, 2, 3, 37, 24), 5, device="cuda")
+    t5 = synth.uniform((1, 2, 3, 37, 24), 6, device="cuda")
+    assert torch.allclose(P.score.weighted_rmse_channels(p5, t5).cpu(), O.weighted_rmse_channels(p5.cpu(), t5.cpu()), rtol=2e-5)
+    assert torch.allclose(P.score.weighted_acc_channels(p5, t5).cpu(), O.weighted_acc_channels(p5.cpu(), t5.cpu()), rtol=2e-4, atol=1e-6)
+
+
+def test_device_prefetcher(P):
+    batches = [(torch.full((1, 5, 13, 8, 16), float(i)) + torch.arange(13.0).view(1, 1, 13, 1, 1),
+                torch.full((1, 4, 8, 16), float(i)), torch.full((1, 5, 13, 8, 16), -float(i)), torch.zeros(1, 4, 8, 16), i)
+               for i in range(5)]
+    got = list(P.data.DevicePrefetcher(batches, "cuda", flip_levels=True))
+    assert len(got) == 5
+    for i, (a, b, c, d, tag) in enumerate(got):
+        assert a.is_cuda and tag == i
+        assert torch.equal(a.cpu(), batches[i][0].flip(-3)) and torch.equal(b.cpu(), batches[i][1])
+        assert torch.equal(c.cpu(), batches[i][2].flip(-3))
+    plain = list(P.data.DevicePrefetcher(batches, "cuda"))
+    assert torch.equal(plain[3][0].cpu(), batches[3][0])

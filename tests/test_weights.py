@@ -1,0 +1,68 @@
+"""Weight import + compact bias table and the oracle's score restatement (8(f)-3), CPU side."""
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import pangu_oracle as O
+import synth
+import pangu_pytorch_amd as P
+from pangu_pytorch_amd import weights as Wt
+
+
+def test_position_index_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "index.npz"))
+    mine = Wt.position_index()
+    assert np.array_equal(mine.numpy(), g["position_index"].astype(np.int64))
+    assert torch.equal(mine, O.position_index())
+    assert int(mine.max()) == 3311 and mine.unique().numel() == 3312
+
+
+def test_expand_bias_matches_reference_gather(golden_dir):
+    g = np.load(os.path.join(golden_dir, "extras.npz"))
+    compact = synth.uniform((3312, 64, 12), synth.name_seed("compact_bias"), 0.5)
+    e = Wt.expand_bias(compact)
+    assert e.shape == (1, 64, 12, 144, 144)
+    assert cases.compare_summary(e, g, "expanded_bias", 0) == 0.0             # pure gather: bit-exact
+    assert torch.equal(e, O.expand_bias(compact))
+    back = Wt.compact_bias(e)
+    assert torch.allclose(back, compact, rtol=0, atol=1e-6)                     # exact inverse up to the mean's rounding
+
+
+def test_oracle_scores_match_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "extras.npz"))
+    pred = synth.uniform((2, 5, 721, 1440), synth.name_seed("score_pred"))
+    tgt = pred * 0.7 + 0.5 * synth.uniform((2, 5, 721, 1440), synth.name_seed("score_tgt"))
+    assert np.allclose(O.weighted_rmse_channels(pred, tgt).numpy(), g["rmse"], rtol=1e-5)
+    assert np.allclose(O.weighted_acc_channels(pred, tgt).numpy(), g["acc"], rtol=1e-5)
+
+
+def test_load_checkpoint_formats(tmp_path):
+    blk = P.layers.EarthSpecificBlock(192, 0.0, 6)
+    sd = {k: torch.randn_like(v) for k, v in blk.state_dict().items()}
+    Wt.load_checkpoint(blk, {"model": sd, "epoch": 3})                          # reference finetune_fully.py:115-116
+    assert torch.equal(blk.norm1.weight, sd["norm1.weight"])
+    path = tmp_path / "ckpt.pth"
+    torch.save({"model": {k: v * 2 for k, v in sd.items()}}, path)
+    Wt.load_checkpoint(blk, str(path))
+    assert torch.equal(blk.norm1.weight, sd["norm1.weight"] * 2)
+    with pytest.raises(RuntimeError):
+        Wt.load_checkpoint(blk, {"model": {"norm1.weight": sd["norm1.weight"]}})   # strict
+
+
+def test_load_onnx_initializers_semantics():
+    """2-D MatMul initialisers are stored (in,out) and must be transposed; others copied (reference onnx2torch.py:36-52)."""
+    m = P.layers.DownSample(192)
+    table = {"linear.weight": "onnx::MatMul_1", "norm.weight": "b.norm.weight", "norm.bias": "b.norm.bias"}
+    w_onnx = np.random.RandomState(0).randn(768, 384).astype(np.float32)             # (in, out)
+    ow = {"onnx::MatMul_1": w_onnx, "b.norm.weight": np.full(768, 2.0, np.float32), "b.norm.bias": np.zeros(768, np.float32)}
+    missing = Wt.load_onnx_initializers(m, ow, table, freeze=True)
+    assert missing == []
+    assert torch.equal(m.linear.weight, torch.from_numpy(w_onnx).t()) and not m.linear.weight.requires_grad
+    assert float(m.norm.weight[0]) == 2.0
+    with pytest.raises(ValueError):
+        Wt.load_onnx_initializers(m, {**ow, "onnx::MatMul_1": w_onnx.T.copy()}, table)
+    assert Wt.load_onnx_initializers(m, ow, {"linear.weight": "onnx::MatMul_1"}) == ["norm.weight", "norm.bias"]
