@@ -64,6 +64,12 @@ int pangu_window_mask_export(pangu_stream_t stream, float* out, int Z, int H, in
 int pangu_linear_fwd(pangu_stream_t stream, const float* A, int lda, const float* W, const float* bias,
                      float* C, int ldc, int M, int N, int K, int act, float* aux);
 
+/* OPT-IN fast fp32 projection: same contract as pangu_linear_fwd (fp32 in / out / accumulate), products evaluated on
+ * the bf16 matrix pipe as hi*hi + hi*lo + lo*hi of on-the-fly bf16 splits (3/16 of the exact path's matrix cycles,
+ * ~1e-5 instead of ~1e-7 relative error per dot product).  K % 8 == 0.  Never the default. */
+int pangu_linear_fwd_f32x3(pangu_stream_t stream, const float* A, int lda, const float* W, const float* bias,
+                           float* C, int ldc, int M, int N, int K, int act, float* aux);
+
 /* Weight/bias gradient of a projection (autograd of the calls above; the training step of reference
  * models/pangu_sample.py:71 `loss.backward()`):
  *   dW[N,K] += dC[M,N]^T @ A[M,K]      db[N] += sum_m dC[m,:]   (db may be NULL)

@@ -8,6 +8,27 @@ from . import _lib
 
 ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
 
+# fp32 projection arithmetic: False = exact f32 MFMA (default, the parity-tested headline path); True = opt-in
+# split-bf16 ("bf16x3") products on the bf16 matrix pipe (see csrc/gemm_f32x3.hip).
+_F32_SPLIT = False
+
+
+class f32_split:
+    """Context manager / switch: `with ops.f32_split(True): ...` routes fp32 projections through the bf16x3 kernel."""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _F32_SPLIT
+        self.prev, _F32_SPLIT = _F32_SPLIT, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global _F32_SPLIT
+        _F32_SPLIT = self.prev
+
+
 # Optional live kernel timing (bench.py): HIP events recorded on the launch stream around each launch.
 _timing = None
 
@@ -97,9 +118,11 @@ def linear(a, weight, bias=None, act=ACT_NONE, out=None, aux=None):
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     op, ldc = _rows(out, "linear.out")
-    with _timed("linear", 2.0 * M * N * K):
-        _lib.check(lib.pangu_linear_fwd(_stream(), ap, lda, wp, bp, op, ldc, M, N, K, act,
-                                        _chk(aux, "linear.aux") if aux is not None else None), "linear_fwd")
+    split = _F32_SPLIT and K % 8 == 0
+    fn = lib.pangu_linear_fwd_f32x3 if split else lib.pangu_linear_fwd
+    with _timed("linear_x3" if split else "linear", 2.0 * M * N * K):
+        _lib.check(fn(_stream(), ap, lda, wp, bp, op, ldc, M, N, K, act,
+                      _chk(aux, "linear.aux") if aux is not None else None), "linear_fwd")
     return out
 
 

@@ -41,9 +41,10 @@ class PanguModel(nn.Module):
         self.register_buffer("_c_maps", None, persistent=False)
         self.register_buffer("_c_const_h", None, persistent=False)
         self.compute_dtype = torch.float32
+        self.f32_split = False
         self._shadow = None
 
-    def set_compute_dtype(self, dtype):
+    def set_compute_dtype(self, dtype, f32_split=False):
         """torch.float32 (default; parity <= 1e-3 with the reference) or torch.bfloat16 (inference: bf16 activations and
         weight shadows, fp32 LayerNorm/softmax/accumulation).  bf16 is also selected by an enclosing
         `torch.autocast("cuda", dtype=torch.bfloat16)` — the switch the reference leaves commented out at
@@ -51,6 +52,9 @@ class PanguModel(nn.Module):
         if dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
         self.compute_dtype = dtype
+        # f32_split (fp32 only, opt-in): projections evaluate their fp32 products as split-bf16 triples on the bf16
+        # matrix pipe (csrc/gemm_f32x3.hip): ~5x fewer matrix cycles, ~1e-5 instead of ~1e-7 relative error
+        self.f32_split = bool(f32_split) and dtype == torch.float32
         return self
 
     def _init_weights(self, m):                                                # reference pangu_model.py:41-48
@@ -92,6 +96,11 @@ class PanguModel(nn.Module):
             if grad_path:
                 return autograd_bf16.forward_train(self, input, input_surface, statistics, maps, const_h)
             return fused_bf16.forward(self, input, input_surface, statistics, maps, const_h)
+        from . import ops
+        with ops.f32_split(self.f32_split):
+            return self._forward_f32(input, input_surface, statistics, maps, const_h, grad_path)
+
+    def _forward_f32(self, input, input_surface, statistics, maps, const_h, grad_path):
         B = input.shape[0]
         x = self._input_layer(input, input_surface, statistics, maps, const_h)             # (B,521280,192)
         N, C = x.shape[1], x.shape[2]

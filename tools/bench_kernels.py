@@ -44,6 +44,10 @@ def gemm(lib_compare):
         out = torch.empty(M, N, device="cuda")
         ms = timeit(lambda: ops.linear(a, w, b, act=act, out=out))
         line = f"{name:14s} M={M:6d} N={N:4d} K={K:4d}  {ms:7.3f} ms  {2.0 * M * N * K / ms / 1e9:6.1f} TF/s"
+        if K % 8 == 0:
+            with ops.f32_split(True):
+                ms3 = timeit(lambda: ops.linear(a, w, b, act=act, out=out))
+            line += f"   | x3 {ms3:7.3f} ms {2.0 * M * N * K / ms3 / 1e9:6.1f} TF/s {(M * K + M * N) * 4.0 / ms3 / 1e6:7.1f} GB/s"
         if lib_compare:
             f = (lambda: torch.nn.functional.gelu(torch.addmm(b, a, w.t()))) if act else (lambda: torch.addmm(b, a, w.t()))
             ms2 = timeit(f)
