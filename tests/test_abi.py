@@ -32,8 +32,10 @@ def test_argument_validation_without_gpu():
     if not os.path.exists(_lib.LIB_PATH):
         pytest.skip("libpangu_hip.so not built")
     lib = _lib.load()
-    assert lib.pangu_linear_fwd(None, None, 0, None, None, None, 0, 1, 1, 16, 0) == -2          # NULL
-    assert lib.pangu_linear_fwd(None, 8, 8, 8, None, 8, 8, 4, 8, 8, 0) == -1                      # K % 16
+    assert lib.pangu_linear_fwd(None, None, 0, None, None, None, 0, 1, 1, 16, 0, None) == -2    # NULL
+    assert lib.pangu_linear_fwd(None, 8, 16, 8, None, 8, 8, 4, 8, 8, 0, None) == -1              # K % 16
+    assert lib.pangu_linear_fwd_bf16(None, 8, 16, 8, None, 8, 8, 4, 8, 12, 0, None, 1) == -1     # K % 8
+    assert lib.pangu_linear_fwd_bf16(None, 8, 16, 8, None, 8, 8, 4, 8, 16, 0, None, 7) == -3     # dtype tag
     assert lib.pangu_window_attn_fwd(None, 8, 8, 8, 8, None, 8, 181, 25, 192, 6, 0) == -1         # W % 12
     assert lib.pangu_window_attn_fwd(None, 8, 8, 8, 8, None, 8, 181, 24, 192, 5, 0) == -1         # C != 32*heads
     assert lib.pangu_error_string(-1) == b"unsupported shape"
