@@ -3,7 +3,9 @@
 // One workgroup (3 waves) per (longitude window l, window type t, head): 144 tokens x 32 dims.
 // Roll / pad / partition / reverse / crop are address arithmetic (win_src_token); the shift mask is closed
 // form; nothing of size (..,144,144) ever reaches HBM.
-//   K, V of the window are staged in LDS ([144][36] floats, padded rows: conflict-free reads).
+//   K, V of the window are staged in LDS as [144][32] floats with the 16-B chunk index XOR-swizzled by a function of
+//   the key (conflict-free for the b128 row reads AND the b32 column reads): 37.4 KB per workgroup, so FOUR
+//   workgroups = 12 waves = 3 per SIMD share a CU (the padded [144][36] image allowed only 9 waves: 3/2/2/2).
 //   Each wave owns 3 query tiles of 16 rows.  Per tile it computes the TRANSPOSED scores
 //     S^T[key][query] = K . (scale*Q)^T      with v_mfma_f32_16x16x4_f32 (9 key tiles x 8 k-steps),
 //   so a query's 144 scores live in 16 lanes-groups' registers: softmax = in-lane reduce + 2 shuffles,
@@ -16,7 +18,13 @@
 
 namespace {
 
-constexpr int KV_LD = 36;
+constexpr int KV_LD = 32;
+
+// float offset of element (key, d): chunk (d>>2) XOR f(key), f = key bits {1,3,2} -> chunk bits {0,1,2}
+__device__ inline int kvoff(int key, int d) {
+  const int f = ((key >> 1) & 1) | (((key >> 3) & 1) << 1) | (((key >> 2) & 1) << 2);
+  return key * KV_LD + ((((d >> 2) ^ f) << 2) | (d & 3));
+}
 
 template <bool SHIFTED>
 __global__ __launch_bounds__(192, 3) void window_attn_f32_kernel(const float* __restrict__ qkv,
@@ -50,8 +58,8 @@ __global__ __launch_bounds__(192, 3) void window_attn_f32_kernel(const float* __
     const float* src = tok >= 0 ? qkv + (size_t)tok * C3 : qkv_bias;
     const f32x4 kv = *reinterpret_cast<const f32x4*>(src + C + hd * 32 + c4);
     const f32x4 vv = *reinterpret_cast<const f32x4*>(src + 2 * C + hd * 32 + c4);
-    *reinterpret_cast<f32x4*>(&Ks[n * KV_LD + c4]) = kv;
-    *reinterpret_cast<f32x4*>(&Vs[n * KV_LD + c4]) = vv;
+    *reinterpret_cast<f32x4*>(&Ks[kvoff(n, c4)]) = kv;
+    *reinterpret_cast<f32x4*>(&Vs[kvoff(n, c4)]) = vv;
   }
   __syncthreads();
 
@@ -87,12 +95,13 @@ __global__ __launch_bounds__(192, 3) void window_attn_f32_kernel(const float* __
     asm volatile("" : "+v"(lz));
     const float* Ksq = Ks + lz;
     const float* Vsq = Vs + lz;
-    // Q fragment: 8 dims d = 8*lg .. 8*lg+7 of query qn, pre-scaled
+    // Q fragment: lane group lg owns dims {4lg..4lg+3} and {16+4lg..16+4lg+3} (the MFMA k index is permuted the same
+    // way for K: chunk pairs (lg, lg^1) inside every ds_read_b128 lane group keep the swizzled reads conflict-free)
     f32x4 q0, q1;
     {
-      const float* src = (qtok >= 0 ? qkv + (size_t)qtok * C3 : qkv_bias) + hd * 32 + lg * 8;
+      const float* src = (qtok >= 0 ? qkv + (size_t)qtok * C3 : qkv_bias) + hd * 32 + lg * 4;
       q0 = *reinterpret_cast<const f32x4*>(src);
-      q1 = *reinterpret_cast<const f32x4*>(src + 4);
+      q1 = *reinterpret_cast<const f32x4*>(src + 16);
       q0 *= scale; q1 *= scale;
     }
     // ---- S^T = bias^T + K (scale Q)^T : 9 key tiles; the bias tile is the accumulator's initial value.
@@ -107,8 +116,8 @@ __global__ __launch_bounds__(192, 3) void window_attn_f32_kernel(const float* __
       f32x4 k0[3], k1[3];
 #pragma unroll
       for (int jj = 0; jj < 3; ++jj) {
-        k0[jj] = *reinterpret_cast<const f32x4*>(&Ksq[((j0 + jj) * 16 + lq) * KV_LD + lg * 8]);
-        k1[jj] = *reinterpret_cast<const f32x4*>(&Ksq[((j0 + jj) * 16 + lq) * KV_LD + lg * 8 + 4]);
+        k0[jj] = *reinterpret_cast<const f32x4*>(&Ksq[kvoff((j0 + jj) * 16 + lq, lg * 4)]);
+        k1[jj] = *reinterpret_cast<const f32x4*>(&Ksq[kvoff((j0 + jj) * 16 + lq, 16 + lg * 4)]);
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
@@ -162,8 +171,8 @@ __global__ __launch_bounds__(192, 3) void window_attn_f32_kernel(const float* __
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = j * 16 + lg * 4 + r;
-        const float v0 = Vsq[key * KV_LD + lq];
-        const float v1 = Vsq[key * KV_LD + 16 + lq];
+        const float v0 = Vsq[kvoff(key, lq)];
+        const float v1 = Vsq[kvoff(key, 16 + lq)];
         o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, s[j][r], o0, 0, 0, 0);
         o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, s[j][r], o1, 0, 0, 0);
       }
