@@ -179,10 +179,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const u16* __restr
       unsigned char* slot = ep + (i * 16 + lc) * EP_LD + (j * 16 + lg * 4) * 2;
       if (ACT == PANGU_ACT_GELU_BWD) {
         const u32x2 xp = *reinterpret_cast<const u32x2*>(slot);
-        v[0] *= gelu_erf_grad(__builtin_bit_cast(float, xp[0] << 16));
-        v[1] *= gelu_erf_grad(__builtin_bit_cast(float, xp[0] & 0xFFFF0000u));
-        v[2] *= gelu_erf_grad(__builtin_bit_cast(float, xp[1] << 16));
-        v[3] *= gelu_erf_grad(__builtin_bit_cast(float, xp[1] & 0xFFFF0000u));
+        v[0] *= gelu_erf_grad_lp(__builtin_bit_cast(float, xp[0] << 16));
+        v[1] *= gelu_erf_grad_lp(__builtin_bit_cast(float, xp[0] & 0xFFFF0000u));
+        v[2] *= gelu_erf_grad_lp(__builtin_bit_cast(float, xp[1] << 16));
+        v[3] *= gelu_erf_grad_lp(__builtin_bit_cast(float, xp[1] & 0xFFFF0000u));
       }
       if (ACT == PANGU_ACT_GELU) {
         if (aux) {                                          // pre-activation out (rounded to bf16, as it will be re-read)
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const u16* __restr
           __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])}, x_rsrc, (int)xo, 0, 0);
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = gelu_erf(v[c]);
+        for (int c = 0; c < 4; ++c) v[c] = gelu_erf_lp(v[c]);
       }
       *reinterpret_cast<u32x2*>(slot) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
     }

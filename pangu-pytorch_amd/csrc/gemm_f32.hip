@@ -97,22 +97,31 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_tn_f32_kernel(c
     }
     const float* As = smem[kt & 1];
     const float* Ws = As + BM * LDS_LD;
-    // fragments in two halves (k-steps 0-3, then 4-7): 20 live fragment registers instead of 40
+    // fragments in two halves (k-steps 0-3, then 4-7); the second half is fetched before the first half's MFMAs issue,
+    // so only one LDS round trip per K-step is exposed to this wave
+    f32x4 fa0[2], fw0[TN], fa1[2], fw1[TN];
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      f32x4 fa[2], fw[TN];
+    for (int i = 0; i < 2; ++i) fa0[i] = *reinterpret_cast<const f32x4*>(&As[rd_a + i * 32 * LDS_LD]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f32x4*>(&As[rd_a + i * 32 * LDS_LD + 4 * hf]);
+    for (int j = 0; j < TN; ++j) fw0[j] = *reinterpret_cast<const f32x4*>(&Ws[rd_w + j * 32 * LDS_LD]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fw[j] = *reinterpret_cast<const f32x4*>(&Ws[rd_w + j * 32 * LDS_LD + 4 * hf]);
+    for (int i = 0; i < 2; ++i) fa1[i] = *reinterpret_cast<const f32x4*>(&As[rd_a + i * 32 * LDS_LD + 4]);
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+    for (int j = 0; j < TN; ++j) fw1[j] = *reinterpret_cast<const f32x4*>(&Ws[rd_w + j * 32 * LDS_LD + 4]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fw[j][s], acc[i][j], 0, 0, 0);
-    }
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i][s], fw0[j][s], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[i][s], fw1[j][s], acc[i][j], 0, 0, 0);
     if (more) {
       float* An = smem[(kt + 1) & 1];
       float* Wn = An + BM * LDS_LD;

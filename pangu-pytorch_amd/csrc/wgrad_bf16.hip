@@ -9,6 +9,7 @@
 // assignment make every transposing read conflict-free in its 32-lane half.
 // Grid = (128 x 64*TK output tiles) x (M splits); each workgroup adds its tile to dW with fp32 no-return atomics.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -170,7 +171,8 @@ int launch_wgrad_bf16(hipStream_t s, const u16* dC, int lddc, const u16* A, int 
   const int n_tiles = (N + WB_N - 1) / WB_N, k_tiles = (K + BKC - 1) / BKC;
   const int tiles = n_tiles * k_tiles;
   // ~2 rounds of the 512 resident workgroups: long token slabs keep the fp32 atomic tail (98 KB per workgroup) small
-  int split = (1024 + tiles - 1) / tiles;
+  static const int target = getenv("PANGU_WGRAD_WGS") ? atoi(getenv("PANGU_WGRAD_WGS")) : 768;   // tuning knob
+  int split = (target + tiles - 1) / tiles;
   int rows = ((M + split - 1) / split + 63) / 64 * 64;
   if (rows < 256) rows = 256;
   split = (M + rows - 1) / rows;

@@ -9,6 +9,7 @@
 // columns (conflict-free), lane half h supplying token 2s+h of k-step s.
 // All loads go through range-checked buffer descriptors (rows >= M read as 0, no divergent branches).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -155,7 +156,8 @@ int launch_wgrad(hipStream_t s, const float* dC, int lddc, const float* A, int l
   const int n_tiles = (N + WG_BN - 1) / WG_BN, k_tiles = (K + BKC - 1) / BKC;
   const int tiles = n_tiles * k_tiles;
   // ~3 workgroups per CU slot-pair: enough M-splits to fill 256 CUs x 2, slabs a multiple of the K-step
-  int split = (1536 + tiles - 1) / tiles;
+  static const int target = getenv("PANGU_WGRAD_WGS") ? atoi(getenv("PANGU_WGRAD_WGS")) : 1536;   // tuning knob
+  int split = (target + tiles - 1) / tiles;
   int rows = ((M + split - 1) / split + WG_BM - 1) / WG_BM * WG_BM;
   if (rows < 8 * WG_BM) rows = 8 * WG_BM;
   split = (M + rows - 1) / rows;
