@@ -230,3 +230,17 @@ def test_full_model_forward_golden(P, golden_dir):
     with torch.no_grad():
         out2, _ = m(inp, inp_s)
     assert torch.equal(out, out2)
+
+
+def test_batch_of_two_equals_two_singles(P):
+    """The reference is B=1 only (layers.py:219,227); the drop-in is batch-generic: B=2 == two B=1 calls, bit for bit."""
+    m = _model(P)
+    inp, inp_s, stats, maps, const_h = cases.model_inputs("cuda")
+    inp2 = torch.cat((inp, synth.uniform(inp.shape, 4242, device="cuda")), 0)
+    inp_s2 = torch.cat((inp_s, synth.uniform(inp_s.shape, 4243, device="cuda")), 0)
+    with torch.no_grad():
+        o2, os2 = m(inp2, inp_s2, stats, maps, const_h)
+        oa, osa = m(inp2[:1], inp_s2[:1], stats, maps, const_h)
+        ob, osb = m(inp2[1:], inp_s2[1:], stats, maps, const_h)
+    assert o2.shape == (2, 5, 13, 721, 1440)
+    assert torch.equal(o2[0], oa[0]) and torch.equal(o2[1], ob[0]) and torch.equal(os2[1], osb[0])
