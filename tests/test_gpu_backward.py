@@ -214,3 +214,39 @@ def test_full_backward_smooth_golden(P, golden_dir):
         worst_mass = max(worst_mass, (k, mass), key=lambda t: t[1])
     assert worst[1] < REL, worst
     assert worst_mass[1] < REL, worst_mass
+
+
+@pytest.mark.parametrize("s1,s2", [(0.0, 1.25), (1.25, 0.0), (1.25, 1.25)])
+def test_block_droppath_branches(P, s1, s2):
+    """Training-mode stochastic depth (timm DropPath, reference layers.py:140,250-251): a kept branch is scaled by
+    1/(1-p), a dropped branch contributes nothing (and is not computed); forward and every gradient vs torch autograd
+    over the oracle with the same per-branch factors."""
+    C, roll, W = 192, True, 12
+    st = cases.STAGES[C]
+    blk = P.layers.EarthSpecificBlock(C, 0.2, st["heads"], device="cuda").cuda().train()
+    pre = cases.block_prefix(C, roll)
+    blk.load_state_dict({k: synth.synth_param(pre + k, s, "cuda") for k, s in cases.block_param_shapes(C).items()})
+    seq = iter([s1, s2])
+    blk.drop_path.sample_scale = lambda training: next(seq)
+    x = cases.block_input(C, W, "cuda").requires_grad_(True)
+    y = blk(x, st["Z"], st["H"], W, roll)
+    cot = cases.cotangent("dp", y.shape, "cuda")
+    (y * cot).sum().backward()
+    # oracle with explicit branch factors
+    p = {k: v.requires_grad_(True) for k, v in cases.block_params(C, roll).items()}
+    g = lambda k: p[pre + k]
+    xr = x.detach().cpu().requires_grad_(True)
+    a = O.window_attention(xr, g("attention.linear1.weight"), g("attention.linear1.bias"), g("attention.linear2.weight"),
+                           g("attention.linear2.bias"), g("attention.earth_specific_bias"), st["Z"], st["H"], W,
+                           st["heads"], roll)
+    x1 = xr + s1 * torch.nn.functional.layer_norm(a, (C,), g("norm1.weight"), g("norm1.bias"))
+    m = O.mlp(x1, g("linear.linear1.weight"), g("linear.linear1.bias"), g("linear.linear2.weight"), g("linear.linear2.bias"))
+    ref = x1 + s2 * torch.nn.functional.layer_norm(m, (C,), g("norm2.weight"), g("norm2.bias"))
+    (ref * cot.cpu()).sum().backward()
+    assert rel_err(y, ref) < TIGHT and rel_err(x.grad, xr.grad) < TIGHT
+    for k, q in blk.named_parameters():
+        want = p[pre + k].grad
+        if want is None or float(want.abs().max()) == 0.0:
+            assert q.grad is None or float(q.grad.abs().max()) == 0.0, k
+        else:
+            assert rel_err(q.grad, want) < TIGHT, k
