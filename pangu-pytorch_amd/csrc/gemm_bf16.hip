@@ -11,6 +11,7 @@
 //   ds_read_b128 lane groups (each group holds 16 distinct rows with chunks c / c^1) and for the staging writes.
 //   Staging: global_load_dwordx4 -> registers -> ds_write_b128 one K-step ahead (double-buffered LDS).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -29,91 +30,11 @@ __device__ inline unsigned pack2(float a, float b) { return (unsigned)f2bf(a) | 
 __device__ inline int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }   // byte offset
 
 template <int TN, int ACT, bool HAS_BIAS, bool OUT_F32>
-__global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const u16* __restrict__ A, int lda,
-                                                              const u16* __restrict__ W, const float* __restrict__ bias,
-                                                              void* __restrict__ Cv, int ldc, int M, int N, int K,
-                                                              int m_tiles, int n_tiles, u16* __restrict__ aux) {
-  constexpr int BN = 64 * TN;
-  constexpr int STAGE = (BBM + BN) * 128;                 // bytes per LDS stage
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-  const int b = blockIdx.x;
-  const int xcd = b & 7, local = b >> 3;
-  const int m_tile = (local / n_tiles) * 8 + xcd;
-  const int n_tile = local % n_tiles;
-  if (m_tile >= m_tiles) return;
-  const int m0 = m_tile * BBM, n0 = n_tile * BN;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ void bf16_epilogue(f32x4 (&acc)[4][2 * TN], unsigned char* smem, const float* __restrict__ bias,
+                                              void* __restrict__ Cv, int ldc, int M, int N, u16* __restrict__ aux, int m0,
+                                              int n0, int wave, int lane) {
   const int wm = wave >> 1, wn = wave & 1;
   const int lc = lane & 15, lg = lane >> 4;
-
-  // staging: (BBM + BN) rows x 8 chunks of 16 B; chunk id f = tid + 256*i -> row f>>3, chunk f&7
-  constexpr int NCH = (BBM + BN) * 8 / 256;               // 4 + 2*TN chunks per thread
-  const u16* src[NCH];
-  int dst[NCH];
-  const int kchunk = tid & 7;
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int row = (tid >> 3) + 32 * i;                   // 0 .. BBM+BN-1
-    if (row < BBM) {
-      int r = m0 + row;
-      r = r < M ? r : M - 1;
-      src[i] = A + (size_t)r * lda + kchunk * 8;
-    } else {
-      int r = n0 + row - BBM;
-      r = r < N ? r : N - 1;
-      src[i] = W + (size_t)r * K + kchunk * 8;
-    }
-    dst[i] = (row < BBM ? swz(row, kchunk) : BBM * 128 + swz(row - BBM, kchunk));
-  }
-  const int KT = (K + BBK - 1) / BBK;
-  u32x4 stg[NCH];
-  auto fetch = [&](int kt) {
-    const bool in = kt * BBK + kchunk * 8 < K;             // K % 8 == 0: a chunk is entirely inside or outside
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      stg[i] = in ? *reinterpret_cast<const u32x4*>(src[i] + (size_t)kt * BBK) : u32x4{0u, 0u, 0u, 0u};
-    }
-  };
-  auto stash = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) *reinterpret_cast<u32x4*>(smem + buf * STAGE + dst[i]) = stg[i];
-  };
-
-  f32x4 acc[4][2 * TN];                                    // [m tile 16][n tile 16], lane: 4 consecutive n of row m=lc
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2 * TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  fetch(0);
-  stash(0);
-  __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
-    const bool more = kt + 1 < KT;
-    if (more) fetch(kt + 1);
-    const unsigned char* As = smem + (kt & 1) * STAGE;
-    const unsigned char* Ws = As + BBM * 128;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 fa[4], fw[2 * TN];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        fa[i] = *reinterpret_cast<const bf16x8*>(As + swz(wm * 64 + i * 16 + lc, kk * 4 + lg));
-#pragma unroll
-      for (int j = 0; j < 2 * TN; ++j)
-        fw[j] = *reinterpret_cast<const bf16x8*>(Ws + swz(wn * 32 * TN + j * 16 + lc, kk * 4 + lg));
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2 * TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);   // D[n][m]
-    }
-    if (more) stash((kt + 1) & 1);
-    __syncthreads();
-  }
-
   // ---- epilogue.  lane (lg, lc) of tile (i, j) holds C[m = wm*64 + 16i + lc][n = wn*32TN + 16j + 4lg + r], r = 0..3
   const int wave_n0 = n0 + wn * 32 * TN;
   const int wave_m0 = m0 + wm * 64;
@@ -209,16 +130,220 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const u16* __restr
   }
 }
 
+template <int TN, int ACT, bool HAS_BIAS, bool OUT_F32>
+__global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const u16* __restrict__ A, int lda,
+                                                              const u16* __restrict__ W, const float* __restrict__ bias,
+                                                              void* __restrict__ Cv, int ldc, int M, int N, int K,
+                                                              int m_tiles, int n_tiles, u16* __restrict__ aux) {
+  constexpr int BN = 64 * TN;
+  constexpr int STAGE = (BBM + BN) * 128;                 // bytes per LDS stage
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int b = blockIdx.x;
+  const int xcd = b & 7, local = b >> 3;
+  const int m_tile = (local / n_tiles) * 8 + xcd;
+  const int n_tile = local % n_tiles;
+  if (m_tile >= m_tiles) return;
+  const int m0 = m_tile * BBM, n0 = n_tile * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lc = lane & 15, lg = lane >> 4;
+
+  // staging: (BBM + BN) rows x 8 chunks of 16 B; chunk id f = tid + 256*i -> row f>>3, chunk f&7
+  constexpr int NCH = (BBM + BN) * 8 / 256;               // 4 + 2*TN chunks per thread
+  const u16* src[NCH];
+  int dst[NCH];
+  const int kchunk = tid & 7;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int row = (tid >> 3) + 32 * i;                   // 0 .. BBM+BN-1
+    if (row < BBM) {
+      int r = m0 + row;
+      r = r < M ? r : M - 1;
+      src[i] = A + (size_t)r * lda + kchunk * 8;
+    } else {
+      int r = n0 + row - BBM;
+      r = r < N ? r : N - 1;
+      src[i] = W + (size_t)r * K + kchunk * 8;
+    }
+    dst[i] = (row < BBM ? swz(row, kchunk) : BBM * 128 + swz(row - BBM, kchunk));
+  }
+  const int KT = (K + BBK - 1) / BBK;
+  u32x4 stg[NCH];
+  auto fetch = [&](int kt) {
+    const bool in = kt * BBK + kchunk * 8 < K;             // K % 8 == 0: a chunk is entirely inside or outside
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      stg[i] = in ? *reinterpret_cast<const u32x4*>(src[i] + (size_t)kt * BBK) : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) *reinterpret_cast<u32x4*>(smem + buf * STAGE + dst[i]) = stg[i];
+  };
+
+  f32x4 acc[4][2 * TN];                                    // [m tile 16][n tile 16], lane: 4 consecutive n of row m=lc
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2 * TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const bool more = kt + 1 < KT;
+    if (more) fetch(kt + 1);
+    const unsigned char* As = smem + (kt & 1) * STAGE;
+    const unsigned char* Ws = As + BBM * 128;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[4], fw[2 * TN];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        fa[i] = *reinterpret_cast<const bf16x8*>(As + swz(wm * 64 + i * 16 + lc, kk * 4 + lg));
+#pragma unroll
+      for (int j = 0; j < 2 * TN; ++j)
+        fw[j] = *reinterpret_cast<const bf16x8*>(Ws + swz(wn * 32 * TN + j * 16 + lc, kk * 4 + lg));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2 * TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);   // D[n][m]
+    }
+    if (more) stash((kt + 1) & 1);
+    __syncthreads();
+  }
+  bf16_epilogue<TN, ACT, HAS_BIAS, OUT_F32>(acc, smem, bias, Cv, ldc, M, N, aux, m0, n0, wave, lane);
+}
+
+// ---- direct-to-LDS variant -------------------------------------------------------------------------------------------
+// Same tile and fragment scheme, but the operands travel HBM/L2 -> LDS with buffer_load_dwordx4 ... lds (no staging VGPRs,
+// no ds_write pass), BK = 32 and a FOUR-stage LDS ring (4 x 20 KB, still two workgroups per CU): loads run three K-steps
+// ahead of the MFMAs behind counted s_waitcnt vmcnt(N) and ONE raw s_barrier per step.  An LDS-DMA wave-instruction
+// writes 1 KB linearly (16 rows x 64 B), so the bank swizzle is applied on the SOURCE side: the lane that fills
+// physical chunk p of row r fetches logical chunk p ^ F(r).  Rows >= M / >= N fall outside the descriptor's range
+// and arrive as zeros.
+constexpr int GBK = 32;
+constexpr int GST = 4;
+
+__device__ inline int kswz64(int row, int chunk) {      // 64-byte rows, 4 chunks: F = {0,2,3,1}[(row>>2)&3]
+  const int f = (0x78 >> (((row >> 2) & 3) * 2)) & 3;
+  return row * 64 + ((chunk ^ f) << 4);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int TN, int ACT, bool HAS_BIAS, bool OUT_F32>
+__global__ __launch_bounds__(256, 2) void gemm_tn_bf16_glds_kernel(const u16* __restrict__ A, int lda,
+                                                                   const u16* __restrict__ W, const float* __restrict__ bias,
+                                                                   void* __restrict__ Cv, int ldc, int M, int N, int K,
+                                                                   int m_tiles, int n_tiles, u16* __restrict__ aux) {
+  constexpr int BN = 64 * TN;
+  constexpr int ROWS = BBM + BN;
+  constexpr int STAGE = ROWS * 64;                        // bytes per ring slot
+  constexpr int LPS = ROWS / 64;                          // LDS-DMA instructions per wave and stage (16 rows each)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int b = blockIdx.x;
+  const int xcd = b & 7, local = b >> 3;
+  const int m_tile = (local / n_tiles) * 8 + xcd;
+  const int n_tile = local % n_tiles;
+  if (m_tile >= m_tiles) return;
+  const int m0 = m_tile * BBM, n0 = n_tile * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lc = lane & 15, lg = lane >> 4;
+
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<u16*>(A), 0, (int)(((size_t)(M - 1) * lda + K) * sizeof(u16)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<u16*>(W), 0, (int)((size_t)N * K * sizeof(u16)), 0x00020000);
+  // instruction q = i*4 + wave (i < LPS) fills rows 16q .. 16q+15; this lane fills (row 16q + lane>>2, chunk lane&3)
+  unsigned voff[LPS];
+#pragma unroll
+  for (int i = 0; i < LPS; ++i) {
+    const int row = 16 * (i * 4 + wave) + (lane >> 2);
+    const int f = (0x78 >> (((row >> 2) & 3) * 2)) & 3;
+    const int c = (lane & 3) ^ f;                           // logical chunk this physical slot must receive
+    voff[i] = row < BBM ? ((unsigned)(m0 + row) * (unsigned)lda + c * 8) * 2u
+                        : ((unsigned)(n0 + row - BBM) * (unsigned)K + c * 8) * 2u;
+  }
+  auto issue = [&](int kt) {
+    unsigned char* base = smem + (kt % GST) * STAGE;
+#pragma unroll
+    for (int i = 0; i < LPS; ++i) {
+      const int q = i * 4 + wave;
+      auto dst = (__attribute__((address_space(3))) void*)(base + q * 1024);
+      if (16 * q < BBM) __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, dst, 16, (int)voff[i], kt * GBK * 2, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, dst, 16, (int)voff[i], kt * GBK * 2, 0, 0);
+    }
+  };
+
+  f32x4 acc[4][2 * TN];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2 * TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int KT = K / GBK;
+#pragma unroll
+  for (int s0 = 0; s0 < GST - 1; ++s0)
+    if (s0 < KT) issue(s0);
+  for (int kt = 0; kt < KT; ++kt) {
+    const int rem = KT - 1 - kt;                           // newer steps already in flight: min(rem, 2)
+    if (rem >= 2) wait_vmcnt<2 * LPS>();
+    else if (rem == 1) wait_vmcnt<LPS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                          // step kt landed for every wave; slot (kt-1)%4 is free
+    asm volatile("" ::: "memory");
+    if (kt + GST - 1 < KT) issue(kt + GST - 1);
+    const unsigned char* As = smem + (kt % GST) * STAGE;
+    const unsigned char* Ws = As + BBM * 64;
+    bf16x8 fa[4], fw[2 * TN];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(As + kswz64(wm * 64 + i * 16 + lc, lg));
+#pragma unroll
+    for (int j = 0; j < 2 * TN; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(Ws + kswz64(wn * 32 * TN + j * 16 + lc, lg));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2 * TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+  }
+  __syncthreads();                                         // every wave is done with the ring before the epilogue reuses it
+  bf16_epilogue<TN, ACT, HAS_BIAS, OUT_F32>(acc, smem, bias, Cv, ldc, M, N, aux, m0, n0, wave, lane);
+}
+
 template <int TN, bool OUT_F32>
 int launch_bf16(hipStream_t s, const u16* A, int lda, const u16* W, const float* bias, void* C, int ldc, int M, int N,
                 int K, int act, u16* aux) {
   constexpr int BN = 64 * TN;
   const int m_tiles = (M + BBM - 1) / BBM, n_tiles = (N + BN - 1) / BN;
   const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
-  const size_t shm = 2 * (size_t)(BBM + BN) * 128;
+  // Two staging pipelines, A/B-measured on MI355X at this model's shapes (tools/bench_kernels.py gemm_bf16): the
+  // register-staged double buffer and the 4-stage LDS-DMA ring run within 2 % of each other on every shape (the tile's
+  // MFMA-per-barrier ratio, not the load path, bounds both), so the simpler register-staged kernel is the default and
+  // PANGU_BF16_GLDS=1 selects the ring.
+  static const bool allow_glds = getenv("PANGU_BF16_GLDS") && atoi(getenv("PANGU_BF16_GLDS")) == 1;
+  const bool glds = allow_glds && (K % GBK == 0);
+  const size_t shm = glds ? (size_t)GST * (BBM + BN) * 64 : 2 * (size_t)(BBM + BN) * 128;
   dim3 g(grid), blk(256);
 #define PANGU_BGEMM(ACT, HB)                                                                                          \
   do {                                                                                                                \
+    if (glds) {                                                                                                       \
+      auto kern = gemm_tn_bf16_glds_kernel<TN, ACT, HB, OUT_F32>;                                                     \
+      static bool attr_set_g = false;                                                                                 \
+      if (!attr_set_g) {                                                                                              \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+        attr_set_g = true;                                                                                            \
+      }                                                                                                               \
+      hipLaunchKernelGGL(kern, g, blk, shm, s, A, lda, W, bias, C, ldc, M, N, K, m_tiles, n_tiles, aux);              \
+      break;                                                                                                          \
+    }                                                                                                                 \
     auto kern = gemm_tn_bf16_kernel<TN, ACT, HB, OUT_F32>;                                                            \
     static bool attr_set = false; /* once per instantiation, outside any later graph capture */                       \
     if (!attr_set) {                                                                                                  \
