@@ -366,6 +366,9 @@ int launch_bf16(hipStream_t s, const u16* A, int lda, const u16* W, const float*
 
 }  // namespace
 
+int pangu_linear_ws_bf16(hipStream_t s, const void* A, int lda, const void* W, const float* bias, void* C, int ldc, int M,
+                         int N, int K, int act, void* aux, int out_f32);      // gemm_ws_bf16.hip
+
 extern "C" int pangu_linear_fwd_bf16(pangu_stream_t stream, const void* A, int lda, const void* W, const float* bias,
                                      void* C, int ldc, int M, int N, int K, int act, void* aux, int out_dtype) {
   if (!A || !W || !C) return PANGU_E_NULL;
@@ -375,6 +378,12 @@ extern "C" int pangu_linear_fwd_bf16(pangu_stream_t stream, const void* A, int l
   if (out_dtype != PANGU_BF16 && out_dtype != PANGU_F32) return PANGU_E_DTYPE;
   if (out_dtype == PANGU_BF16 && (ldc & 7)) return PANGU_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
+  // K <= 384: weights-stationary barrier-free kernel (PANGU_BF16_WS=0 disables it: A/B knob)
+  static const bool allow_ws = !(getenv("PANGU_BF16_WS") && atoi(getenv("PANGU_BF16_WS")) == 0);
+  if (allow_ws && M >= 4096) {
+    const int rc = pangu_linear_ws_bf16(s, A, lda, W, bias, C, ldc, M, N, K, act, aux, out_dtype == PANGU_F32);
+    if (rc != PANGU_E_SHAPE) return rc;
+  }
   const u16* a = (const u16*)A;
   const u16* w = (const u16*)W;
   u16* x = (u16*)aux;
