@@ -19,9 +19,8 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "oracle")):
-    if p not in sys.path:
-        sys.path.insert(0, p)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
@@ -32,6 +31,7 @@ PEAK_HBM_GBS = 8000.0
 
 def cpu_baseline():
     """Time the CPU oracle on a 1/5-longitude slice of each stage and extrapolate to one forward step."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))      # the ONLY place bench.py touches oracle/: the CPU baseline leg
     import cases
     import pangu_oracle as O
     # pick the thread count torch's CPU backend runs this workload fastest with on this host (the reference's
@@ -74,6 +74,16 @@ def cpu_baseline():
     }
 
 
+def synthetic_inputs(dev, seed):
+    """One synthetic ERA5-shaped sample, resident in HBM: upper-air (1,5,13,721,1440), surface (1,4,721,1440), O(1)
+    values, non-trivial normalisation statistics, the three constant maps and const_h (reference pangu_model.py:60-66)."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    u = lambda shape, scale=1.0, shift=0.0: (torch.rand(shape, generator=g, device=dev) * 2 - 1) * scale + shift
+    inp, inp_s = u((1, 5, 13, 721, 1440)), u((1, 4, 721, 1440))
+    stats = (u((4,), 0.3), u((4,), 0.2, 1.2), u((13, 1, 1, 5), 0.3), u((13, 1, 1, 5), 0.2, 1.2))
+    return inp, inp_s, stats, u((1, 3, 724, 1440)), u((1, 1, 1, 13, 721, 1440))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,17 +113,13 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    import cases
-    import synth
     import pangu_pytorch_amd as P
     from pangu_pytorch_amd import ops
 
     dev = torch.device("cuda", local_rank)
     torch.manual_seed(0)
     model = P.PanguModel(device=dev).to(dev).eval()          # random-init weights of the real architecture
-    inp, inp_s, stats, maps, const_h = cases.model_inputs(dev)
-    if rank:
-        inp = synth.uniform(inp.shape, 1000 + rank, device=dev)      # a different sample per rank
+    inp, inp_s, stats, maps, const_h = synthetic_inputs(dev, seed=1000 + rank)   # a different sample per rank
 
     def step():
         with torch.no_grad():
@@ -195,7 +201,7 @@ def main():
         from pangu_pytorch_amd.dist import FlatGradSync
         del out
         model.train()
-        tgt, tgt_s = cases.model_targets(dev)
+        tgt, tgt_s, *_ = synthetic_inputs(dev, seed=2000 + rank)      # synthetic targets of the input's shape
         opt = torch.optim.Adam(model.parameters(), lr=5e-6, weight_decay=3e-6)      # reference finetune_fully.py:121
         sync = FlatGradSync(model) if world > 1 else None
         batch = (inp, inp_s, tgt, tgt_s)

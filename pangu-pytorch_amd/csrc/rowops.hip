@@ -2,6 +2,7 @@
 // gather + LayerNorm, patch-embed gather, patch-recover scatter.  One wave per token row, float4 lanes,
 // wave-shuffle reductions; all permute/pad/crop steps of the reference are address arithmetic.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -217,8 +218,9 @@ __global__ __launch_bounds__(256) void patch_recover_scatter_kernel(const float*
 }
 
 int row_grid(int rows) {
+  static const int cap = getenv("PANGU_ROW_BLOCKS") ? atoi(getenv("PANGU_ROW_BLOCKS")) : 8192;
   int blocks = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-  return blocks < 8192 ? blocks : 8192;
+  return blocks < cap ? blocks : cap;
 }
 
 }  // namespace

@@ -1,6 +1,7 @@
 // bf16-I/O variants of the HBM-bound row kernels (fp32 statistics and arithmetic, bf16 loads/stores as 8-byte
 // quads per lane): post-norm residual, down/up-sample gather + LayerNorm, patch-embed gather.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -65,6 +66,76 @@ __global__ __launch_bounds__(256) void ln_residual_bf16_kernel(const u16* __rest
         const f32x4 sc = ld4(shortcut + (size_t)row * lds + 4 * (lane + 64 * i));
         st4(out + (size_t)row * ldo + 4 * (lane + 64 * i), sc + branch_scale * v[i]);
       }
+  }
+}
+
+// Fast path of the post-norm residual for C % 8 == 0, C <= 512 (the model's 192 / 384): 16-B loads (8 channels per
+// lane), LPR lanes per row (32 -> two rows per wave at C <= 256), gamma/beta held in registers, the branch AND the
+// shortcut requested together before any arithmetic, two row groups in flight per wave.
+template <int LPR>
+__global__ __launch_bounds__(256) void ln_residual_bf16_v8_kernel(const u16* __restrict__ y, const u16* __restrict__ shortcut,
+                                                                  int lds, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, u16* __restrict__ out,
+                                                                  int ldo, int N, int C, float branch_scale) {
+  constexpr int RPW = 64 / LPR, UNR = 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, l = lane % LPR;
+  const bool act = l * 8 < C;
+  float gm[8], bt[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    gm[c] = act ? gamma[l * 8 + c] : 0.f;
+    bt[c] = act ? beta[l * 8 + c] : 0.f;
+  }
+  const float inv_c = 1.0f / C;
+  const int rows_per_block = 4 * RPW * UNR;
+  for (int base = blockIdx.x * rows_per_block + wave * RPW * UNR; base < N; base += gridDim.x * rows_per_block) {
+    u32x4 yv[UNR], sv[UNR];
+    bool ok[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int row = base + u * RPW + sub;
+      ok[u] = act && row < N;
+      yv[u] = u32x4{0u, 0u, 0u, 0u};
+      sv[u] = u32x4{0u, 0u, 0u, 0u};
+      if (ok[u]) {
+        yv[u] = *reinterpret_cast<const u32x4*>(y + (size_t)row * C + l * 8);
+        sv[u] = *reinterpret_cast<const u32x4*>(shortcut + (size_t)row * lds + l * 8);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      float v[8];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        v[2 * c] = __builtin_bit_cast(float, yv[u][c] << 16);
+        v[2 * c + 1] = __builtin_bit_cast(float, yv[u][c] & 0xFFFF0000u);
+      }
+      float s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      const float mean = s * inv_c;
+      float q = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { const float d = v[c] - mean; q += d * d; }
+      if (!act) q = 0.f;                       // idle lanes hold zeros, not (0 - mean)^2
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+      const float rstd = rsqrtf(q * inv_c + LN_EPS);
+      if (ok[u]) {
+        u32x4 o4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float s0 = __builtin_bit_cast(float, sv[u][c] << 16);
+          const float s1 = __builtin_bit_cast(float, sv[u][c] & 0xFFFF0000u);
+          const float r0 = s0 + branch_scale * ((v[2 * c] - mean) * rstd * gm[2 * c] + bt[2 * c]);
+          const float r1 = s1 + branch_scale * ((v[2 * c + 1] - mean) * rstd * gm[2 * c + 1] + bt[2 * c + 1]);
+          o4[c] = (unsigned)f2bf(r0) | ((unsigned)f2bf(r1) << 16);
+        }
+        const int row = base + u * RPW + sub;
+        *reinterpret_cast<u32x4*>(out + (size_t)row * ldo + l * 8) = o4;
+      }
+    }
   }
 }
 
@@ -175,8 +246,9 @@ __global__ __launch_bounds__(256) void patch_embed_gather_bf16_kernel(
 }
 
 int row_grid(int rows) {
+  static const int cap = getenv("PANGU_ROW_BLOCKS") ? atoi(getenv("PANGU_ROW_BLOCKS")) : 8192;
   int blocks = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-  return blocks < 8192 ? blocks : 8192;
+  return blocks < cap ? blocks : cap;
 }
 
 }  // namespace
@@ -195,6 +267,19 @@ extern "C" int pangu_ln_residual_fwd_bf16(pangu_stream_t stream, const void* y, 
   if (N <= 0 || C <= 0 || (C & 3) || C > 1024 || lds < C || ldo < C || (lds & 3) || (ldo & 3)) return PANGU_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   dim3 g(row_grid(N)), b(256);
+  if ((C & 7) == 0 && C <= 512 && (lds & 7) == 0 && (ldo & 7) == 0) {
+    static const int cap = getenv("PANGU_LN_BLOCKS") ? atoi(getenv("PANGU_LN_BLOCKS")) : 2048;   // 8 workgroups per CU, grid-stride: workgroup launch rate limits smaller blocks
+    if (C <= 256) {
+      const int blocks = (N + 15) / 16;
+      hipLaunchKernelGGL(ln_residual_bf16_v8_kernel<32>, dim3(blocks < cap ? blocks : cap), b, 0, s, (const u16*)y,
+                         (const u16*)shortcut, lds, gamma, beta, (u16*)out, ldo, N, C, branch_scale);
+    } else {
+      const int blocks = (N + 7) / 8;
+      hipLaunchKernelGGL(ln_residual_bf16_v8_kernel<64>, dim3(blocks < cap ? blocks : cap), b, 0, s, (const u16*)y,
+                         (const u16*)shortcut, lds, gamma, beta, (u16*)out, ldo, N, C, branch_scale);
+    }
+    return pangu_launch_status();
+  }
   PANGU_NVB(C, ln_residual_bf16_kernel, (const u16*)y, (const u16*)shortcut, lds, gamma, beta, (u16*)out, ldo, N, C, branch_scale);
   return pangu_launch_status();
 }

@@ -1,7 +1,7 @@
 // fp32 weight-gradient GEMM for gfx950:  dW[N,K] += dC[M,N]^T @ A[M,K],  db[N] += colsum(dC).
 //
 // The contraction runs over the token dimension M (65k..521k) while the output is small (<= 1536 x 384), so the
-// grid is (output tiles) x (M splits): each 256-thread workgroup owns one 128(n) x 64*TK(k) output tile and a
+// grid is (output tiles) x (M splits): each 256-thread workgroup owns one 64*TNN(n) x 64*TK(k) output tile and a
 // contiguous slab of tokens, accumulates it with v_mfma_f32_32x32x2_f32 and adds the tile to dW with no-return
 // fp32 atomics (each wave-instruction adds two 128-B row segments: the full-rate atomic shape).
 // Both operands are read exactly as they lie in memory (token-major rows): a 16-token slab of dC and of A is
@@ -13,19 +13,24 @@
 
 namespace {
 
-constexpr int WG_BN = 128;   // output rows (n) per tile
 constexpr int WG_BM = 16;    // tokens per K-step
 
-template <int TK>
+// TNN x TK = 32x32 accumulators per wave (2x2 waves): <2,*> for N % 128 == 0, <3,*> for N % 192 == 0 (N = 192 would
+// leave every second 128-row tile half empty)
+template <int TNN, int TK>
 __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const float* __restrict__ dC, int lddc,
                                                            const float* __restrict__ A, int lda,
                                                            float* __restrict__ dW, float* __restrict__ db, int M, int N,
                                                            int K, int n_tiles, int k_tiles, int rows_per_split) {
+  constexpr int WG_BN = 64 * TNN;                    // output rows (n) per tile
   constexpr int BKC = 64 * TK;                       // output columns (k) per tile
   constexpr int D_LD = WG_BN + 4, A_LD = BKC + 4;    // +4 keeps rows 16-B aligned and staggers the two lane halves
   __shared__ __attribute__((aligned(16))) float smem[2][WG_BM * (D_LD + A_LD)];
 
-  const int tile = blockIdx.x % (n_tiles * k_tiles), split = blockIdx.x / (n_tiles * k_tiles);
+  // XCD-aware order (blocks b, b+8, b+16.. share an XCD and its L2): the output tiles of ONE token slab run
+  // back to back on one XCD, so each dC / A slab is fetched from HBM once and re-read from that L2.
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int tile = local % (n_tiles * k_tiles), split = (local / (n_tiles * k_tiles)) * 8 + xcd;
   const int n_tile = tile / k_tiles, k_tile = tile - n_tile * k_tiles;
   const int n0 = n_tile * WG_BN, k0 = k_tile * BKC;
   const int m_begin = split * rows_per_split;
@@ -41,9 +46,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const float* __restri
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(A), 0, (int)(((size_t)(M - 1) * lda + K) * sizeof(float)), 0x00020000);
 
-  // staging assignment.  dC slab: 16 x 128 floats = 512 float4 (2 per thread); A slab: 16 x BKC = 256*TK float4.
-  const int d_row = tid >> 5, d_c4 = tid & 31;                // + 8 rows for the second float4
-  const bool d_ok = n0 + d_c4 * 4 < N;
+  // staging assignment.  dC slab: 16 x WG_BN floats = 256*TNN float4; A slab: 16 x BKC = 256*TK float4.
+  const int d_per_row = 16 * TNN;
+  int d_row[TNN], d_c4[TNN];
+  bool d_ok[TNN];
+#pragma unroll
+  for (int i = 0; i < TNN; ++i) {
+    const int f = tid + 256 * i;
+    d_row[i] = f / d_per_row;
+    d_c4[i] = f - d_row[i] * d_per_row;
+    d_ok[i] = n0 + d_c4[i] * 4 < N;
+  }
   const int a_per_row = 16 * TK;
   int a_row[TK], a_c4[TK];
   bool a_ok[TK];
@@ -56,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const float* __restri
   }
 
   auto load_d = [&](int m, int i) -> f32x4 {
-    const unsigned off = d_ok ? ((unsigned)(m + d_row + 8 * i) * (unsigned)lddc + (unsigned)(n0 + d_c4 * 4)) * 4u : 0xFFFFFFFFu;
+    const unsigned off = d_ok[i] ? ((unsigned)(m + d_row[i]) * (unsigned)lddc + (unsigned)(n0 + d_c4[i] * 4)) * 4u : 0xFFFFFFFFu;
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d_rsrc, (int)off, 0, 0));
   };
   auto load_a = [&](int m, int i) -> f32x4 {
@@ -64,22 +77,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const float* __restri
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)off, 0, 0));
   };
 
-  f32x16 acc[2][TK];
+  f32x16 acc[TNN][TK];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TNN; ++i)
 #pragma unroll
     for (int j = 0; j < TK; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 dbacc[TNN];
+#pragma unroll
+  for (int i = 0; i < TNN; ++i) dbacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // rows >= m_end inside the last slab belong to the next split: mask them through the row bound
-  f32x4 rd[2], ra[TK];
+  f32x4 rd[TNN], ra[TK];
   auto fetch = [&](int m) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TNN; ++i) {
       rd[i] = load_d(m, i);
-      if (m + d_row + 8 * i >= m_end) rd[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (m + d_row[i] >= m_end) rd[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int i = 0; i < TK; ++i) ra[i] = load_a(m, i);
@@ -88,9 +103,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const float* __restri
     float* Ds = smem[buf];
     float* As = Ds + WG_BM * D_LD;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<f32x4*>(&Ds[(d_row + 8 * i) * D_LD + d_c4 * 4]) = rd[i];
-      dbacc += rd[i];
+    for (int i = 0; i < TNN; ++i) {
+      *reinterpret_cast<f32x4*>(&Ds[d_row[i] * D_LD + d_c4[i] * 4]) = rd[i];
+      dbacc[i] += rd[i];
     }
 #pragma unroll
     for (int i = 0; i < TK; ++i) *reinterpret_cast<f32x4*>(&As[a_row[i] * A_LD + a_c4[i] * 4]) = ra[i];
@@ -107,13 +122,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const float* __restri
     const float* As = Ds + WG_BM * D_LD;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      float fd[2], fa[TK];
+      float fd[TNN], fa[TK];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fd[i] = Ds[(2 * s + lh) * D_LD + wn * 64 + i * 32 + lr];
+      for (int i = 0; i < TNN; ++i) fd[i] = Ds[(2 * s + lh) * D_LD + wn * 32 * TNN + i * 32 + lr];
 #pragma unroll
       for (int j = 0; j < TK; ++j) fa[j] = As[(2 * s + lh) * A_LD + wk * 32 * TK + j * 32 + lr];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TNN; ++i)
 #pragma unroll
         for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fd[i], fa[j], acc[i][j], 0, 0, 0);
     }
@@ -126,42 +141,41 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const float* __restri
   for (int j = 0; j < TK; ++j) {
     const int kc = k0 + wk * 32 * TK + j * 32 + lr;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TNN; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int n = n0 + wn * 32 * TNN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (n < N && kc < K) atomicAdd(&dW[(size_t)n * K + kc], acc[i][j][r]);
       }
   }
   // bias gradient: column sums of the dC slab, from the staging registers (k-tile 0 only)
   if (db != nullptr && k_tile == 0) {
-    float* red = &smem[0][0];               // [8 row groups][128 columns]
+    float* red = &smem[0][0];               // [WG_BN columns], LDS atomics
+    __syncthreads();
+    if (tid < WG_BN) red[tid] = 0.f;
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < 4; ++c) red[d_row * WG_BN + d_c4 * 4 + c] = dbacc[c];
-    __syncthreads();
-    if (tid < WG_BN) {
-      float v = 0.f;
+    for (int i = 0; i < TNN; ++i)
 #pragma unroll
-      for (int g = 0; g < 8; ++g) v += red[g * WG_BN + tid];
-      if (n0 + tid < N) atomicAdd(&db[n0 + tid], v);
-    }
+      for (int c = 0; c < 4; ++c) atomicAdd(&red[d_c4[i] * 4 + c], dbacc[i][c]);
+    __syncthreads();
+    if (tid < WG_BN && n0 + tid < N) atomicAdd(&db[n0 + tid], red[tid]);
   }
 }
 
-template <int TK>
+template <int TNN, int TK>
 int launch_wgrad(hipStream_t s, const float* dC, int lddc, const float* A, int lda, float* dW, float* db, int M, int N,
                  int K) {
-  constexpr int BKC = 64 * TK;
+  constexpr int WG_BN = 64 * TNN, BKC = 64 * TK;
   const int n_tiles = (N + WG_BN - 1) / WG_BN, k_tiles = (K + BKC - 1) / BKC;
   const int tiles = n_tiles * k_tiles;
   // ~3 workgroups per CU slot-pair: enough M-splits to fill 256 CUs x 2, slabs a multiple of the K-step
   static const int target = getenv("PANGU_WGRAD_WGS") ? atoi(getenv("PANGU_WGRAD_WGS")) : 1536;   // tuning knob
-  int split = (target + tiles - 1) / tiles;
+  int split = ((target + tiles - 1) / tiles + 7) & ~7;              // equal share per XCD
   int rows = ((M + split - 1) / split + WG_BM - 1) / WG_BM * WG_BM;
   if (rows < 8 * WG_BM) rows = 8 * WG_BM;
-  split = (M + rows - 1) / rows;
-  hipLaunchKernelGGL((wgrad_f32_kernel<TK>), dim3(tiles * split), dim3(256), 0, s, dC, lddc, A, lda, dW, db, M, N, K,
+  split = ((M + rows - 1) / rows + 7) & ~7;                         // grid padded to whole XCD rounds (empty slabs exit)
+  hipLaunchKernelGGL((wgrad_f32_kernel<TNN, TK>), dim3(tiles * split), dim3(256), 0, s, dC, lddc, A, lda, dW, db, M, N, K,
                      n_tiles, k_tiles, rows);
   return pangu_launch_status();
 }
@@ -174,7 +188,16 @@ extern "C" int pangu_linear_wgrad(pangu_stream_t stream, const float* dC, int ld
   if (M <= 0 || N <= 0 || K <= 0 || (N & 3) || (K & 3) || lddc < N || lda < K || (lddc & 3) || (lda & 3))
     return PANGU_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
-  if (K % 192 == 0) return launch_wgrad<3>(s, dC, lddc, A, lda, dW, db, M, N, K);
-  if (K % 128 == 0) return launch_wgrad<2>(s, dC, lddc, A, lda, dW, db, M, N, K);
-  return launch_wgrad<1>(s, dC, lddc, A, lda, dW, db, M, N, K);
+  static const int force_tnn = getenv("PANGU_WGRAD_TNN") ? atoi(getenv("PANGU_WGRAD_TNN")) : 0;   // tuning knob
+  // measured (tools/bench_kernels.py wgrad): 192-row tiles win where 128-row tiles would be part empty (N = 192, 576, 160)
+  // and at N = 1152 (12 instead of 18 tiles per slab); 128-row tiles win at N = 384, 768, 1536
+  const bool wide = force_tnn ? force_tnn == 3 : (N % 192 == 0 && N % 384 != 0) || (N > 128 && N < 192) || N == 1152;
+  if (wide) {
+    if (K % 192 == 0) return launch_wgrad<3, 3>(s, dC, lddc, A, lda, dW, db, M, N, K);
+    if (K % 128 == 0) return launch_wgrad<3, 2>(s, dC, lddc, A, lda, dW, db, M, N, K);
+    return launch_wgrad<3, 1>(s, dC, lddc, A, lda, dW, db, M, N, K);
+  }
+  if (K % 192 == 0) return launch_wgrad<2, 3>(s, dC, lddc, A, lda, dW, db, M, N, K);
+  if (K % 128 == 0) return launch_wgrad<2, 2>(s, dC, lddc, A, lda, dW, db, M, N, K);
+  return launch_wgrad<2, 1>(s, dC, lddc, A, lda, dW, db, M, N, K);
 }

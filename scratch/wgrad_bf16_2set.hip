@@ -72,22 +72,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const u16* __restric
     a_ch[i] = f - a_row[i] * ACH;
     a_ok[i] = k0 + a_ch[i] * 8 < K;
   }
-  u32x4 rd[ND], ra[NA];
+  // Two register staging sets: the slab for step st+2 is requested while the slab for st+1 is still in flight, so a
+  // workgroup keeps two slabs (2 x 20 KB at TK = 3) outstanding -- at ~3 us loaded HBM latency one slab per workgroup
+  // caps the chip at ~3 TB/s.  Fetches are unconditional (slabs past m_end get the out-of-range offset: no traffic),
+  // which lets the compiler wait with a counted vmcnt for the older set only.
+  u32x4 rd0[ND], ra0[NA], rd1[ND], ra1[NA];
   f32x4 dbacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 
-  auto fetch = [&](int m) {
+  auto fetch = [&](int m, u32x4* rd, u32x4* ra) {
+    const bool live = m < m_end;
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
-      const unsigned off = d_ok ? ((unsigned)(m + d_row + 16 * i) * (unsigned)lddc + (unsigned)(n0 + d_ch * 8)) * 2u : 0xFFFFFFFFu;
+      const unsigned off = (d_ok & live) ? ((unsigned)(m + d_row + 16 * i) * (unsigned)lddc + (unsigned)(n0 + d_ch * 8)) * 2u : 0xFFFFFFFFu;
       rd[i] = __builtin_amdgcn_raw_buffer_load_b128(d_rsrc, (int)off, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const unsigned off = a_ok[i] ? ((unsigned)(m + a_row[i]) * (unsigned)lda + (unsigned)(k0 + a_ch[i] * 8)) * 2u : 0xFFFFFFFFu;
+      const unsigned off = (a_ok[i] & live) ? ((unsigned)(m + a_row[i]) * (unsigned)lda + (unsigned)(k0 + a_ch[i] * 8)) * 2u : 0xFFFFFFFFu;
       ra[i] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)off, 0, 0);
     }
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](int buf, const u32x4* rd, const u32x4* ra) {
     unsigned char* Ds = smem + buf * STAGE;
     unsigned char* As = Ds + WB_M * D_LD;
 #pragma unroll
@@ -109,14 +114,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const u16* __restric
 #pragma unroll
     for (int j = 0; j < 2 * TK; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  fetch(m_begin);
-  stash(0);
-  __syncthreads();
-  const int steps = (m_end - m_begin + WB_M - 1) / WB_M;
-  for (int st = 0; st < steps; ++st) {
-    const bool more = st + 1 < steps;
-    if (more) fetch(m_begin + (st + 1) * WB_M);
-    const unsigned char* Ds = smem + (st & 1) * STAGE;
+  auto compute = [&](int buf) {
+    const unsigned char* Ds = smem + buf * STAGE;
     const unsigned char* As = Ds + WB_M * D_LD;
 #pragma unroll
     for (int kk = 0; kk < WB_M / 32; ++kk) {
@@ -131,7 +130,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const u16* __restric
         for (int j = 0; j < 2 * TK; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd[i], fa[j], acc[i][j], 0, 0, 0);     // D[n][k]
     }
-    if (more) stash((st + 1) & 1);
+  };
+
+  fetch(m_begin, rd0, ra0);
+  fetch(m_begin + WB_M, rd1, ra1);
+  stash(0, rd0, ra0);
+  __syncthreads();
+  const int steps = (m_end - m_begin + WB_M - 1) / WB_M;
+  for (int st = 0; st < steps; st += 2) {
+    // even step: LDS buffer 0 holds slab st, set 1 holds slab st+1 (in flight), set 0 is free
+    fetch(m_begin + (st + 2) * WB_M, rd0, ra0);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(0);
+    __builtin_amdgcn_sched_barrier(0);
+    stash(1, rd1, ra1);
+    __syncthreads();
+    if (st + 1 >= steps) break;
+    // odd step: buffer 1 holds slab st+1, set 0 holds slab st+2, set 1 is free
+    fetch(m_begin + (st + 3) * WB_M, rd1, ra1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(1);
+    __builtin_amdgcn_sched_barrier(0);
+    stash(0, rd0, ra0);
     __syncthreads();
   }
 

@@ -9,7 +9,6 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import torch  # noqa: E402
 import pangu_pytorch_amd as P  # noqa: E402
 from pangu_pytorch_amd import ops  # noqa: E402
@@ -124,6 +123,11 @@ def rows():
         out = torch.empty_like(y)
         ms = timeit(lambda: ops.ln_residual(y, s, g, b, out=out))
         print(f"ln_residual N={N} C={C}: {ms:7.3f} ms  {3.0 * N * C * 4 / ms / 1e6:7.1f} GB/s")
+        from pangu_pytorch_amd import ops_bf16 as ob
+        yb, sb = y.bfloat16(), s.bfloat16()
+        ob_out = torch.empty_like(yb)
+        ms = timeit(lambda: ob.ln_residual(yb, sb, g, b, out=ob_out))
+        print(f"ln_residual bf16 N={N} C={C}: {ms:7.3f} ms  {3.0 * N * C * 2 / ms / 1e6:7.1f} GB/s")
 
 
 if __name__ == "__main__":
