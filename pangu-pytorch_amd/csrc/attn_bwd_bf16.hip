@@ -59,7 +59,14 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_bf16_kernel(
   float* pad_s = reinterpret_cast<float*>(tok_s + PANGU_WTOK);     // [2][32]: dK, dV summed over the zero-pad keys
   u16* Bs = reinterpret_cast<u16*>(pad_s + 64);                    // [144][144] bf16 bias tile (window-invariant)
 
-  const int pair = blockIdx.x;
+  // the two heads sharing each token's 128-B line (a bf16 head slice is 64 B) run side by side on ONE XCD (blocks b and
+  // b+8 share an L2) and walk the longitude windows together: the second head's reads / writes hit that L2
+  int pair = blockIdx.x;
+  if (!(heads & 1)) {
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    pair = 2 * ((local >> 1) * 8 + xcd) + (local & 1);
+  }
+  if (pair >= g.types * heads) return;
   const int t = pair / heads, hd = pair - t * heads;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 15, lg = lane >> 4;
@@ -275,7 +282,7 @@ extern "C" int pangu_window_attn_bwd_bf16(pangu_stream_t stream, const void* qkv
   if (Z <= 0 || H <= 0 || W <= 0 || Z % PANGU_WZ || (H + PANGU_PAD_H) % PANGU_WH || W % PANGU_WW) return PANGU_E_SHAPE;
   if (heads <= 0 || C != heads * PANGU_HEAD_DIM) return PANGU_E_SHAPE;
   const WinGeom g = make_geom(Z, H, W);
-  const int n_pairs = g.types * heads;
+  const int n_pairs = (heads & 1) ? g.types * heads : ((g.types * heads / 2 + 7) / 8) * 16;    // padded to whole XCD rounds
   const size_t shm = 4 * (size_t)ROWIMG + 3 * (size_t)TIMG + 3 * PANGU_WTOK * sizeof(float) + 64 * sizeof(float) +
                      (size_t)PANGU_WTOK * PANGU_WTOK * sizeof(u16);
   hipStream_t s = (hipStream_t)stream;
