@@ -182,13 +182,23 @@ def main():
             gr.step()
         barrier()
         tr = time.perf_counter() - tr
+        # per-step drift of the bf16 rollout against the SAME rollout in fp32 on this GPU (the
+        # ONNX reference is unavailable)
+        del gr
+        _, _, hist_b = R.rollout(model, inp, inp_s, stats, maps, const_h, sl, steps=7, graph=True, keep=True)
+        model.set_compute_dtype(torch.float32)
+        _, _, hist_f = R.rollout(model, inp, inp_s, stats, maps, const_h, sl, steps=7, graph=False, keep=True)
+        model.set_compute_dtype(torch.bfloat16)
+        roll_drift = [((hb[0].double() - hf[0].double()).norm() / hf[0].double().norm()).item()
+                      for hb, hf in zip(hist_b, hist_f)]
+        del hist_b, hist_f
         bf16_res = {"metric": "bf16 forward steps/s (bf16 activations+weights, fp32 LN/softmax/accumulate), hipGraph replay",
                     "value": world * args.steps / tg, "ms_per_step": tg / args.steps * 1e3,
                     "eager_ms_per_step": tb / args.steps * 1e3, "rel_l2_drift_vs_f32": drift,
                     "model_tflops": FWD_GFLOP / (tg / args.steps * 1e3),
-                    "rollout_7x24h_ms": tr * 1e3}
+                    "rollout_7x24h_ms": tr * 1e3, "rollout_rel_l2_drift_vs_f32_per_step": roll_drift}
         model.set_compute_dtype(torch.float32)
-        del out_b, gs, gr
+        del out_b, gs
       except Exception as e:      # secondary metrics must never take the headline line down
         bf16_res = {"error": repr(e)[:300]}
         model.set_compute_dtype(torch.float32)

@@ -26,6 +26,116 @@ __device__ inline int kvoff(int key, int d) {
   return key * KV_LD + ((((d >> 2) ^ f) << 2) | (d & 3));
 }
 
+struct BiasRowF {          // one query row of the bias tile, this lane's 36 keys (key 16j + 4lg + r)
+  f32x4 v[9];
+};
+
+__device__ inline BiasRowF load_bias_row(const float* __restrict__ bias_tile, int qn, int lg) {
+  const float* brow = bias_tile + (size_t)qn * PANGU_WTOK + lg * 4;
+  BiasRowF b;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) b.v[j] = *reinterpret_cast<const f32x4*>(brow + j * 16);
+  return b;
+}
+
+// One 16-query tile of one wave.  q0/q1 (scaled Q fragment) and the bias row are already in registers.
+template <bool SHIFTED>
+__device__ __forceinline__ void attn_tile_f32(const float* Ks, const float* Vs, const f32x4 q0, const f32x4 q1,
+                                              const BiasRowF& bias, int qn, int qtok, int lq, int lg, bool zcut,
+                                              bool hcut, unsigned long long kz_bits, unsigned long long kh_bits,
+                                              float* __restrict__ out, float* __restrict__ lse, int C, int heads, int hd) {
+  // K/V fragments are the same for every query tile; keep them in LDS rather than letting the compiler keep
+  // 200+ tile-invariant registers live across the three tiles (which halves the occupancy): opaque zero offset.
+  int lz = 0;
+  asm volatile("" : "+v"(lz));
+  const float* Ksq = Ks + lz;
+  const float* Vsq = Vs + lz;
+  // ---- S^T = bias^T + K (scale Q)^T : 9 key tiles; the bias tile is the accumulator's initial value.
+  // Key tiles go three at a time so consecutive MFMAs hit different accumulators (16x16x4 f32: 32-cycle issue,
+  // 40-cycle dependent latency).
+  f32x4 s[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) s[j] = bias.v[j];
+#pragma unroll
+  for (int j0 = 0; j0 < 9; j0 += 3) {
+    f32x4 k0[3], k1[3];
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+      k0[jj] = *reinterpret_cast<const f32x4*>(&Ksq[kvoff((j0 + jj) * 16 + lq, lg * 4)]);
+      k1[jj] = *reinterpret_cast<const f32x4*>(&Ksq[kvoff((j0 + jj) * 16 + lq, 16 + lg * 4)]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj)
+        s[j0 + jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(k0[jj][ks], q0[ks], s[j0 + jj], 0, 0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj)
+        s[j0 + jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(k1[jj][ks], q1[ks], s[j0 + jj], 0, 0, 0);
+  }
+  // lane holds S^T[key = 16j + 4lg + r][query = qn], r = 0..3
+  // ---- shift mask (closed form, only in the cut window types), row max
+  float mx = -INFINITY;
+  if (SHIFTED) {
+    if (zcut || hcut) {
+      const bool zq = qn >= 72, hq = ((qn / 12) % 6) < 3;
+      // bit (4j + r) of the key-class words: this lane's 36 keys kn = 16j + 4lg + r
+      const unsigned long long zsel = zq ? ~kz_bits : kz_bits;      // keys whose z-half differs from the query's
+      const unsigned long long hsel = hq ? ~kh_bits : kh_bits;
+      const unsigned long long cut = (zcut ? zsel : 0ull) | (hcut ? hsel : 0ull);
+#pragma unroll
+      for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if ((cut >> (4 * j + r)) & 1ull) s[j][r] += -100.0f;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 9; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[j][r]);
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 9; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float e = __expf(s[j][r] - mx);
+      s[j][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  // ---- O^T = V^T P^T : two 16-dim tiles, k = key
+  f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = j * 16 + lg * 4 + r;
+      const float v0 = Vsq[kvoff(key, lq)];
+      const float v1 = Vsq[kvoff(key, 16 + lq)];
+      o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, s[j][r], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, s[j][r], o1, 0, 0, 0);
+    }
+  }
+  // lane holds O^T[d = 16*dt + 4lg + r][query = qn]
+  if (qtok >= 0) {
+    const float inv = 1.0f / sum;
+    o0 *= inv; o1 *= inv;
+    float* dst = out + (size_t)qtok * C + hd * 32 + lg * 4;
+    *reinterpret_cast<f32x4*>(dst) = o0;
+    *reinterpret_cast<f32x4*>(dst + 16) = o1;
+    if (lse && lg == 0) lse[(size_t)qtok * heads + hd] = mx + __logf(sum);
+  }
+}
+
+// Latency structure: every global load the workgroup needs up front -- the K/V rows it stages (source tokens from the
+// closed form, not through LDS), the Q fragments of all three query tiles of each wave and the first tile's bias row --
+// is issued before anything waits; the bias row of tile i+1 is requested before tile i computes; ONE barrier.
 template <bool SHIFTED>
 __global__ __launch_bounds__(192, 3) void window_attn_f32_kernel(const float* __restrict__ qkv,
                                                               const float* __restrict__ qkv_bias,
@@ -34,7 +144,6 @@ __global__ __launch_bounds__(192, 3) void window_attn_f32_kernel(const float* __
                                                               WinGeom g, int C, int heads, int n_pairs) {
   __shared__ __attribute__((aligned(16))) float Ks[PANGU_WTOK * KV_LD];
   __shared__ __attribute__((aligned(16))) float Vs[PANGU_WTOK * KV_LD];
-  __shared__ int tok_s[PANGU_WTOK];
 
   // block -> (pair=(t,head), l): blocks b, b+8, .. share an XCD and walk l for one pair
   const int b = blockIdx.x;
@@ -45,37 +154,52 @@ __global__ __launch_bounds__(192, 3) void window_attn_f32_kernel(const float* __
   const int t = pair / heads, hd = pair - t * heads;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 15, lg = lane >> 4;
   const int C3 = 3 * C;
   const float scale = 0.17677669529663687f;   // 32^-0.5, reference layers.py:289
-
-  if (tid < PANGU_WTOK) tok_s[tid] = win_src_token(g, l, t, tid, SHIFTED);
-  __syncthreads();
-
-  // ---- stage K and V: 144 rows x 8 float4 each
-  for (int f = tid; f < PANGU_WTOK * 8; f += 192) {
-    const int n = f >> 3, c4 = (f & 7) * 4;
-    const int tok = tok_s[n];
-    const float* src = tok >= 0 ? qkv + (size_t)tok * C3 : qkv_bias;
-    const f32x4 kv = *reinterpret_cast<const f32x4*>(src + C + hd * 32 + c4);
-    const f32x4 vv = *reinterpret_cast<const f32x4*>(src + 2 * C + hd * 32 + c4);
-    *reinterpret_cast<f32x4*>(&Ks[kvoff(n, c4)]) = kv;
-    *reinterpret_cast<f32x4*>(&Vs[kvoff(n, c4)]) = vv;
-  }
-  __syncthreads();
-
-  const int lq = lane & 15, lg = lane >> 4;
   const float* bias_tile = esb + (size_t)(t * heads + hd) * PANGU_WTOK * PANGU_WTOK;
 
+  // ---- up-front loads.  Q fragment: lane group lg owns dims {4lg..4lg+3} and {16+4lg..16+4lg+3} (the MFMA k index is
+  // permuted the same way for K: chunk pairs (lg, lg^1) inside every ds_read_b128 lane group keep the swizzled reads
+  // conflict-free)
+  int qtok[3];
+  f32x4 q0[3], q1[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int qn = (wave + 3 * i) * 16 + lq;
+    qtok[i] = win_src_token(g, l, t, qn, SHIFTED);
+    const float* src = (qtok[i] >= 0 ? qkv + (size_t)qtok[i] * C3 : qkv_bias) + hd * 32 + lg * 4;
+    q0[i] = *reinterpret_cast<const f32x4*>(src);
+    q1[i] = *reinterpret_cast<const f32x4*>(src + 16);
+  }
+  BiasRowF b0 = load_bias_row(bias_tile, wave * 16 + lq, lg);
+  // K and V: 144 rows x 8 float4 each = 6 per thread, staged in two halves of 3 (register budget)
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    f32x4 kv[3], vv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int f = tid + 192 * (3 * half + i), n = f >> 3, c4 = (f & 7) * 4;
+      const int tok = win_src_token(g, l, t, n, SHIFTED);
+      const float* src = tok >= 0 ? qkv + (size_t)tok * C3 : qkv_bias;
+      kv[i] = *reinterpret_cast<const f32x4*>(src + C + hd * 32 + c4);
+      vv[i] = *reinterpret_cast<const f32x4*>(src + 2 * C + hd * 32 + c4);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int f = tid + 192 * (3 * half + i), n = f >> 3, c4 = (f & 7) * 4;
+      *reinterpret_cast<f32x4*>(&Ks[kvoff(n, c4)]) = kv[i];
+      *reinterpret_cast<f32x4*>(&Vs[kvoff(n, c4)]) = vv[i];
+    }
+  }
+
   bool zcut = false, hcut = false;
+  // per-lane key-class bits (bit 4j+r <-> key 16j+4lg+r): kz = key in the upper z-plane, kh = key in rows hi<3
+  unsigned long long kz_bits = 0ull, kh_bits = 0ull;
   if (SHIFTED) {
     const int zwin = t / g.nHw, hwin = t - zwin * g.nHw;
     zcut = zwin == g.nZw - 1;
     hcut = hwin == g.nHw - 1;
-  }
-
-  // per-lane key-class bits (bit 4j+r <-> key 16j+4lg+r): kz = key in the upper z-plane, kh = key in rows hi<3
-  unsigned long long kz_bits = 0ull, kh_bits = 0ull;
-  if (SHIFTED) {
 #pragma unroll
     for (int j = 0; j < 9; ++j)
 #pragma unroll
@@ -85,108 +209,18 @@ __global__ __launch_bounds__(192, 3) void window_attn_f32_kernel(const float* __
         if (((kn / 12) % 6) < 3) kh_bits |= 1ull << (4 * j + r);
       }
   }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { q0[i] *= scale; q1[i] *= scale; }
+  __syncthreads();
 
-  for (int qt = wave; qt < 9; qt += 3) {
-    const int qn = qt * 16 + lq;                 // this lane's query slot in the window
-    const int qtok = tok_s[qn];
-    // K/V fragments are the same for every query tile; keep them in LDS rather than letting the compiler hoist
-    // 200+ loop-invariant registers out of this loop (which halves the occupancy): opaque zero offset.
-    int lz = 0;
-    asm volatile("" : "+v"(lz));
-    const float* Ksq = Ks + lz;
-    const float* Vsq = Vs + lz;
-    // Q fragment: lane group lg owns dims {4lg..4lg+3} and {16+4lg..16+4lg+3} (the MFMA k index is permuted the same
-    // way for K: chunk pairs (lg, lg^1) inside every ds_read_b128 lane group keep the swizzled reads conflict-free)
-    f32x4 q0, q1;
-    {
-      const float* src = (qtok >= 0 ? qkv + (size_t)qtok * C3 : qkv_bias) + hd * 32 + lg * 4;
-      q0 = *reinterpret_cast<const f32x4*>(src);
-      q1 = *reinterpret_cast<const f32x4*>(src + 16);
-      q0 *= scale; q1 *= scale;
-    }
-    // ---- S^T = bias^T + K (scale Q)^T : 9 key tiles; the bias tile is the accumulator's initial value.
-    // Key tiles go three at a time so consecutive MFMAs hit different accumulators (16x16x4 f32: 32-cycle issue,
-    // 40-cycle dependent latency).
-    const float* brow = bias_tile + (size_t)qn * PANGU_WTOK + lg * 4;
-    f32x4 s[9];
-#pragma unroll
-    for (int j = 0; j < 9; ++j) s[j] = *reinterpret_cast<const f32x4*>(brow + j * 16);
-#pragma unroll
-    for (int j0 = 0; j0 < 9; j0 += 3) {
-      f32x4 k0[3], k1[3];
-#pragma unroll
-      for (int jj = 0; jj < 3; ++jj) {
-        k0[jj] = *reinterpret_cast<const f32x4*>(&Ksq[kvoff((j0 + jj) * 16 + lq, lg * 4)]);
-        k1[jj] = *reinterpret_cast<const f32x4*>(&Ksq[kvoff((j0 + jj) * 16 + lq, 16 + lg * 4)]);
-      }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int jj = 0; jj < 3; ++jj)
-          s[j0 + jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(k0[jj][ks], q0[ks], s[j0 + jj], 0, 0, 0);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int jj = 0; jj < 3; ++jj)
-          s[j0 + jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(k1[jj][ks], q1[ks], s[j0 + jj], 0, 0, 0);
-    }
-    // lane holds S^T[key = 16j + 4lg + r][query = qn], r = 0..3
-    // ---- shift mask (closed form, only in the cut window types), row max
-    float mx = -INFINITY;
-    if (SHIFTED) {
-      if (zcut || hcut) {
-        const bool zq = qn >= 72, hq = ((qn / 12) % 6) < 3;
-        // bit (4j + r) of the key-class words: this lane's 36 keys kn = 16j + 4lg + r
-        const unsigned long long zsel = zq ? ~kz_bits : kz_bits;      // keys whose z-half differs from the query's
-        const unsigned long long hsel = hq ? ~kh_bits : kh_bits;
-        const unsigned long long cut = (zcut ? zsel : 0ull) | (hcut ? hsel : 0ull);
-#pragma unroll
-        for (int j = 0; j < 9; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if ((cut >> (4 * j + r)) & 1ull) s[j][r] += -100.0f;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 9; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[j][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < 9; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = __expf(s[j][r] - mx);
-        s[j][r] = e;
-        sum += e;
-      }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    // ---- O^T = V^T P^T : two 16-dim tiles, k = key
-    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < 9; ++j) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = j * 16 + lg * 4 + r;
-        const float v0 = Vsq[kvoff(key, lq)];
-        const float v1 = Vsq[kvoff(key, 16 + lq)];
-        o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, s[j][r], o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, s[j][r], o1, 0, 0, 0);
-      }
-    }
-    // lane holds O^T[d = 16*dt + 4lg + r][query = qn]
-    if (qtok >= 0) {
-      const float inv = 1.0f / sum;
-      o0 *= inv; o1 *= inv;
-      float* dst = out + (size_t)qtok * C + hd * 32 + lg * 4;
-      *reinterpret_cast<f32x4*>(dst) = o0;
-      *reinterpret_cast<f32x4*>(dst + 16) = o1;
-      if (lse && lg == 0) lse[(size_t)qtok * heads + hd] = mx + __logf(sum);
-    }
-  }
+  const BiasRowF b1 = load_bias_row(bias_tile, (wave + 3) * 16 + lq, lg);
+  attn_tile_f32<SHIFTED>(Ks, Vs, q0[0], q1[0], b0, wave * 16 + lq, qtok[0], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse,
+                         C, heads, hd);
+  b0 = load_bias_row(bias_tile, (wave + 6) * 16 + lq, lg);
+  attn_tile_f32<SHIFTED>(Ks, Vs, q0[1], q1[1], b1, (wave + 3) * 16 + lq, qtok[1], lq, lg, zcut, hcut, kz_bits, kh_bits, out,
+                         lse, C, heads, hd);
+  attn_tile_f32<SHIFTED>(Ks, Vs, q0[2], q1[2], b0, (wave + 6) * 16 + lq, qtok[2], lq, lg, zcut, hcut, kz_bits, kh_bits, out,
+                         lse, C, heads, hd);
 }
 
 __global__ void window_index_export_kernel(int32_t* out, WinGeom g, int shifted) {
