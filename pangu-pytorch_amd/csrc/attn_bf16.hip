@@ -22,7 +22,7 @@ typedef unsigned short u16;
 constexpr int VT_LD = 336;      // bytes per V^T row (144 keys * 2 B + pad; 336 = 80 mod 256: conflict-free b128 fragment reads)
 
 __device__ inline u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
-__device__ inline unsigned pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+__device__ inline unsigned pack2(float a, float b) { return pack_bf16x2(a, b); }
 __device__ inline float bflo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ inline float bfhi(unsigned u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
 

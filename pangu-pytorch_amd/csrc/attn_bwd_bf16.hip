@@ -21,7 +21,7 @@ constexpr int ROWIMG = PANGU_WTOK * 64;        // bytes of a row-major [144][32]
 constexpr int TIMG = 32 * T_LD;
 
 __device__ inline u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
-__device__ inline unsigned pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+__device__ inline unsigned pack2(float a, float b) { return pack_bf16x2(a, b); }
 __device__ inline float bflo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ inline float bfhi(unsigned u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
 __device__ inline float bf1(u16 h) { return __builtin_bit_cast(float, (unsigned)h << 16); }

@@ -80,6 +80,36 @@ __device__ inline float erf_poly(float x) {
   return copysignf(fminf(p * ax, 1.0f), x);
 }
 __device__ inline float gelu_erf_lp(float x) { return 0.5f * x * (1.0f + erf_poly(x * 0.70710678118654752440f)); }
+
+// The same GELU on a float4 with gfx950's packed-fp32 VALU ops (v_pk_mul/fma/add_f32: two lanes-elements per
+// instruction): gelu(x) = x (0.5 + h(x/sqrt2)), h = erf/2 = clamp(u P'(u^2), -.5, .5) with P' = P/2 and u clamped to
+// +-2.8 (odd in u: no abs / copysign).  7.5 VALU instructions per element instead of 15.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ inline f32x2_t half_erf_poly2(f32x2_t u) {
+  f32x2_t uc;
+  uc[0] = __builtin_amdgcn_fmed3f(u[0], -2.8f, 2.8f);
+  uc[1] = __builtin_amdgcn_fmed3f(u[1], -2.8f, 2.8f);
+  const f32x2_t t = uc * uc;
+#define PANGU_C2(v) f32x2_t{v, v}
+  f32x2_t p = __builtin_elementwise_fma(PANGU_C2(0.5f * 5.37784878e-06f), t, PANGU_C2(0.5f * -0.000177775825f));
+  p = __builtin_elementwise_fma(p, t, PANGU_C2(0.5f * 0.00251051432f));
+  p = __builtin_elementwise_fma(p, t, PANGU_C2(0.5f * -0.0201338951f));
+  p = __builtin_elementwise_fma(p, t, PANGU_C2(0.5f * 0.103594314f));
+  p = __builtin_elementwise_fma(p, t, PANGU_C2(0.5f * -0.370308868f));
+  p = __builtin_elementwise_fma(p, t, PANGU_C2(0.5f * 1.12730194f));
+#undef PANGU_C2
+  f32x2_t e = p * uc;
+  e[0] = __builtin_amdgcn_fmed3f(e[0], -0.5f, 0.5f);
+  e[1] = __builtin_amdgcn_fmed3f(e[1], -0.5f, 0.5f);
+  return e;
+}
+__device__ inline f32x4 gelu_erf_lp4(f32x4 x) {
+  const f32x2_t c = {0.70710678118654752440f, 0.70710678118654752440f}, half = {0.5f, 0.5f};
+  f32x2_t a = {x[0], x[1]}, b = {x[2], x[3]};
+  a = a * (half_erf_poly2(a * c) + half);
+  b = b * (half_erf_poly2(b * c) + half);
+  return f32x4{a[0], a[1], b[0], b[1]};
+}
 __device__ inline float gelu_erf_grad_lp(float x) {
   return 0.5f * (1.0f + erf_poly(x * 0.70710678118654752440f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
@@ -87,6 +117,12 @@ __device__ inline float gelu_erf_grad_lp(float x) {
 // d/dx gelu(x) = Phi(x) + x*phi(x)
 __device__ inline float gelu_erf_grad(float x) {
   return 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// two floats -> two bf16 (round-to-nearest-even) in ONE v_cvt_pk_bf16_f32, low half = a
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ inline unsigned pack_bf16x2(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
 }
 
 __device__ inline float wave_sum(float v) {

@@ -25,7 +25,7 @@ constexpr int BBK = 64;
 __device__ inline u16 f2bf(float f) {   // round-to-nearest-even, NaN-preserving via the hardware convert
   return __builtin_bit_cast(u16, (__bf16)f);
 }
-__device__ inline unsigned pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+__device__ inline unsigned pack2(float a, float b) { return pack_bf16x2(a, b); }
 
 __device__ inline int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }   // byte offset
 
@@ -110,8 +110,7 @@ __device__ __forceinline__ void bf16_epilogue(f32x4 (&acc)[4][2 * TN], unsigned 
           const unsigned xo = col < N ? ((unsigned)(wave_m0 + i * 16 + lc) * (unsigned)N + (unsigned)col) * 2u : 0xFFFFFFFFu;
           __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])}, x_rsrc, (int)xo, 0, 0);
         }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = gelu_erf_lp(v[c]);
+        v = gelu_erf_lp4(v);
       }
       *reinterpret_cast<u32x2*>(slot) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
     }

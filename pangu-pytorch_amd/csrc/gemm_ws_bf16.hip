@@ -25,7 +25,7 @@ constexpr int WS_WAVES = 8;
 constexpr int WS_BM = 32 * WS_WAVES;          // 256 token rows per workgroup tile
 
 __device__ inline u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
-__device__ inline unsigned pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+__device__ inline unsigned pack2(float a, float b) { return pack_bf16x2(a, b); }
 
 // byte offset of 16-B chunk `chunk` of weight row `row` (row pitch = KMAX*2 bytes, a multiple of 128)
 // Row pitch 384 B (KMAX 192, = 128 mod 256): XOR the low 3 chunk bits with (row>>1)&7; pitch 768 B (KMAX 384, = 0 mod
@@ -148,8 +148,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_bf16_kernel(const u16* __restr
             const unsigned xo = col < N ? ((unsigned)(m_cur + mt * 16 + lc) * (unsigned)N + (unsigned)col) * 2u : 0xFFFFFFFFu;
             __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])}, x_rsrc, (int)xo, 0, 0);
           }
-#pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] = gelu_erf_lp(v[c]);
+          v = gelu_erf_lp4(v);
         }
         if (OUT_F32) *reinterpret_cast<f32x4*>(ep + lc * EP_LD + (j * 16 + lg * 4) * 4) = v;
         else *reinterpret_cast<u32x2*>(ep + lc * EP_LD + (j * 16 + lg * 4) * 2) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};

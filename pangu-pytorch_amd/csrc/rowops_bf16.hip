@@ -18,8 +18,7 @@ __device__ inline f32x4 ld4(const u16* p) {
                __builtin_bit_cast(float, u[1] << 16), __builtin_bit_cast(float, u[1] & 0xFFFF0000u)};
 }
 __device__ inline void st4(u16* p, f32x4 v) {
-  *reinterpret_cast<u32x2*>(p) = u32x2{(unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16),
-                                        (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16)};
+  *reinterpret_cast<u32x2*>(p) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
 }
 
 template <int NV>
@@ -130,7 +129,7 @@ __global__ __launch_bounds__(256) void ln_residual_bf16_v8_kernel(const u16* __r
           const float s1 = __builtin_bit_cast(float, sv[u][c] & 0xFFFF0000u);
           const float r0 = s0 + branch_scale * ((v[2 * c] - mean) * rstd * gm[2 * c] + bt[2 * c]);
           const float r1 = s1 + branch_scale * ((v[2 * c + 1] - mean) * rstd * gm[2 * c + 1] + bt[2 * c + 1]);
-          o4[c] = (unsigned)f2bf(r0) | ((unsigned)f2bf(r1) << 16);
+          o4[c] = pack_bf16x2(r0, r1);
         }
         const int row = base + u * RPW + sub;
         *reinterpret_cast<u32x4*>(out + (size_t)row * ldo + l * 8) = o4;

@@ -21,8 +21,7 @@ __device__ inline f32x4 ld4(const u16* p) {
                __builtin_bit_cast(float, u[1] << 16), __builtin_bit_cast(float, u[1] & 0xFFFF0000u)};
 }
 __device__ inline void st4(u16* p, f32x4 v) {
-  *reinterpret_cast<u32x2*>(p) = u32x2{(unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16),
-                                        (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16)};
+  *reinterpret_cast<u32x2*>(p) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
 }
 
 // y: pre-norm row (in), g: upstream gradient row already multiplied by the branch scale (in) -> dy (out, in y)
