@@ -38,45 +38,39 @@ __device__ inline BiasRowF load_bias_row(const float* __restrict__ bias_tile, in
   return b;
 }
 
-// One 16-query tile of one wave.  q0/q1 (scaled Q fragment) and the bias row are already in registers.
-template <bool SHIFTED>
-__device__ __forceinline__ void attn_tile_f32(const float* Ks, const float* Vs, const f32x4 q0, const f32x4 q1,
-                                              const BiasRowF& bias, int qn, int qtok, int lq, int lg, bool zcut,
-                                              bool hcut, unsigned long long kz_bits, unsigned long long kh_bits,
-                                              float* __restrict__ out, float* __restrict__ lse, int C, int heads, int hd) {
-  // K/V fragments are the same for every query tile; keep them in LDS rather than letting the compiler keep
-  // 200+ tile-invariant registers live across the three tiles (which halves the occupancy): opaque zero offset.
-  int lz = 0;
-  asm volatile("" : "+v"(lz));
-  const float* Ksq = Ks + lz;
-  const float* Vsq = Vs + lz;
-  // ---- S^T = bias^T + K (scale Q)^T : 9 key tiles; the bias tile is the accumulator's initial value.
-  // Key tiles go three at a time so consecutive MFMAs hit different accumulators (16x16x4 f32: 32-cycle issue,
-  // 40-cycle dependent latency).
-  f32x4 s[9];
+// ---- the three phases of one 16-query tile of one wave -----------------------------------------------------------------
+// S^T = bias^T + K (scale Q)^T : 9 key tiles, `s` enters holding the bias row (the accumulators' initial value).
+// Key tiles go three at a time so consecutive MFMAs hit different accumulators (16x16x4 f32: 32-cycle issue, 40-cycle
+// dependent latency).  lane holds S^T[key = 16j + 4lg + r][query], r = 0..3.
+__device__ __forceinline__ void s_chunk(f32x4 (&s)[9], const float* Ksq, const f32x4 q0, const f32x4 q1, int lq, int lg,
+                                        int j0) {
+  f32x4 k0[3], k1[3];
 #pragma unroll
-  for (int j = 0; j < 9; ++j) s[j] = bias.v[j];
-#pragma unroll
-  for (int j0 = 0; j0 < 9; j0 += 3) {
-    f32x4 k0[3], k1[3];
-#pragma unroll
-    for (int jj = 0; jj < 3; ++jj) {
-      k0[jj] = *reinterpret_cast<const f32x4*>(&Ksq[kvoff((j0 + jj) * 16 + lq, lg * 4)]);
-      k1[jj] = *reinterpret_cast<const f32x4*>(&Ksq[kvoff((j0 + jj) * 16 + lq, 16 + lg * 4)]);
-    }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int jj = 0; jj < 3; ++jj)
-        s[j0 + jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(k0[jj][ks], q0[ks], s[j0 + jj], 0, 0, 0);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int jj = 0; jj < 3; ++jj)
-        s[j0 + jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(k1[jj][ks], q1[ks], s[j0 + jj], 0, 0, 0);
+  for (int jj = 0; jj < 3; ++jj) {
+    k0[jj] = *reinterpret_cast<const f32x4*>(&Ksq[kvoff((j0 + jj) * 16 + lq, lg * 4)]);
+    k1[jj] = *reinterpret_cast<const f32x4*>(&Ksq[kvoff((j0 + jj) * 16 + lq, 16 + lg * 4)]);
   }
-  // lane holds S^T[key = 16j + 4lg + r][query = qn], r = 0..3
-  // ---- shift mask (closed form, only in the cut window types), row max
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj)
+      s[j0 + jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(k0[jj][ks], q0[ks], s[j0 + jj], 0, 0, 0);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj)
+      s[j0 + jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(k1[jj][ks], q1[ks], s[j0 + jj], 0, 0, 0);
+}
+__device__ __forceinline__ void s_phase(f32x4 (&s)[9], const float* Ksq, const f32x4 q0, const f32x4 q1, int lq, int lg) {
+  s_chunk(s, Ksq, q0, q1, lq, lg, 0);
+  s_chunk(s, Ksq, q0, q1, lq, lg, 3);
+  s_chunk(s, Ksq, q0, q1, lq, lg, 6);
+}
+
+// shift mask (closed form, only in the cut window types) and row max
+template <bool SHIFTED>
+__device__ __forceinline__ float softmax_max(f32x4 (&s)[9], int qn, bool zcut, bool hcut, unsigned long long kz_bits,
+                                             unsigned long long kh_bits) {
   float mx = -INFINITY;
   if (SHIFTED) {
     if (zcut || hcut) {
@@ -98,31 +92,62 @@ __device__ __forceinline__ void attn_tile_f32(const float* Ks, const float* Vs, 
     for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[j][r]);
   mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  return mx;
+}
+// softmax numerators of key tiles [JLO, JHI) in place; returns their partial sum
+template <int JLO, int JHI>
+__device__ __forceinline__ float softmax_exp(f32x4 (&s)[9], float mx) {
   float sum = 0.f;
 #pragma unroll
-  for (int j = 0; j < 9; ++j)
+  for (int j = JLO; j < JHI; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float e = __expf(s[j][r] - mx);
       s[j][r] = e;
       sum += e;
     }
+  return sum;
+}
+__device__ __forceinline__ float softmax_sum(float sum) {
   sum += __shfl_xor(sum, 16, 64);
   sum += __shfl_xor(sum, 32, 64);
-  // ---- O^T = V^T P^T : two 16-dim tiles, k = key
+  return sum;
+}
+
+// O^T = V^T P^T : two 16-dim tiles, k = key; normalise and store.  lane holds O^T[d = 16*dt + 4lg + r][query].
+// The A operands V[key 16j + 4lg + r][d] are b32 column reads of the row-major V image; the eight reads of key tile
+// j+1 are issued as a batch before the eight MFMAs of tile j (read just ahead of each MFMA, every MFMA would wait a
+// full LDS round trip).
+__device__ __forceinline__ void pv_phase(const f32x4 (&s)[9], const float* Vsq, float mx, float sum, int qtok, int lq, int lg,
+                                         float* __restrict__ out, float* __restrict__ lse, int C, int heads, int hd) {
   f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+  float va[4], vb[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    va[r] = Vsq[kvoff(lg * 4 + r, lq)];
+    vb[r] = Vsq[kvoff(lg * 4 + r, 16 + lq)];
+  }
 #pragma unroll
   for (int j = 0; j < 9; ++j) {
+    float ca[4], cb[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ca[r] = va[r]; cb[r] = vb[r]; }
+    if (j < 8) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = (j + 1) * 16 + lg * 4 + r;
+        va[r] = Vsq[kvoff(key, lq)];
+        vb[r] = Vsq[kvoff(key, 16 + lq)];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int key = j * 16 + lg * 4 + r;
-      const float v0 = Vsq[kvoff(key, lq)];
-      const float v1 = Vsq[kvoff(key, 16 + lq)];
-      o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, s[j][r], o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, s[j][r], o1, 0, 0, 0);
+      o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[r], s[j][r], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cb[r], s[j][r], o1, 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
-  // lane holds O^T[d = 16*dt + 4lg + r][query = qn]
   if (qtok >= 0) {
     const float inv = 1.0f / sum;
     o0 *= inv; o1 *= inv;
@@ -133,9 +158,90 @@ __device__ __forceinline__ void attn_tile_f32(const float* Ks, const float* Vs, 
   }
 }
 
+// K/V fragments are the same for every query tile; an opaque zero offset per use keeps the compiler from holding
+// 200+ tile-invariant fragment registers live across the tiles (which would halve the occupancy).
+__device__ __forceinline__ const float* opaque(const float* p) {
+  int lz = 0;
+  asm volatile("" : "+v"(lz));
+  return p + lz;
+}
+
+// Current tile's softmax (scores in sc) overlapped with the next tile's 72 score MFMAs (into sn) INSIDE one wave: each
+// MFMA (8 passes = 32 cycles in the matrix core) is followed in program order by a few independent softmax VALU
+// instructions that execute in its shadow; a sched_barrier after every slot pins that order (the scheduler otherwise
+// clusters the MFMAs and leaves the VALU work serial behind them).  Chunks: [24 MFMAs | row max], [24 | exp of key
+// tiles 0-4.5], [24 | exp of the rest], so each chunk has independent work for both pipes.
+template <bool SHIFTED>
+__device__ __forceinline__ void softmax_with_next_scores(f32x4 (&sc)[9], f32x4 (&sn)[9], const float* Ks, const f32x4 q0,
+                                                         const f32x4 q1, int qn, int lq, int lg, bool zcut, bool hcut,
+                                                         unsigned long long kz_bits, unsigned long long kh_bits, float& mx_out,
+                                                         float& sum_out) {
+  if (SHIFTED) {
+    if (zcut || hcut) {
+      const bool zq = qn >= 72, hq = ((qn / 12) % 6) < 3;
+      const unsigned long long zsel = zq ? ~kz_bits : kz_bits;      // keys whose z-half differs from the query's
+      const unsigned long long hsel = hq ? ~kh_bits : kh_bits;
+      const unsigned long long cut = (zcut ? zsel : 0ull) | (hcut ? hsel : 0ull);
+#pragma unroll
+      for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if ((cut >> (4 * j + r)) & 1ull) sc[j][r] += -100.0f;
+    }
+  }
+  float mx = -INFINITY, sum = 0.f;
+  const float LOG2E = 1.4426950408889634f;
+  float nmx = 0.f;                                            // -mx * log2(e)
+#pragma unroll
+  for (int chunk = 0; chunk < 3; ++chunk) {
+    const int j0 = 3 * chunk;
+    const float* Ksq = opaque(Ks);
+    f32x4 k0[3], k1[3];
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+      k0[jj] = *reinterpret_cast<const f32x4*>(&Ksq[kvoff((j0 + jj) * 16 + lq, lg * 4)]);
+      k1[jj] = *reinterpret_cast<const f32x4*>(&Ksq[kvoff((j0 + jj) * 16 + lq, 16 + lg * 4)]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < 24; ++m) {
+      const int half = m / 12, ks = (m % 12) / 3, jj = m % 3;
+      sn[j0 + jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(half ? k1[jj][ks] : k0[jj][ks], half ? q1[ks] : q0[ks],
+                                                         sn[j0 + jj], 0, 0, 0);
+      if (chunk == 0) {
+        if (m < 18) {                                         // row max: two of the 36 scores per slot
+          const int e = 2 * m;
+          mx = fmaxf(mx, fmaxf(sc[e >> 2][e & 3], sc[(e + 1) >> 2][(e + 1) & 3]));
+        }
+      } else {
+        const int e = 18 * (chunk - 1) + m;                   // softmax numerators: one score per slot (18 per chunk)
+        if (m < 18) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(sc[e >> 2][e & 3], LOG2E, nmx));
+          sc[e >> 2][e & 3] = p;
+          sum += p;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (chunk == 0) {
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      nmx = -mx * LOG2E;
+    }
+  }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  mx_out = mx;
+  sum_out = sum;
+}
+
 // Latency structure: every global load the workgroup needs up front -- the K/V rows it stages (source tokens from the
 // closed form, not through LDS), the Q fragments of all three query tiles of each wave and the first tile's bias row --
-// is issued before anything waits; the bias row of tile i+1 is requested before tile i computes; ONE barrier.
+// is issued before anything waits; ONE barrier.  The score MFMAs of tile i+1 are issued slot by slot between the
+// softmax VALU instructions of tile i (tools/ubench_mfma_rate.hip: on gfx950 a VALU instruction costs ~3 cycles and a
+// v_exp ~12 cycles of the SIMD's MFMA issue time even at 3 waves/SIMD, so the gain is only the removed dependency
+// stalls; ablations -- no bias loads, no exp, head-fastest block order -- change nothing, no global loads/stores at all
+// gives 0.58 ms of the 0.79 ms at stage 0: the kernel is bound by MFMA issue + its own VALU/LDS instruction stream).
 template <bool SHIFTED>
 __global__ __launch_bounds__(192, 3) void window_attn_f32_kernel(const float* __restrict__ qkv,
                                                               const float* __restrict__ qkv_bias,
@@ -172,7 +278,12 @@ __global__ __launch_bounds__(192, 3) void window_attn_f32_kernel(const float* __
     q0[i] = *reinterpret_cast<const f32x4*>(src);
     q1[i] = *reinterpret_cast<const f32x4*>(src + 16);
   }
-  BiasRowF b0 = load_bias_row(bias_tile, wave * 16 + lq, lg);
+  f32x4 sA[9], sB[9];
+  {
+    const BiasRowF b0 = load_bias_row(bias_tile, wave * 16 + lq, lg);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) sA[j] = b0.v[j];
+  }
   // K and V: 144 rows x 8 float4 each = 6 per thread, staged in two halves of 3 (register budget)
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -213,14 +324,30 @@ __global__ __launch_bounds__(192, 3) void window_attn_f32_kernel(const float* __
   for (int i = 0; i < 3; ++i) { q0[i] *= scale; q1[i] *= scale; }
   __syncthreads();
 
-  const BiasRowF b1 = load_bias_row(bias_tile, (wave + 3) * 16 + lq, lg);
-  attn_tile_f32<SHIFTED>(Ks, Vs, q0[0], q1[0], b0, wave * 16 + lq, qtok[0], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse,
-                         C, heads, hd);
-  b0 = load_bias_row(bias_tile, (wave + 6) * 16 + lq, lg);
-  attn_tile_f32<SHIFTED>(Ks, Vs, q0[1], q1[1], b1, (wave + 3) * 16 + lq, qtok[1], lq, lg, zcut, hcut, kz_bits, kh_bits, out,
-                         lse, C, heads, hd);
-  attn_tile_f32<SHIFTED>(Ks, Vs, q0[2], q1[2], b0, (wave + 6) * 16 + lq, qtok[2], lq, lg, zcut, hcut, kz_bits, kh_bits, out,
-                         lse, C, heads, hd);
+  float mx, sum;
+  // tile 0 scores; bias row of tile 1 -> sB
+  {
+    const BiasRowF b1 = load_bias_row(bias_tile, (wave + 3) * 16 + lq, lg);
+    s_phase(sA, opaque(Ks), q0[0], q1[0], lq, lg);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) sB[j] = b1.v[j];
+  }
+  // tile 0 softmax  ||  tile 1 scores
+  softmax_with_next_scores<SHIFTED>(sA, sB, Ks, q0[1], q1[1], wave * 16 + lq, lq, lg, zcut, hcut, kz_bits, kh_bits, mx, sum);
+  {
+    const BiasRowF b2 = load_bias_row(bias_tile, (wave + 6) * 16 + lq, lg);
+    pv_phase(sA, opaque(Vs), mx, sum, qtok[0], lq, lg, out, lse, C, heads, hd);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) sA[j] = b2.v[j];
+  }
+  // tile 1 softmax  ||  tile 2 scores
+  softmax_with_next_scores<SHIFTED>(sB, sA, Ks, q0[2], q1[2], (wave + 3) * 16 + lq, lq, lg, zcut, hcut, kz_bits, kh_bits, mx,
+                                    sum);
+  pv_phase(sB, opaque(Vs), mx, sum, qtok[1], lq, lg, out, lse, C, heads, hd);
+  // tile 2
+  mx = softmax_max<SHIFTED>(sA, (wave + 6) * 16 + lq, zcut, hcut, kz_bits, kh_bits);
+  sum = softmax_sum(softmax_exp<0, 9>(sA, mx));
+  pv_phase(sA, opaque(Vs), mx, sum, qtok[2], lq, lg, out, lse, C, heads, hd);
 }
 
 __global__ void window_index_export_kernel(int32_t* out, WinGeom g, int shifted) {
