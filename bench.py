@@ -212,7 +212,7 @@ def main():
         del out
         model.train()
         tgt, tgt_s, *_ = synthetic_inputs(dev, seed=2000 + rank)      # synthetic targets of the input's shape
-        opt = torch.optim.Adam(model.parameters(), lr=5e-6, weight_decay=3e-6)      # reference finetune_fully.py:121
+        opt = train.make_optimizer(model)      # Adam(lr=5e-6, weight_decay=3e-6), reference finetune_fully.py:121
         sync = FlatGradSync(model) if world > 1 else None
         batch = (inp, inp_s, tgt, tgt_s)
         for tag, dt in (("ddp_train", torch.float32), ("ddp_train_bf16", torch.bfloat16)):

@@ -24,6 +24,15 @@ def weighted_l1_loss(output, output_surface, target, target_surface):
     return loss_upper + loss_surface * 0.25
 
 
+def make_optimizer(model, lr=5e-6, weight_decay=3e-6):
+    """The reference's optimiser (finetune_fully.py:121: Adam(lr=5e-6, weight_decay=3e-6)) in torch's single-kernel
+    multi-tensor form when the parameters live on a HIP device: the same update rule, one launch instead of ~10 per
+    parameter tensor (223 tensors -> 2 200 launches of ~6 us per step otherwise)."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    fused = all(p.is_cuda for p in params)
+    return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, fused=fused)
+
+
 def train_step(model, optimizer, batch, statistics, maps, const_h, stats_last=None, grad_sync=None):
     """One optimisation step (reference pangu_sample.py:45-77). batch = (input, input_surface, target, target_surface).
     `grad_sync` (optional callable) runs between backward and optimizer.step(): the data-parallel gradient
