@@ -40,6 +40,7 @@ extern "C" {
 #define PANGU_ACT_NONE 0
 #define PANGU_ACT_GELU 1       /* exact erf GELU, reference layers.py:261; aux (optional) receives the pre-activation */
 #define PANGU_ACT_GELU_BWD 2   /* C = (A @ W^T) * gelu'(aux): backward through the GELU, aux = saved pre-activation */
+#define PANGU_ACT_ADD 3        /* C = A @ W^T + bias + aux: residual-gradient accumulation fused into the data-gradient GEMM */
 
 typedef void* pangu_stream_t;  /* hipStream_t */
 

@@ -62,9 +62,12 @@ class EarthBlockFn(torch.autograd.Function):
             dpre = ops.linear(dm, _wt(m2w), None, act=ops.ACT_GELU_BWD, aux=pre)
             del dm
             g["m1w"], g["m1b"] = ops.linear_wgrad(dpre, x1)
-            dx1 = ops.linear(dpre, _wt(m1w))
+            if dout.is_contiguous():      # residual gradient added in the GEMM epilogue (no extra pass over N x C)
+                dx1 = ops.linear(dpre, _wt(m1w), act=ops.ACT_ADD, aux=dout)
+            else:
+                dx1 = ops.linear(dpre, _wt(m1w))
+                dx1 += dout
             del dpre
-            dx1 += dout
         dx = dx1
         if s1 != 0.0:
             dy, g["n1w"], g["n1b"] = ops.ln_residual_bwd(dx1, y, n1w, s1)
@@ -76,8 +79,11 @@ class EarthBlockFn(torch.autograd.Function):
             g["esb"] = desb.unsqueeze(0)
             g["a1w"], g["a1b"] = ops.linear_wgrad(dqkv, x)
             g["a1b"] += dqb_pad
-            dx = ops.linear(dqkv, _wt(a1w))
-            dx += dx1
+            if dx1.is_contiguous():
+                dx = ops.linear(dqkv, _wt(a1w), act=ops.ACT_ADD, aux=dx1)
+            else:
+                dx = ops.linear(dqkv, _wt(a1w))
+                dx += dx1
         elif not dx.is_contiguous():
             dx = dx.contiguous()
         return (dx, g["n1w"], g["n1b"], g["n2w"], g["n2b"], g["m1w"], g["m1b"], g["m2w"], g["m2b"], g["esb"],

@@ -52,9 +52,12 @@ class EarthBlockFnBF16(torch.autograd.Function):
             dpre = ob.linear(dm, sh.get_t(m2w), None, act=ob.ACT_GELU_BWD, aux=pre)
             del dm
             g["m1w"], g["m1b"] = ob.linear_wgrad(dpre, x1)
-            dx1 = ob.linear(dpre, sh.get_t(m1w))
+            if dout.is_contiguous():      # residual gradient added in the GEMM epilogue (no extra pass over N x C)
+                dx1 = ob.linear(dpre, sh.get_t(m1w), act=ob.ACT_ADD, aux=dout)
+            else:
+                dx1 = ob.linear(dpre, sh.get_t(m1w))
+                dx1 += dout
             del dpre
-            dx1 += dout
         dx = dx1
         if s1 != 0.0:
             dy, g["n1w"], g["n1b"] = ob.ln_residual_bwd(dx1, y, n1w, s1)
@@ -66,8 +69,11 @@ class EarthBlockFnBF16(torch.autograd.Function):
             g["esb"] = desb.unsqueeze(0)
             g["a1w"], g["a1b"] = ob.linear_wgrad(dqkv, x)
             g["a1b"] += dqb_pad
-            dx = ob.linear(dqkv, sh.get_t(a1w))
-            dx += dx1
+            if dx1.is_contiguous():
+                dx = ob.linear(dqkv, sh.get_t(a1w), act=ob.ACT_ADD, aux=dx1)
+            else:
+                dx = ob.linear(dqkv, sh.get_t(a1w))
+                dx += dx1
         elif not dx.is_contiguous():
             dx = dx.contiguous()
         return (dx, g["n1w"], g["n1b"], g["n2w"], g["n2b"], g["m1w"], g["m1b"], g["m2w"], g["m2b"], g["esb"],

@@ -72,8 +72,8 @@ __device__ __forceinline__ void bf16_epilogue(f32x4 (&acc)[4][2 * TN], unsigned 
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       aux, 0, aux ? (int)((size_t)M * N * sizeof(u16)) : 0, 0x00020000);
   constexpr int CPR = ROWB / 16;                           // 16-B chunks per patch row
-  if (ACT == PANGU_ACT_GELU_BWD) {
-    // stage the saved pre-activation patch first (coalesced 16-B loads), so gelu' can be applied in the MFMA layout
+  if (ACT == PANGU_ACT_GELU_BWD || ACT == PANGU_ACT_ADD) {
+    // stage the saved pre-activation (or addend) patch first (coalesced 16-B loads), so gelu' can be applied in the MFMA layout
 #pragma unroll
     for (int it = 0; it < CPR; ++it) {
       const int f = lane + 64 * it, row = f / CPR, ch = f - row * CPR;
@@ -104,6 +104,13 @@ __device__ __forceinline__ void bf16_epilogue(f32x4 (&acc)[4][2 * TN], unsigned 
         v[1] *= gelu_erf_grad_lp(__builtin_bit_cast(float, xp[0] & 0xFFFF0000u));
         v[2] *= gelu_erf_grad_lp(__builtin_bit_cast(float, xp[1] << 16));
         v[3] *= gelu_erf_grad_lp(__builtin_bit_cast(float, xp[1] & 0xFFFF0000u));
+      }
+      if (ACT == PANGU_ACT_ADD) {
+        const u32x2 xp = *reinterpret_cast<const u32x2*>(slot);
+        v[0] += __builtin_bit_cast(float, xp[0] << 16);
+        v[1] += __builtin_bit_cast(float, xp[0] & 0xFFFF0000u);
+        v[2] += __builtin_bit_cast(float, xp[1] << 16);
+        v[3] += __builtin_bit_cast(float, xp[1] & 0xFFFF0000u);
       }
       if (ACT == PANGU_ACT_GELU) {
         if (aux) {                                          // pre-activation out (rounded to bf16, as it will be re-read)
@@ -356,6 +363,9 @@ int launch_bf16(hipStream_t s, const u16* A, int lda, const u16* W, const float*
   } else if (act == PANGU_ACT_GELU_BWD) {
     if (OUT_F32) return PANGU_E_ARG;
     PANGU_BGEMM(PANGU_ACT_GELU_BWD, false);
+  } else if (act == PANGU_ACT_ADD) {
+    if (OUT_F32) return PANGU_E_ARG;
+    if (bias) PANGU_BGEMM(PANGU_ACT_ADD, true); else PANGU_BGEMM(PANGU_ACT_ADD, false);
   } else {
     if (bias) PANGU_BGEMM(PANGU_ACT_NONE, true); else PANGU_BGEMM(PANGU_ACT_NONE, false);
   }
@@ -372,14 +382,15 @@ extern "C" int pangu_linear_fwd_bf16(pangu_stream_t stream, const void* A, int l
                                      void* C, int ldc, int M, int N, int K, int act, void* aux, int out_dtype) {
   if (!A || !W || !C) return PANGU_E_NULL;
   if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (N & 7) || lda < K || ldc < N || (lda & 7) || (ldc & 3)) return PANGU_E_SHAPE;
-  if (act != PANGU_ACT_NONE && act != PANGU_ACT_GELU && act != PANGU_ACT_GELU_BWD) return PANGU_E_ARG;
+  if (act != PANGU_ACT_NONE && act != PANGU_ACT_GELU && act != PANGU_ACT_GELU_BWD && act != PANGU_ACT_ADD) return PANGU_E_ARG;
   if (act == PANGU_ACT_GELU_BWD && (!aux || bias)) return PANGU_E_ARG;
+  if (act == PANGU_ACT_ADD && !aux) return PANGU_E_ARG;
   if (out_dtype != PANGU_BF16 && out_dtype != PANGU_F32) return PANGU_E_DTYPE;
   if (out_dtype == PANGU_BF16 && (ldc & 7)) return PANGU_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   // K <= 384: weights-stationary barrier-free kernel (PANGU_BF16_WS=0 disables it: A/B knob)
   static const bool allow_ws = !(getenv("PANGU_BF16_WS") && atoi(getenv("PANGU_BF16_WS")) == 0);
-  if (allow_ws && M >= 4096) {
+  if (allow_ws && M >= 4096 && act != PANGU_ACT_ADD) {
     const int rc = pangu_linear_ws_bf16(s, A, lda, W, bias, C, ldc, M, N, K, act, aux, out_dtype == PANGU_F32);
     if (rc != PANGU_E_SHAPE) return rc;
   }

@@ -175,6 +175,7 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_tn_f32_kernel(c
 #pragma unroll
           for (int c = 0; c < 4; ++c) v[c] *= gelu_erf_grad(x[c]);
         }
+        if (ACT == PANGU_ACT_ADD) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)xoff, 0, 0));
         const unsigned off = col_ok ? ((unsigned)(row0 + 8 * it) * (unsigned)ldc + (unsigned)col) * 4u : 0xFFFFFFFFu;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), c_rsrc, (int)off, 0, 0);
       }
@@ -195,6 +196,8 @@ int launch_tn(hipStream_t s, const float* A, int lda, const float* W, const floa
     if (bias) PANGU_GEMM_LAUNCH(PANGU_ACT_GELU, true); else PANGU_GEMM_LAUNCH(PANGU_ACT_GELU, false);
   } else if (act == PANGU_ACT_GELU_BWD) {
     if (bias) PANGU_GEMM_LAUNCH(PANGU_ACT_GELU_BWD, true); else PANGU_GEMM_LAUNCH(PANGU_ACT_GELU_BWD, false);
+  } else if (act == PANGU_ACT_ADD) {
+    if (bias) PANGU_GEMM_LAUNCH(PANGU_ACT_ADD, true); else PANGU_GEMM_LAUNCH(PANGU_ACT_ADD, false);
   } else {
     if (bias) PANGU_GEMM_LAUNCH(PANGU_ACT_NONE, true); else PANGU_GEMM_LAUNCH(PANGU_ACT_NONE, false);
   }
@@ -209,8 +212,8 @@ extern "C" int pangu_linear_fwd(pangu_stream_t stream, const float* A, int lda, 
   if (!A || !W || !C) return PANGU_E_NULL;
   if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || (N & 3) || lda < K || ldc < N || (lda & 3) || (ldc & 3))
     return PANGU_E_SHAPE;
-  if (act != PANGU_ACT_NONE && act != PANGU_ACT_GELU && act != PANGU_ACT_GELU_BWD) return PANGU_E_ARG;
-  if (act == PANGU_ACT_GELU_BWD && !aux) return PANGU_E_NULL;
+  if (act != PANGU_ACT_NONE && act != PANGU_ACT_GELU && act != PANGU_ACT_GELU_BWD && act != PANGU_ACT_ADD) return PANGU_E_ARG;
+  if ((act == PANGU_ACT_GELU_BWD || act == PANGU_ACT_ADD) && !aux) return PANGU_E_NULL;
   hipStream_t s = (hipStream_t)stream;
   static const int force_tn = getenv("PANGU_GEMM_TN") ? atoi(getenv("PANGU_GEMM_TN")) : 0;   // tuning knob
   if (force_tn == 1) return launch_tn<1>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);

@@ -6,7 +6,7 @@ import torch
 
 from . import _lib
 
-ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_ADD = 0, 1, 2, 3
 
 # fp32 projection arithmetic: False = exact f32 MFMA (default, the parity-tested headline path); True = opt-in
 # split-bf16 ("bf16x3") products on the bf16 matrix pipe (see csrc/gemm_f32x3.hip).
@@ -105,7 +105,8 @@ def window_mask(Z, H, W, device):
 
 def linear(a, weight, bias=None, act=ACT_NONE, out=None, aux=None):
     """out[M,N] = act(a[M,K] @ weight[N,K]^T + bias). `a`/`out` may be row-strided views.
-    act=GELU: aux (optional, dense [M,N]) receives the pre-activation; act=GELU_BWD: out = (a@w^T) * gelu'(aux)."""
+    act=GELU: aux (optional, dense [M,N]) receives the pre-activation; act=GELU_BWD: out = (a@w^T) * gelu'(aux);
+    act=ADD: out = a@w^T + bias + aux (residual-gradient accumulation fused into the data-gradient GEMM)."""
     lib = _lib.load()
     ap, lda = _rows(a, "linear.a")
     M, K = a.shape
@@ -118,7 +119,7 @@ def linear(a, weight, bias=None, act=ACT_NONE, out=None, aux=None):
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     op, ldc = _rows(out, "linear.out")
-    split = _F32_SPLIT and K % 8 == 0
+    split = _F32_SPLIT and K % 8 == 0 and act != ACT_ADD
     fn = lib.pangu_linear_fwd_f32x3 if split else lib.pangu_linear_fwd
     with _timed("linear_x3" if split else "linear", 2.0 * M * N * K):
         _lib.check(fn(_stream(), ap, lda, wp, bp, op, ldc, M, N, K, act,
@@ -133,8 +134,9 @@ def linear_wgrad(dc, a, want_bias=True):
     ap, lda = _rows(a, "wgrad.a")
     M, N = dc.shape
     K = a.shape[1]
-    dw = torch.zeros((N, K), dtype=torch.float32, device=dc.device)
-    db = torch.zeros((N,), dtype=torch.float32, device=dc.device) if want_bias else None
+    buf = torch.zeros((N * K + (N if want_bias else 0),), dtype=torch.float32, device=dc.device)   # one fill launch
+    dw = buf[:N * K].view(N, K)
+    db = buf[N * K:] if want_bias else None
     with _timed("wgrad", 2.0 * M * N * K):
         _lib.check(lib.pangu_linear_wgrad(_stream(), dp, lddc, ap, lda, dw.data_ptr(),
                                           db.data_ptr() if want_bias else None, M, N, K), "linear_wgrad")
@@ -180,8 +182,7 @@ def ln_residual_bwd(dout, y, gamma, branch_scale=1.0):
     N, C = y.shape
     dp, lddo = _rows(dout, "ln_bwd.dout")
     dy = torch.empty_like(y)
-    dg = torch.zeros((C,), dtype=torch.float32, device=y.device)
-    db = torch.zeros((C,), dtype=torch.float32, device=y.device)
+    dg, db = torch.zeros((2, C), dtype=torch.float32, device=y.device).unbind(0)
     _lib.check(lib.pangu_ln_residual_bwd(_stream(), dp, lddo, _chk(y, "ln_bwd.y"), _chk(gamma, "gamma"), dy.data_ptr(),
                                          dg.data_ptr(), db.data_ptr(), N, C, float(branch_scale)), "ln_residual_bwd")
     return dy, dg, db
@@ -192,8 +193,7 @@ def downsample_ln_bwd(dout, x, gamma, Z, H, W):
     xp, ldx = _rows(x, "downsample_bwd.x")
     C = x.shape[1]
     dx = torch.empty((Z * H * W, C), dtype=torch.float32, device=x.device)
-    dg = torch.zeros((4 * C,), dtype=torch.float32, device=x.device)
-    db = torch.zeros((4 * C,), dtype=torch.float32, device=x.device)
+    dg, db = torch.zeros((2, 4 * C), dtype=torch.float32, device=x.device).unbind(0)
     _lib.check(lib.pangu_downsample_ln_bwd(_stream(), _chk(dout, "dout"), xp, ldx, _chk(gamma, "gamma"), dx.data_ptr(),
                                            dg.data_ptr(), db.data_ptr(), Z, H, W, C), "downsample_ln_bwd")
     return dx, dg, db
@@ -203,8 +203,7 @@ def upsample_ln_bwd(dout, y, gamma, Z, H2, W2, H):
     lib = _lib.load()
     Co = y.shape[1] // 4
     dy = torch.empty_like(y)
-    dg = torch.zeros((Co,), dtype=torch.float32, device=y.device)
-    db = torch.zeros((Co,), dtype=torch.float32, device=y.device)
+    dg, db = torch.zeros((2, Co), dtype=torch.float32, device=y.device).unbind(0)
     _lib.check(lib.pangu_upsample_ln_bwd(_stream(), _chk(dout, "dout"), _chk(y, "y"), _chk(gamma, "gamma"),
                                          dy.data_ptr(), dg.data_ptr(), db.data_ptr(), Z, H2, W2, H, Co),
                "upsample_ln_bwd")

@@ -4,7 +4,7 @@ import torch
 from . import _lib
 from .ops import _stream, _timed
 
-ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_ADD = 0, 1, 2, 3
 BF16, F32 = 1, 0
 
 
@@ -108,8 +108,9 @@ def linear_wgrad(dc, a, want_bias=True):
     ap, lda = _rows(a, "wgrad.a")
     M, N = dc.shape
     K = a.shape[1]
-    dw = torch.zeros((N, K), dtype=torch.float32, device=dc.device)
-    db = torch.zeros((N,), dtype=torch.float32, device=dc.device) if want_bias else None
+    buf = torch.zeros((N * K + (N if want_bias else 0),), dtype=torch.float32, device=dc.device)   # one fill launch
+    dw = buf[:N * K].view(N, K)
+    db = buf[N * K:] if want_bias else None
     with _timed("wgrad_bf16", 2.0 * M * N * K):
         _lib.check(lib.pangu_linear_wgrad_bf16(_stream(), dp, lddc, ap, lda, dw.data_ptr(),
                                                db.data_ptr() if want_bias else None, M, N, K), "linear_wgrad_bf16")
@@ -137,8 +138,7 @@ def ln_residual_bwd(dout, y, gamma, branch_scale=1.0):
     N, C = y.shape
     dp, lddo = _rows(dout, "ln_bwd.dout")
     dy = torch.empty_like(y)
-    dg = torch.zeros((C,), dtype=torch.float32, device=y.device)
-    db = torch.zeros((C,), dtype=torch.float32, device=y.device)
+    dg, db = torch.zeros((2, C), dtype=torch.float32, device=y.device).unbind(0)
     _lib.check(lib.pangu_ln_residual_bwd_bf16(_stream(), dp, lddo, _p(y, "y"), _p(gamma, "gamma", torch.float32),
                                               dy.data_ptr(), dg.data_ptr(), db.data_ptr(), N, C, float(branch_scale)),
                "ln_residual_bwd_bf16")
@@ -150,8 +150,7 @@ def downsample_ln_bwd(dout, x, gamma, Z, H, W):
     xp, ldx = _rows(x, "x")
     C = x.shape[1]
     dx = torch.empty((Z * H * W, C), dtype=torch.bfloat16, device=x.device)
-    dg = torch.zeros((4 * C,), dtype=torch.float32, device=x.device)
-    db = torch.zeros((4 * C,), dtype=torch.float32, device=x.device)
+    dg, db = torch.zeros((2, 4 * C), dtype=torch.float32, device=x.device).unbind(0)
     _lib.check(lib.pangu_downsample_ln_bwd_bf16(_stream(), _p(dout, "dout"), xp, ldx, _p(gamma, "gamma", torch.float32),
                                                 dx.data_ptr(), dg.data_ptr(), db.data_ptr(), Z, H, W, C),
                "downsample_ln_bwd_bf16")
@@ -162,8 +161,7 @@ def upsample_ln_bwd(dout, y, gamma, Z, H2, W2, H):
     lib = _lib.load()
     Co = y.shape[1] // 4
     dy = torch.empty_like(y)
-    dg = torch.zeros((Co,), dtype=torch.float32, device=y.device)
-    db = torch.zeros((Co,), dtype=torch.float32, device=y.device)
+    dg, db = torch.zeros((2, Co), dtype=torch.float32, device=y.device).unbind(0)
     _lib.check(lib.pangu_upsample_ln_bwd_bf16(_stream(), _p(dout, "dout"), _p(y, "y"), _p(gamma, "gamma", torch.float32),
                                               dy.data_ptr(), dg.data_ptr(), db.data_ptr(), Z, H2, W2, H, Co),
                "upsample_ln_bwd_bf16")

@@ -51,6 +51,19 @@ def test_linear_bf16(P, M, N, K, act, bias, out_f32):
     assert rel_err(got, ref) < (2e-4 if out_f32 else ROUND)
 
 
+@pytest.mark.parametrize("M,N,K,bias", [(4099, 192, 768, False), (1531, 384, 1152, True), (5000, 192, 192, False)])
+def test_linear_bf16_add_epilogue(P, M, N, K, bias):
+    """act=ADD: out = a @ w^T + bias + aux (bf16 addend), the residual-gradient accumulation of the block backward."""
+    from pangu_pytorch_amd import ops_bf16 as ob
+    a = synth.uniform((M, K), 14).to(BF)
+    w = synth.uniform((N, K), 15, 1.0 / K ** 0.5).to(BF)
+    b = synth.uniform((N,), 16, 0.5) if bias else None
+    add = synth.uniform((M, N), 17, 2.0).to(BF)
+    ref = a.float() @ w.float().t() + add.float() + (b if bias else 0.0)
+    got = ob.linear(a.cuda(), w.cuda(), b.cuda() if bias else None, act=ob.ACT_ADD, aux=add.cuda())
+    assert got.dtype == BF and rel_err(got, ref) < ROUND
+
+
 def test_linear_bf16_gelu_aux_and_bwd(P):
     from pangu_pytorch_amd import ops_bf16 as ob
     M, N, K = 1500, 768, 192

@@ -75,6 +75,18 @@ def test_linear(P, M, N, K, act, bias):
     assert rel_err(got, ref) < TIGHT
 
 
+@pytest.mark.parametrize("M,N,K,bias", [(4099, 192, 768, False), (1531, 384, 1152, True), (650, 160, 384, False)])
+def test_linear_add_epilogue(P, M, N, K, bias):
+    """act=ADD: out = a @ w^T + bias + aux (the residual-gradient accumulation of the block backward)."""
+    a = synth.uniform((M, K), 14)
+    w = synth.uniform((N, K), 15, 1.0 / K ** 0.5)
+    b = synth.uniform((N,), 16, 0.5) if bias else None
+    add = synth.uniform((M, N), 17, 2.0)
+    ref = a @ w.t() + add + (b if bias else 0.0)
+    got = P.ops.linear(a.cuda(), w.cuda(), b.cuda() if bias else None, act=P.ops.ACT_ADD, aux=add.cuda())
+    assert rel_err(got, ref) < TIGHT
+
+
 def test_linear_strided_rows(P):
     a_full = synth.uniform((700, 384), 21).cuda()
     w = synth.uniform((192, 192), 22, 0.07).cuda()
