@@ -173,9 +173,12 @@ int launch_wgrad_bf16(hipStream_t s, const u16* dC, int lddc, const u16* A, int 
   constexpr int WB_M = TK == 3 ? 32 : 64;
   const int n_tiles = (N + WB_N - 1) / WB_N, k_tiles = (K + BKC - 1) / BKC;
   const int tiles = n_tiles * k_tiles;
-  // ~2 rounds of the 512 resident workgroups: long token slabs keep the fp32 atomic tail (98 KB per workgroup) small
-  static const int target = getenv("PANGU_WGRAD_WGS") ? atoi(getenv("PANGU_WGRAD_WGS")) : 768;   // tuning knob
-  int split = ((target + tiles - 1) / tiles + 7) & ~7;              // equal share per XCD
+  // ONE round of the 512 resident workgroups (2 per CU), as many M-splits as fit: every workgroup ends with 98 KB of fp32
+  // atomics into dW, which costs 10-45 % of the kernel at these shapes, so fewer, longer workgroups win as long as no
+  // second (partial) round appears (measured sweep, tools/bench_kernels.py wgrad_bf16).  PANGU_WGRAD_WGS overrides.
+  static const int knob = getenv("PANGU_WGRAD_WGS") ? atoi(getenv("PANGU_WGRAD_WGS")) : 0;
+  int split = knob ? (((knob + tiles - 1) / tiles + 7) & ~7) : (512 / tiles) & ~7;   // multiple of 8: equal share per XCD
+  if (split < 8) split = 8;
   int rows = ((M + split - 1) / split + 63) / 64 * 64;
   if (rows < 256) rows = 256;
   split = ((M + rows - 1) / rows + 7) & ~7;                         // grid padded to whole XCD rounds (empty slabs exit)

@@ -170,7 +170,7 @@ int launch_wgrad(hipStream_t s, const float* dC, int lddc, const float* A, int l
   const int n_tiles = (N + WG_BN - 1) / WG_BN, k_tiles = (K + BKC - 1) / BKC;
   const int tiles = n_tiles * k_tiles;
   // ~3 workgroups per CU slot-pair: enough M-splits to fill 256 CUs x 2, slabs a multiple of the K-step
-  static const int target = getenv("PANGU_WGRAD_WGS") ? atoi(getenv("PANGU_WGRAD_WGS")) : 1536;   // tuning knob
+  static const int target = getenv("PANGU_WGRAD_WGS") ? atoi(getenv("PANGU_WGRAD_WGS")) : 768;    // tuning knob (measured sweep: 768 best)
   int split = ((target + tiles - 1) / tiles + 7) & ~7;              // equal share per XCD
   int rows = ((M + split - 1) / split + WG_BM - 1) / WG_BM * WG_BM;
   if (rows < 8 * WG_BM) rows = 8 * WG_BM;
