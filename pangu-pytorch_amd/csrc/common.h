@@ -125,11 +125,24 @@ __device__ inline unsigned pack_bf16x2(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
 }
 
-__device__ inline float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Sum over the 16 lanes of a DPP row, result in every lane: four v_add_f32 with DPP operand swizzles (quad_perm
+// [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror) -- no LDS crossbar round trips (ds_bpermute) for these steps.
+__device__ inline float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
   return v;
 }
+// Sum over aligned groups of LPR lanes (16, 32 or 64), result in every lane of the group
+template <int LPR>
+__device__ inline float group_sum(float v) {
+  v = row16_sum(v);
+  if (LPR >= 32) v += __shfl_xor(v, 16, 64);
+  if (LPR >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ inline float wave_sum(float v) { return group_sum<64>(v); }
 
 static inline int pangu_launch_status() {
   hipError_t e = hipGetLastError();

@@ -111,15 +111,13 @@ __global__ __launch_bounds__(256) void ln_residual_bf16_v8_kernel(const u16* __r
         v[2 * c + 1] = __builtin_bit_cast(float, yv[u][c] & 0xFFFF0000u);
       }
       float s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-#pragma unroll
-      for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      s = group_sum<LPR>(s);
       const float mean = s * inv_c;
       float q = 0.f;
 #pragma unroll
       for (int c = 0; c < 8; ++c) { const float d = v[c] - mean; q += d * d; }
       if (!act) q = 0.f;                       // idle lanes hold zeros, not (0 - mean)^2
-#pragma unroll
-      for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+      q = group_sum<LPR>(q);
       const float rstd = rsqrtf(q * inv_c + LN_EPS);
       if (ok[u]) {
         u32x4 o4;

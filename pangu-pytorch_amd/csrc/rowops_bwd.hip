@@ -106,6 +106,108 @@ __global__ __launch_bounds__(256) void ln_residual_bwd_kernel(const T* __restric
   flush_param_grads<NV>(dg, db, nvec, lane, wave, dgamma, dbeta, red);
 }
 
+// bf16 fast path of the post-norm residual backward for C % 8 == 0, C <= 512 (the model's 192 / 384): 16-B loads (8 channels
+// per lane), LPR lanes per row (32 -> two rows per wave at C <= 256), gamma and the dgamma/dbeta accumulators in registers,
+// both inputs of two row groups requested together before any arithmetic, persistent grid.  Same math as row_ln_bwd.
+template <int LPR>
+__global__ __launch_bounds__(256) void ln_residual_bwd_bf16_v8_kernel(const u16* __restrict__ dout, int lddo,
+                                                                      const u16* __restrict__ yin,
+                                                                      const float* __restrict__ gamma, u16* __restrict__ dy,
+                                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                      int N, int C, float branch_scale) {
+  constexpr int RPW = 64 / LPR, UNR = 2, GROUPS = 4 * RPW;
+  __shared__ float red[2 * GROUPS * (LPR * 8)];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, l = lane % LPR;
+  const bool act = l * 8 < C;
+  float gm[8], dg[8], db[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    gm[c] = act ? gamma[l * 8 + c] : 0.f;
+    dg[c] = 0.f;
+    db[c] = 0.f;
+  }
+  const float inv_c = 1.0f / C;
+  const int rows_per_block = 4 * RPW * UNR;
+  for (int base = blockIdx.x * rows_per_block + wave * RPW * UNR; base < N; base += gridDim.x * rows_per_block) {
+    u32x4 yv[UNR], gv[UNR];
+    bool ok[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int row = base + u * RPW + sub;
+      ok[u] = act && row < N;
+      yv[u] = u32x4{0u, 0u, 0u, 0u};
+      gv[u] = u32x4{0u, 0u, 0u, 0u};
+      if (ok[u]) {
+        yv[u] = *reinterpret_cast<const u32x4*>(yin + (size_t)row * C + l * 8);
+        gv[u] = *reinterpret_cast<const u32x4*>(dout + (size_t)row * lddo + l * 8);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      float y[8], g[8];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        y[2 * c] = __builtin_bit_cast(float, yv[u][c] << 16);
+        y[2 * c + 1] = __builtin_bit_cast(float, yv[u][c] & 0xFFFF0000u);
+        g[2 * c] = __builtin_bit_cast(float, gv[u][c] << 16) * branch_scale;
+        g[2 * c + 1] = __builtin_bit_cast(float, gv[u][c] & 0xFFFF0000u) * branch_scale;
+      }
+      float s = ((y[0] + y[1]) + (y[2] + y[3])) + ((y[4] + y[5]) + (y[6] + y[7]));
+      s = group_sum<LPR>(s);
+      const float mean = s * inv_c;
+      float q = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { const float d = y[c] - mean; q += d * d; }
+      if (!act) q = 0.f;
+      q = group_sum<LPR>(q);
+      const float rstd = rsqrtf(q * inv_c + LN_EPS);
+      float gg[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        y[c] = act ? (y[c] - mean) * rstd : 0.f;        // xhat
+        gg[c] = g[c] * gm[c];
+        dg[c] += g[c] * y[c];
+        db[c] += g[c];
+        s1 += gg[c];
+        s2 += gg[c] * y[c];
+      }
+      s1 = group_sum<LPR>(s1);
+      s2 = group_sum<LPR>(s2);
+      const float m1 = s1 * inv_c, m2 = s2 * inv_c;
+      if (ok[u]) {
+        u32x4 o4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          o4[c] = pack_bf16x2((gg[2 * c] - m1 - y[2 * c] * m2) * rstd, (gg[2 * c + 1] - m1 - y[2 * c + 1] * m2) * rstd);
+        const int row = base + u * RPW + sub;
+        *reinterpret_cast<u32x4*>(dy + (size_t)row * C + l * 8) = o4;
+      }
+    }
+  }
+  // flush the per-lane parameter gradients: [GROUPS][C] through LDS, one atomic per channel and workgroup
+  const int grp = wave * RPW + sub;
+  constexpr int CW = LPR * 8;
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      red[grp * CW + l * 8 + c] = dg[c];
+      red[(GROUPS + grp) * CW + l * 8 + c] = db[c];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int gq = 0; gq < GROUPS; ++gq) {
+      a += red[gq * CW + c];
+      b += red[(GROUPS + gq) * CW + c];
+    }
+    atomicAdd(&dgamma[c], a);
+    atomicAdd(&dbeta[c], b);
+  }
+}
+
 template <int NV, typename T>
 __global__ __launch_bounds__(256) void downsample_ln_bwd_kernel(const T* __restrict__ dout,
                                                                 const T* __restrict__ x, int ldx,
@@ -287,6 +389,18 @@ extern "C" int pangu_ln_residual_bwd_bf16(pangu_stream_t stream, const void* dou
   if (N <= 0 || C <= 0 || (C & 3) || C > 1024 || lddo < C || (lddo & 3)) return PANGU_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   dim3 g(row_grid(N)), b(256);
+  if ((C & 7) == 0 && C <= 512 && (lddo & 7) == 0) {
+    if (C <= 256) {
+      const int blocks = (N + 15) / 16;
+      hipLaunchKernelGGL(ln_residual_bwd_bf16_v8_kernel<32>, dim3(blocks < 2048 ? blocks : 2048), b, 0, s, (const u16*)dout,
+                         lddo, (const u16*)y, gamma, (u16*)dy, dgamma, dbeta, N, C, branch_scale);
+    } else {
+      const int blocks = (N + 7) / 8;
+      hipLaunchKernelGGL(ln_residual_bwd_bf16_v8_kernel<64>, dim3(blocks < 2048 ? blocks : 2048), b, 0, s, (const u16*)dout,
+                         lddo, (const u16*)y, gamma, (u16*)dy, dgamma, dbeta, N, C, branch_scale);
+    }
+    return pangu_launch_status();
+  }
   PANGU_NV_DISPATCH(C, ln_residual_bwd_kernel, u16, (const u16*)dout, lddo, (const u16*)y, gamma, (u16*)dy, dgamma, dbeta, N,
                     C, branch_scale);
   return pangu_launch_status();

@@ -128,6 +128,10 @@ def rows():
         ob_out = torch.empty_like(yb)
         ms = timeit(lambda: ob.ln_residual(yb, sb, g, b, out=ob_out))
         print(f"ln_residual bf16 N={N} C={C}: {ms:7.3f} ms  {3.0 * N * C * 2 / ms / 1e6:7.1f} GB/s")
+        ms = timeit(lambda: ob.ln_residual_bwd(sb, yb, g, 1.0))
+        print(f"ln_residual_bwd bf16 N={N} C={C}: {ms:7.3f} ms  {3.0 * N * C * 2 / ms / 1e6:7.1f} GB/s")
+        ms = timeit(lambda: ops.ln_residual_bwd(s, y, g, 1.0))
+        print(f"ln_residual_bwd f32  N={N} C={C}: {ms:7.3f} ms  {3.0 * N * C * 4 / ms / 1e6:7.1f} GB/s")
 
 
 if __name__ == "__main__":
