@@ -182,6 +182,13 @@ int pangu_window_attn_fwd_bf16(pangu_stream_t stream, const void* qkv, const voi
 
 int pangu_ln_residual_fwd_bf16(pangu_stream_t stream, const void* y, const void* shortcut, int lds, const float* gamma,
                                const float* beta, void* out, int ldo, int N, int C, float branch_scale);
+/* Projection + post-norm residual in one launch (inference path of layers.py:250-251):
+ *   out[M,N] = shortcut[M,N] + LayerNorm(A[M,K] @ W[N,K]^T + bias) * gamma + beta,   N = 192 or 384 (the tile spans the row).
+ * A, W, shortcut (dense, ld = N), out (row stride ldo) bf16; bias (may be NULL), gamma, beta fp32; statistics in fp32 on the
+ * accumulators.  K % 8 == 0.  Replaces pangu_linear_fwd_bf16 + pangu_ln_residual_fwd_bf16 (branch scale 1). */
+int pangu_linear_ln_residual_fwd_bf16(pangu_stream_t stream, const void* A, int lda, const void* W, const float* bias,
+                                      const void* shortcut, const float* gamma, const float* beta, void* out, int ldo, int M,
+                                      int N, int K);
 int pangu_downsample_ln_fwd_bf16(pangu_stream_t stream, const void* x, int ldx, const float* gamma, const float* beta,
                                  void* out, int Z, int H, int W, int C);
 int pangu_upsample_ln_fwd_bf16(pangu_stream_t stream, const void* y, const float* gamma, const float* beta, void* out,

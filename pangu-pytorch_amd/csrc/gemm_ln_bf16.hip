@@ -1,0 +1,218 @@
+// bf16 projection GEMM with the post-norm residual fused into its epilogue (inference path), gfx950:
+//   out[M,N] = shortcut[M,N] + LayerNorm(A[M,K] @ W[N,K]^T + bias) * gamma + beta        (reference layers.py:250-251)
+// for N = 192 or 384 (the model's two widths): the workgroup tile is 128 rows x the WHOLE row (wave grid 2 x WNW, wave
+// tile 64 x 96, WNW = N / 96), so the row statistics never leave the workgroup.  Same operand staging, LDS swizzle and
+// swapped-operand MFMA layout as gemm_bf16.hip (a lane owns 4 consecutive output columns of one row).
+// Epilogue: the shortcut patch is staged in LDS with coalesced 16-B loads; each wave reduces (sum, sum of squares) of its
+// 96 columns in fp32 straight from the accumulators (in-lane + 2 shuffles), the WNW partials of a row meet in a 4-KB LDS
+// table behind ONE barrier, then normalise / gamma / beta / residual run in the MFMA layout and the rows leave as 16-B
+// segments.  Saves the branch's HBM round trip (write y, read y, read shortcut, write out -> read shortcut, write out):
+// the standalone LN-residual kernel is HBM-bound at ~5 TB/s and was 12 % of the bf16 forward.
+// The statistics are taken on the fp32 accumulators, i.e. BEFORE the bf16 rounding the unfused path applies to y.
+#include "common.h"
+
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int LBM = 128;
+constexpr int LBK = 64;
+constexpr float LN_EPS = 1e-5f;
+
+__device__ inline unsigned pack2(float a, float b) { return pack_bf16x2(a, b); }
+__device__ inline int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }   // byte offset
+
+template <int WNW>
+__global__ __launch_bounds__(128 * WNW, 2) void gemm_ln_residual_bf16_kernel(
+    const u16* __restrict__ A, int lda, const u16* __restrict__ W, const float* __restrict__ bias,
+    const u16* __restrict__ shortcut, const float* __restrict__ gamma, const float* __restrict__ beta, u16* __restrict__ out,
+    int ldo, int M, int K) {
+  constexpr int NT = 128 * WNW;
+  constexpr int BN = 96 * WNW;                             // = N
+  constexpr int STAGE = (LBM + BN) * 128;                  // bytes per LDS stage
+  constexpr int NCH = (LBM + BN) * 8 / NT;                 // 16-B chunks staged per thread and K-step
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int m0 = blockIdx.x * LBM;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WNW, wn = wave % WNW;
+  const int lc = lane & 15, lg = lane >> 4;
+
+  const u16* src[NCH];
+  int dst[NCH];
+  const int kchunk = tid & 7;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int row = (tid >> 3) + (NT / 8) * i;              // 0 .. LBM+BN-1
+    if (row < LBM) {
+      int r = m0 + row;
+      r = r < M ? r : M - 1;
+      src[i] = A + (size_t)r * lda + kchunk * 8;
+    } else {
+      src[i] = W + (size_t)(row - LBM) * K + kchunk * 8;
+    }
+    dst[i] = (row < LBM ? swz(row, kchunk) : LBM * 128 + swz(row - LBM, kchunk));
+  }
+  const int KT = (K + LBK - 1) / LBK;
+  u32x4 stg[NCH];
+  auto fetch = [&](int kt) {
+    const bool in = kt * LBK + kchunk * 8 < K;             // K % 8 == 0: a chunk is entirely inside or outside
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      stg[i] = in ? *reinterpret_cast<const u32x4*>(src[i] + (size_t)kt * LBK) : u32x4{0u, 0u, 0u, 0u};
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) *reinterpret_cast<u32x4*>(smem + buf * STAGE + dst[i]) = stg[i];
+  };
+
+  f32x4 acc[4][6];                                         // [m tile 16][n tile 16], lane: 4 consecutive n of row m = lc
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const bool more = kt + 1 < KT;
+    if (more) fetch(kt + 1);
+    const unsigned char* As = smem + (kt & 1) * STAGE;
+    const unsigned char* Ws = As + LBM * 128;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[4], fw[6];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(As + swz(wm * 64 + i * 16 + lc, kk * 4 + lg));
+#pragma unroll
+      for (int j = 0; j < 6; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(Ws + swz(wn * 96 + j * 16 + lc, kk * 4 + lg));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);   // D[n][m]
+    }
+    if (more) stash((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue.  lane (lg, lc) of tile (i, j) holds y[m = wm*64 + 16i + lc][n = wn*96 + 16j + 4lg + r], r = 0..3
+  constexpr int EP_LD = 96 * 2 + 16;                       // bytes per patch row
+  constexpr int CPR = 12;                                  // 16-B chunks per patch row
+  unsigned char* ep = smem + wave * (64 * EP_LD);
+  float* stats = reinterpret_cast<float*>(smem + 2 * WNW * 64 * EP_LD);      // [2 wm][WNW][64 rows][sum, sumsq]
+  const int wave_n0 = wn * 96, wave_m0 = m0 + wm * 64;
+  const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      out, 0, (int)(((size_t)(M - 1) * ldo + BN) * sizeof(u16)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<u16*>(shortcut), 0, (int)((size_t)M * BN * sizeof(u16)), 0x00020000);
+  // shortcut patch [64][96] -> LDS (rows >= M arrive as zeros)
+#pragma unroll
+  for (int it = 0; it < CPR; ++it) {
+    const int f = lane + 64 * it, row = f / CPR, ch = f - row * CPR;
+    const unsigned off = ((unsigned)(wave_m0 + row) * (unsigned)BN + (unsigned)(wave_n0 + ch * 8)) * 2u;
+    *reinterpret_cast<u32x4*>(ep + row * EP_LD + ch * 16) = __builtin_amdgcn_raw_buffer_load_b128(s_rsrc, (int)off, 0, 0);
+  }
+  // y = acc + bias (kept in acc), per-row partial statistics of this wave's 96 columns
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + wave_n0 + j * 16 + lg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i][j] += bv;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s += acc[i][j][r];
+        q = fmaf(acc[i][j][r], acc[i][j][r], q);
+      }
+    s += __shfl_xor(s, 16, 64);
+    q += __shfl_xor(q, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    q += __shfl_xor(q, 32, 64);
+    if (lg == 0) {
+      float* st = stats + (((wm * WNW + wn) * 64) + i * 16 + lc) * 2;
+      st[0] = s;
+      st[1] = q;
+    }
+  }
+  __syncthreads();
+  f32x4 gv[6], bt[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    gv[j] = *reinterpret_cast<const f32x4*>(gamma + wave_n0 + j * 16 + lg * 4);
+    bt[j] = *reinterpret_cast<const f32x4*>(beta + wave_n0 + j * 16 + lg * 4);
+  }
+  constexpr float INV_C = 1.0f / BN;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int w = 0; w < WNW; ++w) {
+      const float* st = stats + (((wm * WNW + w) * 64) + i * 16 + lc) * 2;
+      s += st[0];
+      q += st[1];
+    }
+    const float mean = s * INV_C;
+    const float rstd = rsqrtf(fmaxf(q * INV_C - mean * mean, 0.f) + LN_EPS);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      unsigned char* slot = ep + (i * 16 + lc) * EP_LD + (j * 16 + lg * 4) * 2;
+      const u32x2 xp = *reinterpret_cast<const u32x2*>(slot);
+      f32x4 v = (acc[i][j] - mean) * rstd * gv[j] + bt[j];
+      v[0] += __builtin_bit_cast(float, xp[0] << 16);
+      v[1] += __builtin_bit_cast(float, xp[0] & 0xFFFF0000u);
+      v[2] += __builtin_bit_cast(float, xp[1] << 16);
+      v[3] += __builtin_bit_cast(float, xp[1] & 0xFFFF0000u);
+      *reinterpret_cast<u32x2*>(slot) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+    }
+    // read back rows 16i .. 16i+15 of the patch: 16 * 12 chunks of 16 B -> whole row segments
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int f = lane + 64 * it;
+      const int row = i * 16 + f / CPR, ch = f % CPR;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(ep + row * EP_LD + ch * 16);
+      const unsigned off = ((unsigned)(wave_m0 + row) * (unsigned)ldo + (unsigned)(wave_n0 + ch * 8)) * 2u;
+      __builtin_amdgcn_raw_buffer_store_b128(v, o_rsrc, (int)off, 0, 0);
+    }
+  }
+}
+
+template <int WNW>
+int launch_ln(hipStream_t s, const u16* A, int lda, const u16* W, const float* bias, const u16* shortcut, const float* gamma,
+              const float* beta, u16* out, int ldo, int M, int K) {
+  constexpr int BN = 96 * WNW;
+  const size_t stages = 2 * (size_t)(LBM + BN) * 128;
+  const size_t epi = (size_t)2 * WNW * 64 * (96 * 2 + 16) + (size_t)2 * WNW * 64 * 2 * sizeof(float);
+  const size_t shm = stages > epi ? stages : epi;
+  auto kern = gemm_ln_residual_bf16_kernel<WNW>;
+  static bool attr_set = false;               // once per instantiation, outside any later graph capture
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((M + LBM - 1) / LBM), dim3(128 * WNW), shm, s, A, lda, W, bias, shortcut, gamma, beta, out, ldo,
+                     M, K);
+  return pangu_launch_status();
+}
+
+}  // namespace
+
+extern "C" int pangu_linear_ln_residual_fwd_bf16(pangu_stream_t stream, const void* A, int lda, const void* W,
+                                                 const float* bias, const void* shortcut, const float* gamma,
+                                                 const float* beta, void* out, int ldo, int M, int N, int K) {
+  if (!A || !W || !shortcut || !gamma || !beta || !out) return PANGU_E_NULL;
+  if (M <= 0 || K <= 0 || (K & 7) || lda < K || (lda & 7) || ldo < N || (ldo & 7)) return PANGU_E_SHAPE;
+  if (N != 192 && N != 384) return PANGU_E_SHAPE;          // the tile must span the whole row
+  hipStream_t s = (hipStream_t)stream;
+  if (N == 192)
+    return launch_ln<2>(s, (const u16*)A, lda, (const u16*)W, bias, (const u16*)shortcut, gamma, beta, (u16*)out, ldo, M, K);
+  return launch_ln<4>(s, (const u16*)A, lda, (const u16*)W, bias, (const u16*)shortcut, gamma, beta, (u16*)out, ldo, M, K);
+}

@@ -1,5 +1,7 @@
 """bf16 inference forward of the whole model (BASELINE configs[2]/[4]): bf16 activations + bf16 weight shadows,
 fp32 LayerNorm / softmax / accumulation, fp32 output fields.  Same launch sequence as the fp32 path."""
+import os
+
 import torch
 
 from . import ops, ops_bf16 as ob
@@ -37,14 +39,25 @@ class WeightShadow:
         return w
 
 
+_FUSE_LN = os.environ.get("PANGU_BF16_FUSE_LN", "1") != "0"      # A/B knob: 0 = separate GEMM + LN-residual launches
+
+
 def _block(blk, sh, x, Z, H, W, roll, out=None):
     """x (N,C) bf16 -> (N,C) bf16 (eval: DropPath is the identity)."""
     att = blk.attention
     qkv = ob.linear(x, sh.get(att.linear1.weight), att.linear1.bias)
     o = ob.window_attention(qkv, sh.get(att.linear1.bias), sh.get(att.earth_specific_bias), Z, H, W, att.head_number, roll)
-    y = ob.linear(o, sh.get(att.linear2.weight), att.linear2.bias)
-    x1 = ob.ln_residual(y, x, blk.norm1.weight, blk.norm1.bias)
+    C = x.shape[1]
+    fuse = _FUSE_LN and C == 192 and x.is_contiguous()      # C = 384: the 8-wave 128x384 tile loses what the fusion saves (measured)
+    if fuse:     # projection + post-norm residual in one launch: the branch never round-trips HBM
+        x1 = ob.linear_ln_residual(o, sh.get(att.linear2.weight), att.linear2.bias, x, blk.norm1.weight, blk.norm1.bias)
+    else:
+        y = ob.linear(o, sh.get(att.linear2.weight), att.linear2.bias)
+        x1 = ob.ln_residual(y, x, blk.norm1.weight, blk.norm1.bias)
     h = ob.linear(x1, sh.get(blk.linear.linear1.weight), blk.linear.linear1.bias, act=ob.ACT_GELU)
+    if fuse:
+        return ob.linear_ln_residual(h, sh.get(blk.linear.linear2.weight), blk.linear.linear2.bias, x1, blk.norm2.weight,
+                                     blk.norm2.bias, out=out)
     m = ob.linear(h, sh.get(blk.linear.linear2.weight), blk.linear.linear2.bias)
     return ob.ln_residual(m, x1, blk.norm2.weight, blk.norm2.bias, out=out)
 

@@ -52,6 +52,25 @@ def window_attention(qkv, qkv_bias, esb, Z, H, W, heads, shifted, want_lse=False
     return (out, lse) if want_lse else out
 
 
+def linear_ln_residual(a, weight, bias, shortcut, gamma, beta, out=None):
+    """out = shortcut + LayerNorm(a @ weight^T + bias) * gamma + beta in ONE launch (N = 192 or 384; inference path)."""
+    lib = _lib.load()
+    ap, lda = _rows(a, "linear_ln.a")
+    M, K = a.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K or a.dtype != torch.bfloat16 or shortcut.shape != (M, N) or not shortcut.is_contiguous():
+        raise RuntimeError(f"linear_ln_residual: a {tuple(a.shape)} weight {tuple(weight.shape)} shortcut {tuple(shortcut.shape)}")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    op, ldo = _rows(out, "linear_ln.out")
+    with _timed("linear_bf16", 2.0 * M * N * K):
+        _lib.check(lib.pangu_linear_ln_residual_fwd_bf16(
+            _stream(), ap, lda, _p(weight, "weight"), _p(bias, "bias", torch.float32) if bias is not None else None,
+            _p(shortcut, "shortcut"), _p(gamma, "gamma", torch.float32), _p(beta, "beta", torch.float32), op, ldo, M, N, K),
+            "linear_ln_residual_fwd_bf16")
+    return out
+
+
 def ln_residual(y, shortcut, gamma, beta, out=None, branch_scale=1.0):
     lib = _lib.load()
     N, C = y.shape

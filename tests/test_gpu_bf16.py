@@ -64,6 +64,28 @@ def test_linear_bf16_add_epilogue(P, M, N, K, bias):
     assert got.dtype == BF and rel_err(got, ref) < ROUND
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 192, 192), (4099, 192, 768), (1531, 384, 384), (777, 384, 1536), (128, 384, 64)])
+@pytest.mark.parametrize("strided_out", [False, True])
+def test_linear_ln_residual_bf16(P, M, N, K, strided_out):
+    """Fused projection + post-norm residual == linear -> LayerNorm -> + shortcut (reference layers.py:250-251)."""
+    from pangu_pytorch_amd import ops_bf16 as ob
+    a = synth.uniform((M, K), 71).to(BF)
+    w = synth.uniform((N, K), 72, 1.0 / K ** 0.5).to(BF)
+    b = synth.uniform((N,), 73, 0.5)
+    sc = synth.uniform((M, N), 74, 1.5).to(BF)
+    g, be = synth.uniform((N,), 75, 0.5, 1.0), synth.uniform((N,), 76, 0.3)
+    y = a.float() @ w.float().t() + b
+    ref = sc.float() + torch.nn.functional.layer_norm(y, (N,), g, be, 1e-5)
+    out = None
+    if strided_out:
+        full = torch.zeros((M, 2 * N), dtype=BF, device="cuda")
+        out = full[:, N:]
+    got = ob.linear_ln_residual(a.cuda(), w.cuda(), b.cuda(), sc.cuda(), g.cuda(), be.cuda(), out=out)
+    assert got.dtype == BF and rel_err(got, ref) < ROUND
+    if strided_out:
+        assert float(full[:, :N].float().abs().max()) == 0.0
+
+
 def test_linear_bf16_gelu_aux_and_bwd(P):
     from pangu_pytorch_amd import ops_bf16 as ob
     M, N, K = 1500, 768, 192
