@@ -111,6 +111,13 @@ int pangu_ln_residual_fwd(pangu_stream_t stream, const float* y, const float* sh
                           const float* gamma, const float* beta, float* out, int ldo, float* mean_rstd,
                           int N, int C, float branch_scale);
 
+/* Projection + post-norm residual in one launch (inference path of layers.py:250-251), fp32, N = 192 only (the GEMM tile
+ * spans the whole row):  out[M,N] = shortcut[M,N] + branch_scale * (LayerNorm(A[M,K] @ W[N,K]^T + bias) * gamma + beta).
+ * shortcut / out row strides lds / ldo; bias may be NULL; K % 16 == 0.  Replaces pangu_linear_fwd + pangu_ln_residual_fwd. */
+int pangu_linear_ln_residual_fwd(pangu_stream_t stream, const float* A, int lda, const float* W, const float* bias,
+                                 const float* shortcut, int lds, const float* gamma, const float* beta, float* out, int ldo,
+                                 int M, int N, int K, float branch_scale);
+
 /* Backward of the LayerNorm branch of pangu_ln_residual_fwd (the shortcut's gradient is dout itself):
  *   dy [N][C] overwritten;  dgamma[C], dbeta[C] ACCUMULATED (atomics).  dout may be row-strided (lddo). */
 int pangu_ln_residual_bwd(pangu_stream_t stream, const float* dout, int lddo, const float* y, const float* gamma,

@@ -3,6 +3,8 @@
 Token tensors are (B, N, C); B is folded into rows for projections / LayerNorm and looped for the
 geometry-dependent kernels (the reference itself is B=1 only, models/layers.py:219,227).
 """
+import os
+
 import torch
 
 from . import ops
@@ -26,6 +28,9 @@ def _tok2d(x):
     if x.stride(2) != 1 or (B > 1 and x.stride(0) != N * x.stride(1)):
         x = x.contiguous()
     return x.as_strided((B * N, C), (x.stride(1), 1), x.storage_offset())
+
+
+_FUSE_LN = os.environ.get("PANGU_F32_FUSE_LN", "1") != "0"       # A/B knob: 0 = separate GEMM + LN-residual launches
 
 
 def mlp(m, x2d):
@@ -62,14 +67,23 @@ def earth_block(blk, x, Z, H, W, roll, out=None):
         o = torch.cat([ops.window_attention(qkv[b * N:(b + 1) * N], att.linear1.bias, esb, Z, H, W,
                                             att.head_number, roll) for b in range(B)], 0) if B > 1 else \
             ops.window_attention(qkv, att.linear1.bias, esb, Z, H, W, att.head_number, roll)
-        y = ops.linear(o, att.linear2.weight, att.linear2.bias)
-        x1 = ops.ln_residual(y, x2, blk.norm1.weight, blk.norm1.bias, branch_scale=s1)
+        if _FUSE_LN and C == 192:     # projection + post-norm residual in one launch (the tile spans the row at C = 192)
+            x1 = ops.linear_ln_residual(o, att.linear2.weight, att.linear2.bias, x2, blk.norm1.weight, blk.norm1.bias,
+                                        branch_scale=s1)
+        else:
+            y = ops.linear(o, att.linear2.weight, att.linear2.bias)
+            x1 = ops.ln_residual(y, x2, blk.norm1.weight, blk.norm1.bias, branch_scale=s1)
     else:
         x1 = x2
     if s2 != 0.0:
-        m = mlp(blk.linear, x1)
         o2 = _tok2d(out) if out is not None else None
-        x2o = ops.ln_residual(m, x1, blk.norm2.weight, blk.norm2.bias, out=o2, branch_scale=s2)
+        if _FUSE_LN and C == 192:
+            h = ops.linear(x1, blk.linear.linear1.weight, blk.linear.linear1.bias, act=ops.ACT_GELU)
+            x2o = ops.linear_ln_residual(h, blk.linear.linear2.weight, blk.linear.linear2.bias, x1, blk.norm2.weight,
+                                         blk.norm2.bias, out=o2, branch_scale=s2)
+        else:
+            m = mlp(blk.linear, x1)
+            x2o = ops.ln_residual(m, x1, blk.norm2.weight, blk.norm2.bias, out=o2, branch_scale=s2)
     else:
         x2o = x1
         if out is not None:

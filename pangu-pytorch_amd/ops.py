@@ -127,6 +127,25 @@ def linear(a, weight, bias=None, act=ACT_NONE, out=None, aux=None):
     return out
 
 
+def linear_ln_residual(a, weight, bias, shortcut, gamma, beta, out=None, branch_scale=1.0):
+    """out = shortcut + branch_scale * (LayerNorm(a @ weight^T + bias) * gamma + beta) in ONE launch (N = 192; inference)."""
+    lib = _lib.load()
+    ap, lda = _rows(a, "linear_ln.a")
+    M, K = a.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K or tuple(shortcut.shape) != (M, N):
+        raise RuntimeError(f"linear_ln_residual: a {tuple(a.shape)} weight {tuple(weight.shape)} shortcut {tuple(shortcut.shape)}")
+    sp, lds = _rows(shortcut, "linear_ln.shortcut")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    op, ldo = _rows(out, "linear_ln.out")
+    with _timed("linear_ln", 2.0 * M * N * K):      # its own bucket: not the plain GEMM kernel of bench.py's roofline
+        _lib.check(lib.pangu_linear_ln_residual_fwd(
+            _stream(), ap, lda, _chk(weight, "linear_ln.weight"), _chk(bias, "linear_ln.bias") if bias is not None else None,
+            sp, lds, _chk(gamma, "gamma"), _chk(beta, "beta"), op, ldo, M, N, K, float(branch_scale)), "linear_ln_residual_fwd")
+    return out
+
+
 def linear_wgrad(dc, a, want_bias=True):
     """dW[N,K] = dc[M,N]^T @ a[M,K], db[N] = colsum(dc) (fp32 atomics into zero-initialised buffers)."""
     lib = _lib.load()

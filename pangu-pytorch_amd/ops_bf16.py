@@ -63,7 +63,7 @@ def linear_ln_residual(a, weight, bias, shortcut, gamma, beta, out=None):
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
     op, ldo = _rows(out, "linear_ln.out")
-    with _timed("linear_bf16", 2.0 * M * N * K):
+    with _timed("linear_ln_bf16", 2.0 * M * N * K):
         _lib.check(lib.pangu_linear_ln_residual_fwd_bf16(
             _stream(), ap, lda, _p(weight, "weight"), _p(bias, "bias", torch.float32) if bias is not None else None,
             _p(shortcut, "shortcut"), _p(gamma, "gamma", torch.float32), _p(beta, "beta", torch.float32), op, ldo, M, N, K),

@@ -87,6 +87,33 @@ def test_linear_add_epilogue(P, M, N, K, bias):
     assert rel_err(got, ref) < TIGHT
 
 
+@pytest.mark.parametrize("M,K,bias,scale", [(1000, 192, True, 1.0), (4099, 768, True, 1.25), (777, 192, False, 1.0),
+                                              (128, 16, True, 0.5)])
+@pytest.mark.parametrize("strided", [False, True])
+def test_linear_ln_residual(P, M, K, bias, scale, strided):
+    """Fused projection + post-norm residual == linear -> LayerNorm -> shortcut + scale * (.) (reference layers.py:250-251)."""
+    N = 192
+    a = synth.uniform((M, K), 81)
+    w = synth.uniform((N, K), 82, 1.0 / K ** 0.5)
+    b = synth.uniform((N,), 83, 0.5) if bias else None
+    sc = synth.uniform((M, N), 84, 1.5)
+    g, be = synth.uniform((N,), 85, 0.5, 1.0), synth.uniform((N,), 86, 0.3)
+    y = a @ w.t() + (b if bias else 0.0)
+    ref = sc + scale * torch.nn.functional.layer_norm(y, (N,), g, be, 1e-5)
+    out, scd = None, sc.cuda()
+    if strided:
+        full = torch.zeros((M, 2 * N), device="cuda")
+        out = full[:, N:]
+        scf = torch.zeros((M, 2 * N), device="cuda")
+        scf[:, :N] = scd
+        scd = scf[:, :N]
+    got = P.ops.linear_ln_residual(a.cuda(), w.cuda(), b.cuda() if bias else None, scd, g.cuda(), be.cuda(), out=out,
+                                   branch_scale=scale)
+    assert rel_err(got, ref) < TIGHT
+    if strided:
+        assert float(full[:, :N].abs().max()) == 0.0
+
+
 def test_linear_strided_rows(P):
     a_full = synth.uniform((700, 384), 21).cuda()
     w = synth.uniform((192, 192), 22, 0.07).cuda()

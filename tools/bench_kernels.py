@@ -73,6 +73,18 @@ def gemm_bf16(lib_compare):
         print(line)
 
 
+def gemm_ln():
+    for M, N, K, name in ((521280, 192, 192, "s0 proj+LN"), (521280, 192, 768, "s0 mlp2+LN")):
+        a = torch.randn(M, K, device="cuda")
+        w = torch.randn(N, K, device="cuda") / K ** 0.5
+        b, g, be = torch.randn(N, device="cuda"), torch.ones(N, device="cuda"), torch.zeros(N, device="cuda")
+        sc = torch.randn(M, N, device="cuda")
+        out, y = torch.empty((M, N), device="cuda"), torch.empty((M, N), device="cuda")
+        ms = timeit(lambda: ops.linear_ln_residual(a, w, b, sc, g, be, out=out))
+        ms2 = timeit(lambda: ops.ln_residual(ops.linear(a, w, b, out=y), sc, g, be, out=out))
+        print(f"{name:12s} M={M:6d} N={N:4d} K={K:4d}  fused {ms:7.3f} ms {2.0 * M * N * K / ms / 1e9:6.1f} TF/s   | separate {ms2:7.3f} ms")
+
+
 def gemm_ln_bf16():
     from pangu_pytorch_amd import ops_bf16 as ob
     bf = torch.bfloat16
@@ -153,5 +165,5 @@ def rows():
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
     {"gemm": lambda: gemm("--lib-compare" in sys.argv), "attn": attn, "rows": rows,
-     "gemm_bf16": lambda: gemm_bf16("--lib-compare" in sys.argv), "attn_bf16": attn_bf16, "gemm_ln_bf16": gemm_ln_bf16,
+     "gemm_bf16": lambda: gemm_bf16("--lib-compare" in sys.argv), "attn_bf16": attn_bf16, "gemm_ln_bf16": gemm_ln_bf16, "gemm_ln": gemm_ln,
      "wgrad_bf16": lambda: wgrad(True), "wgrad": lambda: wgrad(False)}[what]()
