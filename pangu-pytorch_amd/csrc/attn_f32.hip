@@ -284,21 +284,20 @@ __global__ __launch_bounds__(192, 3) void window_attn_f32_kernel(const float* __
 #pragma unroll
     for (int j = 0; j < 9; ++j) sA[j] = b0.v[j];
   }
-  // K and V: 144 rows x 8 float4 each = 6 per thread, staged in two halves of 3 (register budget)
+  // K and V: 144 rows x 8 float4 each = 6 + 6 per thread, all requested before the first LDS write waits
+  {
+    f32x4 kv[6], vv[6];
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    f32x4 kv[3], vv[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int f = tid + 192 * (3 * half + i), n = f >> 3, c4 = (f & 7) * 4;
+    for (int i = 0; i < 6; ++i) {
+      const int f = tid + 192 * i, n = f >> 3, c4 = (f & 7) * 4;
       const int tok = win_src_token(g, l, t, n, SHIFTED);
       const float* src = tok >= 0 ? qkv + (size_t)tok * C3 : qkv_bias;
       kv[i] = *reinterpret_cast<const f32x4*>(src + C + hd * 32 + c4);
       vv[i] = *reinterpret_cast<const f32x4*>(src + 2 * C + hd * 32 + c4);
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int f = tid + 192 * (3 * half + i), n = f >> 3, c4 = (f & 7) * 4;
+    for (int i = 0; i < 6; ++i) {
+      const int f = tid + 192 * i, n = f >> 3, c4 = (f & 7) * 4;
       *reinterpret_cast<f32x4*>(&Ks[kvoff(n, c4)]) = kv[i];
       *reinterpret_cast<f32x4*>(&Vs[kvoff(n, c4)]) = vv[i];
     }
