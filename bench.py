@@ -30,30 +30,30 @@ PEAK_HBM_GBS = 8000.0
 
 
 def cpu_baseline():
-    """Time the CPU oracle on a 1/5-longitude slice of each stage and extrapolate to one forward step."""
+    """Time the CPU oracle on a half-longitude slice of each stage (10-20 s of CPU work) and extrapolate to one forward step."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))      # the ONLY place bench.py touches oracle/: the CPU baseline leg
     import cases
     import pangu_oracle as O
     # pick the thread count torch's CPU backend runs this workload fastest with on this host (the reference's
     # scripts pin 16: inference/test_main.py:60); huge hosts lose time to oversubscription at cpu_count threads
     st = cases.STAGES[384]
-    xs, ps, pre = cases.block_input(384, 12), cases.block_params(384, False), cases.block_prefix(384, False)
+    xs, ps, pre = cases.block_input(384, 36), cases.block_params(384, False), cases.block_prefix(384, False)
     best = (1e30, 1)
     for nt in (8, 16, 32, 64, 128):
         if nt > (os.cpu_count() or 1):
             break
         torch.set_num_threads(nt)
         with torch.no_grad():
-            O.earth_block(ps, pre, xs, st["Z"], st["H"], 12, st["heads"], False)
+            O.earth_block(ps, pre, xs, st["Z"], st["H"], 36, st["heads"], False)
             t0 = time.perf_counter()
-            O.earth_block(ps, pre, xs, st["Z"], st["H"], 12, st["heads"], False)
+            O.earth_block(ps, pre, xs, st["Z"], st["H"], 36, st["heads"], False)
             best = min(best, (time.perf_counter() - t0, nt))
     threads = best[1]
     torch.set_num_threads(threads)
     t_total = 0.0
     parts = {}
     with torch.no_grad():
-        for C, W, pairs in ((192, 72, 2), (384, 36, 6)):
+        for C, W, pairs, full_w in ((192, 180, 2, 360), (384, 96, 6, 180)):
             st = cases.STAGES[C]
             x = cases.block_input(C, W)
             t_pair = 0.0
@@ -65,11 +65,11 @@ def cpu_baseline():
                 O.earth_block(p, pre, x, st["Z"], st["H"], W, st["heads"], roll)
                 t_pair += time.perf_counter() - t0
             parts[C] = t_pair
-            t_total += 5.0 * pairs * t_pair
+            t_total += (full_w / W) * pairs * t_pair
     return {
         "value": 1.0 / t_total, "unit": "forward steps/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
-        "sample": ("oracle earth_block pairs (unshifted+shifted) on a 1/5-longitude slice: C=192 at 8x181x72 "
-                   f"({parts[192]:.2f}s), C=384 at 8x91x36 ({parts[384]:.2f}s); extrapolated x5 to the 4+12 blocks of one "
+        "sample": ("oracle earth_block pairs (unshifted+shifted) on a half-longitude slice: C=192 at 8x181x180 "
+                   f"({parts[192]:.2f}s), C=384 at 8x91x96 ({parts[384]:.2f}s); extrapolated by longitude (x2, x1.875) to the 4+12 blocks of one "
                    "forward (embed/recover/resample excluded, <4% of FLOPs)"),
     }
 
