@@ -3,13 +3,14 @@
 // Same decomposition as attn_f32.hip (one (window, head) per 3-wave workgroup, transposed scores so that the
 // probability registers are the B operand of the second product), on v_mfma_f32_16x16x32_bf16:
 //   S^T tile [16 keys][16 queries] = K[16][32] . Q^T[32][16]  is ONE MFMA (K = head_dim = 32);
-//   O^T[16 d][16 q] += V^T[16 d][32 keys] . P^T[32 keys][16 q]: five MFMAs per d-tile (144 keys padded to 160).
-// With 16x fewer matrix cycles than fp32 the kernel is bound by the softmax VALU work and by HBM (qkv read,
-// out write, 31 MB bias), so: K is staged as [key][32] with a chunk swizzle (conflict-free b128 fragment reads),
-// V is staged TRANSPOSED ([d][160 keys], 336-B rows: conflict-free b64 fragment reads) so that the P^T accumulator
-// quads of two adjacent key tiles form the 8-element B fragment with no data movement (the MFMA k index is
-// permuted identically in both operands), scale is folded into the bias add (s = acc*scale + bias), and the
-// bf16 bias tile is read as 8-byte quads.
+//   O^T[16 d][16 q] += V^T[16 d][32 keys] . P^T[32 keys][16 q]: five MFMAs per d-tile (144 keys = 4.5 k-steps).
+// With 16x fewer matrix cycles than fp32 the kernel is bound by its memory/latency structure and the softmax VALU work, so:
+// K is staged as [key][32] with a chunk swizzle (conflict-free b128 fragment reads), V is staged TRANSPOSED ([d][144
+// keys], 336-B rows); the keys of score tiles 2u, 2u+1 are interleaved (key_of) so that one lane's eight scores are eight
+// CONSECUTIVE keys: the bias arrives as one 16-B load per tile pair, the packed probabilities are the PV B-fragment in
+// natural key order and the V^T A-fragment is one conflict-free ds_read_b128; scale is folded into the bias add
+// (s = acc*scale + bias).  All prologue loads are issued up front (closed-form tokens), there is one barrier, the bias row of
+// tile i+1 is prefetched under tile i, and the two heads sharing a token's 128-B line run back to back on one XCD.
 #include "common.h"
 
 namespace {
