@@ -43,23 +43,37 @@ _FUSE_LN = os.environ.get("PANGU_BF16_FUSE_LN", "1") != "0"      # A/B knob: 0 =
 
 
 def _block(blk, sh, x, Z, H, W, roll, out=None):
-    """x (N,C) bf16 -> (N,C) bf16 (eval: DropPath is the identity)."""
+    """x (N,C) bf16 -> (N,C) bf16.  DropPath (reference layers.py:250-251) is the identity in eval(); in train() mode under
+    no_grad each branch draws its per-sample keep factor like the fp32 path (a dropped branch is not computed)."""
     att = blk.attention
-    qkv = ob.linear(x, sh.get(att.linear1.weight), att.linear1.bias)
-    o = ob.window_attention(qkv, sh.get(att.linear1.bias), sh.get(att.earth_specific_bias), Z, H, W, att.head_number, roll)
+    dp = blk.drop_path
+    s1 = dp.sample_scale(blk.training) if hasattr(dp, "sample_scale") else 1.0
+    s2 = dp.sample_scale(blk.training) if hasattr(dp, "sample_scale") else 1.0
     C = x.shape[1]
-    fuse = _FUSE_LN and C == 192 and x.is_contiguous()      # C = 384: the 8-wave 128x384 tile loses what the fusion saves (measured)
-    if fuse:     # projection + post-norm residual in one launch: the branch never round-trips HBM
-        x1 = ob.linear_ln_residual(o, sh.get(att.linear2.weight), att.linear2.bias, x, blk.norm1.weight, blk.norm1.bias)
+    # projection + post-norm residual in one launch (the branch never round-trips HBM); C = 384: the 8-wave 128x384 tile
+    # loses what the fusion saves (measured), so stage 1/2 keeps the separate launches
+    fuse = _FUSE_LN and C == 192 and x.is_contiguous() and s1 == 1.0 and s2 == 1.0
+    if s1 != 0.0:
+        qkv = ob.linear(x, sh.get(att.linear1.weight), att.linear1.bias)
+        o = ob.window_attention(qkv, sh.get(att.linear1.bias), sh.get(att.earth_specific_bias), Z, H, W, att.head_number, roll)
+        if fuse:
+            x1 = ob.linear_ln_residual(o, sh.get(att.linear2.weight), att.linear2.bias, x, blk.norm1.weight, blk.norm1.bias)
+        else:
+            y = ob.linear(o, sh.get(att.linear2.weight), att.linear2.bias)
+            x1 = ob.ln_residual(y, x, blk.norm1.weight, blk.norm1.bias, branch_scale=s1)
     else:
-        y = ob.linear(o, sh.get(att.linear2.weight), att.linear2.bias)
-        x1 = ob.ln_residual(y, x, blk.norm1.weight, blk.norm1.bias)
+        x1 = x
+    if s2 == 0.0:
+        if out is not None:
+            out.copy_(x1)
+            return out
+        return x1
     h = ob.linear(x1, sh.get(blk.linear.linear1.weight), blk.linear.linear1.bias, act=ob.ACT_GELU)
     if fuse:
         return ob.linear_ln_residual(h, sh.get(blk.linear.linear2.weight), blk.linear.linear2.bias, x1, blk.norm2.weight,
                                      blk.norm2.bias, out=out)
     m = ob.linear(h, sh.get(blk.linear.linear2.weight), blk.linear.linear2.bias)
-    return ob.ln_residual(m, x1, blk.norm2.weight, blk.norm2.bias, out=out)
+    return ob.ln_residual(m, x1, blk.norm2.weight, blk.norm2.bias, out=out, branch_scale=s2)
 
 
 def _layer(layer, sh, x, Z, H, W, out=None):

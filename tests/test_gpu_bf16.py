@@ -290,3 +290,30 @@ def test_full_training_step_bf16(P):
     print("bf16 training step: loss fp32 %.6f bf16 %.6f; worst grad rel-L2:" % (l32.item(), lb.item()), errs[:3])
     med = errs[len(errs) // 2][0]
     assert med < 0.1, med
+
+
+@pytest.mark.parametrize("s1,s2", [(0.0, 1.25), (1.25, 0.0), (1.25, 1.25), (1.0, 1.0)])
+def test_block_bf16_nograd_droppath(P, s1, s2):
+    """bf16 inference block in train() mode under no_grad: DropPath factors per branch like the fp32 path (a dropped
+    branch is skipped); (1,1) takes the fused projection+LN launches.  Compared with the fp32 oracle expression."""
+    from pangu_pytorch_amd import fused_bf16
+    C, roll, W = 192, True, 12
+    st = cases.STAGES[C]
+    blk = P.layers.EarthSpecificBlock(C, 0.2, st["heads"], device="cuda").cuda().train()
+    pre = cases.block_prefix(C, roll)
+    blk.load_state_dict({k: synth.synth_param(pre + k, s, "cuda") for k, s in cases.block_param_shapes(C).items()})
+    seq = iter([s1, s2])
+    blk.drop_path.sample_scale = lambda training: next(seq)
+    x = cases.block_input(C, W)
+    with torch.no_grad():
+        y = fused_bf16._block(blk, fused_bf16.WeightShadow(), x[0].cuda().to(BF).contiguous(), st["Z"], st["H"], W, roll)
+        p = cases.block_params(C, roll)
+        g = lambda k: p[pre + k]
+        xr = x.to(BF).float()
+        a = O.window_attention(xr, g("attention.linear1.weight"), g("attention.linear1.bias"), g("attention.linear2.weight"),
+                               g("attention.linear2.bias"), g("attention.earth_specific_bias"), st["Z"], st["H"], W,
+                               st["heads"], roll)
+        x1 = xr + s1 * torch.nn.functional.layer_norm(a, (C,), g("norm1.weight"), g("norm1.bias"))
+        m = O.mlp(x1, g("linear.linear1.weight"), g("linear.linear1.bias"), g("linear.linear2.weight"), g("linear.linear2.bias"))
+        ref = x1 + s2 * torch.nn.functional.layer_norm(m, (C,), g("norm2.weight"), g("norm2.bias"))
+    assert y.dtype == BF and rel_err(y, ref[0]) < 3e-2
