@@ -213,4 +213,6 @@ def forward_train(model, inp, inp_surface, statistics, maps, const_h):
                                           rec.conv_surface.weight, rec.conv_surface.bias, (H4 * W4, LAT, LON), sh)
         outs.append(o)
         outs_s.append(os_)
+    if B == 1:
+        return outs[0].unsqueeze(0), outs_s[0].unsqueeze(0)
     return torch.stack(outs, 0), torch.stack(outs_s, 0)

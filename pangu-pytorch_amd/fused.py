@@ -166,4 +166,4 @@ def patch_recover(m, x, Z, H, W, LAT=721, LON=1440):
         o, os_ = ops.patch_recover_scatter(y_u, y_s, LAT, LON)
         outs.append(o)
         outs_s.append(os_)
-    return torch.stack(outs, 0), torch.stack(outs_s, 0)
+    return _stack(outs, B), _stack(outs_s, B)

@@ -121,4 +121,6 @@ def forward(model, inp, inp_surface, statistics, maps, const_h):
         o, os_ = ops.patch_recover_scatter(y_u, y_s, LAT, LON)
         outs.append(o)
         outs_s.append(os_)
+    if B == 1:                                   # no 286 MB stack copy for the usual single sample
+        return outs[0].unsqueeze(0), outs_s[0].unsqueeze(0)
     return torch.stack(outs, 0), torch.stack(outs_s, 0)
