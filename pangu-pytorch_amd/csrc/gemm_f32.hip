@@ -2,7 +2,9 @@
 //
 // Shape regime of this path: M = 65k..521k tokens, N,K in {64..1536} -> output-tile parallel, no split-K.
 // Tile: 128 x (64*TN) per 256-thread workgroup (4 waves as 2x2, each 64 x 32*TN = 2 x TN MFMA 32x32 tiles),
-// BK = 16, LDS double-buffered with register prefetch (one barrier per K-step).
+// BK = 16, LDS double-buffered with register prefetch (one barrier per K-step).  Occupancy is the strongest lever measured
+// on this kernel: 3 workgroups per CU for TN = 3 (168 VGPRs), 4 for TN <= 2 (<= 128 VGPRs, 4 x 40 KB = all of the LDS), which
+// is worth +4-5 % on the N = 384 shapes; 192-row tiles at 2 workgroups per CU lose 2-8 %.
 // MFMA: v_mfma_f32_32x32x2_f32 (64 FLOP/clk/SIMD = the chip's f32 matrix peak, 157 TF).  Both operands are
 // K-contiguous in memory, so each lane reads its 8 k-values of a K-step as two ds_read_b128: the MFMA's
 // k index is permuted (lane half h owns k = 8h..8h+7) identically for A and W, which leaves the sum unchanged.
@@ -22,7 +24,7 @@ constexpr int LDS_LD = 20;   // padded row (floats)
 #endif
 
 template <int TN, int ACT, bool HAS_BIAS>
-__global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_tn_f32_kernel(const float* __restrict__ A, int lda,
+__global__ __launch_bounds__(256, TN <= 2 ? 4 : GEMM_WAVES_PER_SIMD) void gemm_tn_f32_kernel(const float* __restrict__ A, int lda,
                                                              const float* __restrict__ W,
                                                              const float* __restrict__ bias,
                                                              float* __restrict__ C, int ldc, int M, int N, int K,
