@@ -242,8 +242,10 @@ __device__ inline int kswz64(int row, int chunk) {      // 64-byte rows, 4 chunk
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int TN, int ACT, bool HAS_BIAS, bool OUT_F32>
-__global__ __launch_bounds__(256, 2) void gemm_tn_bf16_glds_kernel(const u16* __restrict__ A, int lda,
+// RING = LDS ring depth: 4 (80 KB, two workgroups per CU, loads three K-steps ahead) or 2 (40 KB ring, 53 KB with the
+// epilogue patches: THREE workgroups per CU at <= 168 VGPRs -- there are no staging registers -- loads one K-step ahead)
+template <int TN, int ACT, bool HAS_BIAS, bool OUT_F32, int RING>
+__global__ __launch_bounds__(256, RING == 2 ? 3 : 2) void gemm_tn_bf16_glds_kernel(const u16* __restrict__ A, int lda,
                                                                    const u16* __restrict__ W, const float* __restrict__ bias,
                                                                    void* __restrict__ Cv, int ldc, int M, int N, int K,
                                                                    int m_tiles, int n_tiles, u16* __restrict__ aux) {
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_glds_kernel(const u16* __
                         : ((unsigned)(n0 + row - BBM) * (unsigned)K + c * 8) * 2u;
   }
   auto issue = [&](int kt) {
-    unsigned char* base = smem + (kt % GST) * STAGE;
+    unsigned char* base = smem + (kt % RING) * STAGE;
 #pragma unroll
     for (int i = 0; i < LPS; ++i) {
       const int q = i * 4 + wave;
@@ -297,17 +299,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_glds_kernel(const u16* __
 
   const int KT = K / GBK;
 #pragma unroll
-  for (int s0 = 0; s0 < GST - 1; ++s0)
+  for (int s0 = 0; s0 < RING - 1; ++s0)
     if (s0 < KT) issue(s0);
   for (int kt = 0; kt < KT; ++kt) {
-    const int rem = KT - 1 - kt;                           // newer steps already in flight: min(rem, 2)
-    if (rem >= 2) wait_vmcnt<2 * LPS>();
-    else if (rem == 1) wait_vmcnt<LPS>();
+    const int rem = KT - 1 - kt;                           // newer steps already in flight: min(rem, RING - 2)
+    if (RING >= 4 && rem >= 2) wait_vmcnt<2 * LPS>();
+    else if (RING >= 3 && rem >= 1) wait_vmcnt<LPS>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();                          // step kt landed for every wave; slot (kt-1)%4 is free
     asm volatile("" ::: "memory");
-    if (kt + GST - 1 < KT) issue(kt + GST - 1);
-    const unsigned char* As = smem + (kt % GST) * STAGE;
+    if (kt + RING - 1 < KT) issue(kt + RING - 1);
+    const unsigned char* As = smem + (kt % RING) * STAGE;
     const unsigned char* Ws = As + BBM * 64;
     bf16x8 fa[4], fw[2 * TN];
 #pragma unroll
@@ -330,18 +332,31 @@ int launch_bf16(hipStream_t s, const u16* A, int lda, const u16* W, const float*
   constexpr int BN = 64 * TN;
   const int m_tiles = (M + BBM - 1) / BBM, n_tiles = (N + BN - 1) / BN;
   const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
-  // Two staging pipelines, A/B-measured on MI355X at this model's shapes (tools/bench_kernels.py gemm_bf16): the
-  // register-staged double buffer and the 4-stage LDS-DMA ring run within 2 % of each other on every shape (the tile's
-  // MFMA-per-barrier ratio, not the load path, bounds both), so the simpler register-staged kernel is the default and
-  // PANGU_BF16_GLDS=1 selects the ring.
-  static const bool allow_glds = getenv("PANGU_BF16_GLDS") && atoi(getenv("PANGU_BF16_GLDS")) == 1;
-  const bool glds = allow_glds && (K % GBK == 0);
-  const size_t shm = glds ? (size_t)GST * (BBM + BN) * 64 : 2 * (size_t)(BBM + BN) * 128;
+  // Staging pipelines, A/B-measured on MI355X at this model's shapes (tools/bench_kernels.py gemm_bf16): the LDS-DMA ring of 2
+  // runs THREE workgroups per CU (no staging registers, 53 KB of LDS) and wins 7-13 % on the K = 384 / 768 shapes; for
+  // K >= 1024 the register-staged BK = 64 kernel (two workgroups per CU, half the barriers) is 4 % ahead; the ring of 4
+  // equals the register-staged kernel everywhere.  PANGU_BF16_GLDS = 0 / 1 / 2 forces register staging / ring of 4 / ring of 2.
+  static const int forced = getenv("PANGU_BF16_GLDS") ? atoi(getenv("PANGU_BF16_GLDS")) : -1;
+  const int glds_mode = forced >= 0 ? forced : (K < 1024 ? 2 : 0);
+  const bool glds = (glds_mode == 1 || glds_mode == 2) && (K % GBK == 0);
+  const size_t epi = OUT_F32 ? 0 : (size_t)4 * 64 * (32 * TN * 2 + 16);
+  const size_t ring = (size_t)(glds_mode == 2 ? 2 : GST) * (BBM + BN) * 64;
+  const size_t shm = glds ? (ring > epi ? ring : epi) : 2 * (size_t)(BBM + BN) * 128;
   dim3 g(grid), blk(256);
 #define PANGU_BGEMM(ACT, HB)                                                                                          \
   do {                                                                                                                \
+    if (glds && glds_mode == 2) {                                                                                     \
+      auto kern = gemm_tn_bf16_glds_kernel<TN, ACT, HB, OUT_F32, 2>;                                                  \
+      static bool attr_set_g2 = false;                                                                                \
+      if (!attr_set_g2) {                                                                                             \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+        attr_set_g2 = true;                                                                                           \
+      }                                                                                                               \
+      hipLaunchKernelGGL(kern, g, blk, shm, s, A, lda, W, bias, C, ldc, M, N, K, m_tiles, n_tiles, aux);              \
+      break;                                                                                                          \
+    }                                                                                                                 \
     if (glds) {                                                                                                       \
-      auto kern = gemm_tn_bf16_glds_kernel<TN, ACT, HB, OUT_F32>;                                                     \
+      auto kern = gemm_tn_bf16_glds_kernel<TN, ACT, HB, OUT_F32, GST>;                                                \
       static bool attr_set_g = false;                                                                                 \
       if (!attr_set_g) {                                                                                              \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
