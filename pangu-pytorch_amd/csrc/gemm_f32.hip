@@ -209,6 +209,9 @@ int launch_tn(hipStream_t s, const float* A, int lda, const float* W, const floa
 
 }  // namespace
 
+int pangu_linear_f32_dma(hipStream_t s, const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M,
+                         int N, int K, int act, float* aux);      // gemm_f32_dma.hip
+
 extern "C" int pangu_linear_fwd(pangu_stream_t stream, const float* A, int lda, const float* W, const float* bias,
                                 float* C, int ldc, int M, int N, int K, int act, float* aux) {
   if (!A || !W || !C) return PANGU_E_NULL;
@@ -225,7 +228,13 @@ extern "C" int pangu_linear_fwd(pangu_stream_t stream, const float* A, int lda, 
   // or fits one tile (N = 160: 17 % padded MFMAs still beat three 64-wide tiles); N = 384 as 3 x 128 (3072 tiles =
   // exactly 4 waves of the 768 resident workgroups, vs 2048 = 2.67 with 192-wide tiles).
   if (N == 384) return launch_tn<2>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
-  if (N % 192 == 0 || (N > 128 && N < 192)) return launch_tn<3>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
+  if (N % 192 == 0 || (N > 128 && N < 192)) {
+    // default: the LDS-DMA kernel (gemm_f32_dma.hip, four workgroups per CU), +3.5-11 % over the register-staged kernel below
+    // on every 192-wide-tile shape of the model; PANGU_GEMM_DMA=0 selects the register-staged kernel (A/B knob)
+    static const int dma = getenv("PANGU_GEMM_DMA") ? atoi(getenv("PANGU_GEMM_DMA")) : 1;
+    if (dma) return pangu_linear_f32_dma(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
+    return launch_tn<3>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
+  }
   if (N % 128 == 0) return launch_tn<2>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
   return launch_tn<1>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
 }
