@@ -210,7 +210,7 @@ int launch_tn(hipStream_t s, const float* A, int lda, const float* W, const floa
 }  // namespace
 
 int pangu_linear_f32_dma(hipStream_t s, const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M,
-                         int N, int K, int act, float* aux);      // gemm_f32_dma.hip
+                         int N, int K, int act, float* aux, int tn);      // gemm_f32_dma.hip
 
 extern "C" int pangu_linear_fwd(pangu_stream_t stream, const float* A, int lda, const float* W, const float* bias,
                                 float* C, int ldc, int M, int N, int K, int act, float* aux) {
@@ -227,12 +227,18 @@ extern "C" int pangu_linear_fwd(pangu_stream_t stream, const float* A, int lda, 
   // Tile width (measured per shape on MI355X, tools/bench_kernels.py): 192 columns wherever N is a multiple of 192
   // or fits one tile (N = 160: 17 % padded MFMAs still beat three 64-wide tiles); N = 384 as 3 x 128 (3072 tiles =
   // exactly 4 waves of the 768 resident workgroups, vs 2048 = 2.67 with 192-wide tiles).
-  if (N == 384) return launch_tn<2>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
+  // 128 x 128 LDS-DMA tiles (five workgroups per CU) for N = 384, where 192-wide tiles would leave 2.67 rounds of workgroups;
+  // PANGU_GEMM_DMA2 = 0: register-staged kernel, 2: 128-wide DMA tiles for every N % 128 == 0 (A/B knobs)
+  static const int dma2 = getenv("PANGU_GEMM_DMA2") ? atoi(getenv("PANGU_GEMM_DMA2")) : 1;
+  if (N == 384 || (dma2 == 2 && N % 128 == 0)) {
+    if (dma2) return pangu_linear_f32_dma(s, A, lda, W, bias, C, ldc, M, N, K, act, aux, 2);
+    return launch_tn<2>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
+  }
   if (N % 192 == 0 || (N > 128 && N < 192)) {
     // default: the LDS-DMA kernel (gemm_f32_dma.hip, four workgroups per CU), +3.5-11 % over the register-staged kernel below
     // on every 192-wide-tile shape of the model; PANGU_GEMM_DMA=0 selects the register-staged kernel (A/B knob)
     static const int dma = getenv("PANGU_GEMM_DMA") ? atoi(getenv("PANGU_GEMM_DMA")) : 1;
-    if (dma) return pangu_linear_f32_dma(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
+    if (dma) return pangu_linear_f32_dma(s, A, lda, W, bias, C, ldc, M, N, K, act, aux, 3);
     return launch_tn<3>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
   }
   if (N % 128 == 0) return launch_tn<2>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);

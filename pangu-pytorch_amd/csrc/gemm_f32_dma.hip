@@ -13,11 +13,6 @@ namespace {
 
 constexpr int BM = 128;
 constexpr int BK = 16;       // floats per K-step = one 64-byte LDS row
-constexpr int TN = 3;
-constexpr int BN = 64 * TN;
-constexpr int ROWS = BM + BN;
-constexpr int STAGE = ROWS * 64;          // bytes per ring slot
-constexpr int LPS = ROWS / 64;            // LDS-DMA instructions per wave and stage (16 rows of 64 B each)
 
 // byte offset of logical 16-B chunk `chunk` of row `row` (64-byte rows, chunk XOR F[(row>>2)&3], F = {0,2,3,1})
 __device__ inline int kswz64(int row, int chunk) {
@@ -25,11 +20,16 @@ __device__ inline int kswz64(int row, int chunk) {
   return row * 64 + ((chunk ^ f) << 4);
 }
 
-template <int ACT, bool HAS_BIAS>
-__global__ __launch_bounds__(256, 4) void gemm_tn_f32_dma_kernel(const float* __restrict__ A, int lda,
+// TN = 3: 128 x 192 tile, 40 KB ring, 127 VGPRs -> four workgroups per CU; TN = 2: 128 x 128 tile, 32 KB ring -> five
+template <int TN, int ACT, bool HAS_BIAS>
+__global__ __launch_bounds__(256, TN == 3 ? 4 : 5) void gemm_tn_f32_dma_kernel(const float* __restrict__ A, int lda,
                                                                  const float* __restrict__ W, const float* __restrict__ bias,
                                                                  float* __restrict__ C, int ldc, int M, int N, int K,
                                                                  int m_tiles, int n_tiles, float* __restrict__ aux) {
+  constexpr int BN = 64 * TN;
+  constexpr int ROWS = BM + BN;
+  constexpr int STAGE = ROWS * 64;          // bytes per ring slot
+  constexpr int LPS = ROWS / 64;            // LDS-DMA instructions per wave and stage (16 rows of 64 B each)
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
   // XCD-aware tile assignment (blocks b, b+8, b+16.. share an XCD; they walk the n-tiles of one m-tile).
@@ -159,14 +159,15 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_f32_dma_kernel(const float* __
 
 }  // namespace
 
-// gemm_f32.hip dispatches here for its TN = 3 shapes when the variant is enabled
-int pangu_linear_f32_dma(hipStream_t s, const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M,
-                         int N, int K, int act, float* aux) {
+template <int TN>
+int launch_dma(hipStream_t s, const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N, int K,
+               int act, float* aux) {
+  constexpr int BN = 64 * TN;
   const int m_tiles = (M + BM - 1) / BM, n_tiles = (N + BN - 1) / BN;
   const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
   dim3 g(grid), blk(256);
 #define PANGU_DMA_LAUNCH(ACT, HB) \
-  hipLaunchKernelGGL((gemm_tn_f32_dma_kernel<ACT, HB>), g, blk, 0, s, A, lda, W, bias, C, ldc, M, N, K, m_tiles, n_tiles, aux)
+  hipLaunchKernelGGL((gemm_tn_f32_dma_kernel<TN, ACT, HB>), g, blk, 0, s, A, lda, W, bias, C, ldc, M, N, K, m_tiles, n_tiles, aux)
   if (act == PANGU_ACT_GELU) {
     if (bias) PANGU_DMA_LAUNCH(PANGU_ACT_GELU, true); else PANGU_DMA_LAUNCH(PANGU_ACT_GELU, false);
   } else if (act == PANGU_ACT_GELU_BWD) {
@@ -178,4 +179,11 @@ int pangu_linear_f32_dma(hipStream_t s, const float* A, int lda, const float* W,
   }
 #undef PANGU_DMA_LAUNCH
   return pangu_launch_status();
+}
+
+// gemm_f32.hip dispatches here: tn = 3 for its 192-wide-tile shapes, 2 for the 128-wide ones
+int pangu_linear_f32_dma(hipStream_t s, const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M,
+                         int N, int K, int act, float* aux, int tn) {
+  if (tn == 3) return launch_dma<3>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
+  return launch_dma<2>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
 }
