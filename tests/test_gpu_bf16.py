@@ -86,6 +86,33 @@ def test_linear_ln_residual_bf16(P, M, N, K, strided_out):
         assert float(full[:, :N].float().abs().max()) == 0.0
 
 
+def test_linear_bf16_random_shapes(P):
+    """Ragged M, K % 8 == 0, every kernel family (weights-stationary, LDS-DMA ring, register-staged), bias / GELU / add."""
+    import random
+    from pangu_pytorch_amd import ops_bf16 as ob
+    rnd = random.Random(11)
+    torch.manual_seed(11)
+    for _ in range(40):
+        N = rnd.choice([160, 192, 384, 576, 768, 1152, 1536, 136, 176, 64])
+        K = 8 * rnd.randint(1, 200)
+        M = rnd.randint(1, 6000)
+        act = rnd.choice([0, 0, 1, 3])
+        a = torch.randn(M, K, device="cuda").to(BF)
+        w = (torch.randn(N, K, device="cuda") / K ** 0.5).to(BF)
+        b = torch.randn(N, device="cuda") if rnd.random() < 0.7 else None
+        aux = torch.randn(M, N, device="cuda").to(BF) if act == 3 else None
+        ref = a.double() @ w.double().t()
+        if b is not None:
+            ref = ref + b.double()
+        if act == 1:
+            ref = torch.nn.functional.gelu(ref)
+        if act == 3:
+            ref = ref + aux.double()
+        got = ob.linear(a, w, b, act=act, aux=aux)
+        err = ((got.double() - ref).norm() / ref.norm()).item()
+        assert err < ROUND, (M, N, K, act, err)
+
+
 def test_linear_bf16_gelu_aux_and_bwd(P):
     from pangu_pytorch_amd import ops_bf16 as ob
     M, N, K = 1500, 768, 192
