@@ -310,3 +310,25 @@ def test_batch_of_two_equals_two_singles(P):
         ob, osb = m(inp2[1:], inp_s2[1:], stats, maps, const_h)
     assert o2.shape == (2, 5, 13, 721, 1440)
     assert torch.equal(o2[0], oa[0]) and torch.equal(o2[1], ob[0]) and torch.equal(os2[1], osb[0])
+
+
+@pytest.mark.parametrize("Z,H,W,heads", [(2, 1, 12, 1), (4, 7, 24, 2), (2, 13, 36, 5), (6, 19, 12, 3)])
+@pytest.mark.parametrize("shifted", [False, True])
+def test_window_attention_other_geometries(P, Z, H, W, heads, shifted):
+    """Geometries other than the model's two (odd head counts, a single latitude row, three z-windows): the closed-form
+    window addressing / mask against the oracle's explicit gather index, fp32 and bf16 kernels."""
+    from pangu_pytorch_amd import ops_bf16 as ob
+    C = 32 * heads
+    N = Z * H * W
+    types = (Z // 2) * ((H + 5) // 6)
+    qkv = synth.uniform((1, N, 3 * C), 91, 1.5)
+    b1 = synth.uniform((3 * C,), 92, 0.5)
+    esb = synth.uniform((1, types, heads, 144, 144), 93, 0.5)
+    ref, ref_lse = O.window_attention_core(qkv, b1, esb, Z, H, W, heads, shifted)
+    got, lse = P.ops.window_attention(qkv[0].cuda(), b1.cuda(), esb[0].cuda(), Z, H, W, heads, shifted, want_lse=True)
+    assert rel_err(got, ref[0]) < TIGHT
+    bf = torch.bfloat16
+    q16, b16, e16 = qkv.to(bf), b1.to(bf), esb.to(bf)
+    ref16, _ = O.window_attention_core(q16.float(), b16.float(), e16.float(), Z, H, W, heads, shifted)
+    got16 = ob.window_attention(q16[0].cuda(), b16.cuda(), e16[0].cuda(), Z, H, W, heads, shifted)
+    assert rel_err(got16, ref16[0]) < 1.0 / 64
