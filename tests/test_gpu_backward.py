@@ -92,6 +92,32 @@ def test_window_attention_bwd(P, C, shifted):
     assert rel_err(dqb, b1.grad) < TIGHT
 
 
+@pytest.mark.parametrize("Z,H,W,heads", [(4, 7, 24, 3), (2, 13, 12, 2)])
+@pytest.mark.parametrize("shifted", [False, True])
+def test_window_attention_bwd_other_geometries(P, Z, H, W, heads, shifted):
+    """Backward on geometries other than the model's (odd head count = unpaired block order), fp32 and bf16 kernels."""
+    from pangu_pytorch_amd import ops_bf16 as ob
+    C = 32 * heads
+    N = Z * H * W
+    types = (Z // 2) * ((H + 5) // 6)
+    for bf in (False, True):
+        dt = torch.bfloat16 if bf else torch.float32
+        qkv = synth.uniform((1, N, 3 * C), 81, 1.5).to(dt).float().requires_grad_(True)
+        b1 = synth.uniform((3 * C,), 82, 0.5).to(dt).float().requires_grad_(True)
+        esb = synth.uniform((1, types, heads, 144, 144), 83, 0.5).to(dt).float().requires_grad_(True)
+        do = synth.uniform((1, N, C), 84).to(dt).float()
+        ref, _ = O.window_attention_core(qkv, b1, esb, Z, H, W, heads, shifted)
+        (ref * do).sum().backward()
+        mod = ob if bf else P.ops
+        q, bb, e, d = (t.detach().to(dt).cuda() for t in (qkv[0], b1, esb[0], do[0]))
+        o, lse = mod.window_attention(q, bb, e, Z, H, W, heads, shifted, want_lse=True)
+        dqkv, dqb, desb = mod.window_attention_bwd(q, bb, e, o, lse, d, Z, H, W, heads, shifted)
+        tol = 3e-2 if bf else TIGHT
+        assert rel_err(dqkv, qkv.grad[0]) < tol
+        assert rel_err(desb, esb.grad[0]) < tol
+        assert rel_err(dqb, b1.grad) < tol
+
+
 @pytest.mark.parametrize("C", [192, 384])
 @pytest.mark.parametrize("roll", [False, True])
 def test_block_backward_golden(P, golden_dir, C, roll):
