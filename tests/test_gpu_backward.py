@@ -38,6 +38,30 @@ def test_linear_wgrad(P, M, N, K):
     assert rel_err(db, dc.double().sum(0)) < TIGHT
 
 
+def test_linear_wgrad_random_shapes(P):
+    """Ragged token counts and every tile family of the weight-gradient GEMMs (fp32 and bf16) against fp64 products."""
+    import random
+    from pangu_pytorch_amd import ops_bf16 as ob
+    rnd = random.Random(5)
+    torch.manual_seed(5)
+    for _ in range(24):
+        N = rnd.choice([160, 192, 384, 576, 768, 1152, 64, 136])
+        K = rnd.choice([64, 112, 128, 192, 384, 768, 160])
+        M = rnd.randint(1, 9000)
+        dc = torch.randn(M, N, device="cuda")
+        a = torch.randn(M, K, device="cuda")
+        dw, db = P.ops.linear_wgrad(dc, a)
+        ref_w, ref_b = dc.double().t() @ a.double(), dc.double().sum(0)
+        assert ((dw.double() - ref_w).norm() / ref_w.norm()).item() < 3e-6, (M, N, K)
+        assert ((db.double() - ref_b).norm() / ref_b.norm()).item() < 3e-6, (M, N, K)
+        if K % 8 == 0:
+            dcb, ab = dc.bfloat16(), a.bfloat16()
+            dw, db = ob.linear_wgrad(dcb, ab)
+            ref_w, ref_b = dcb.double().t() @ ab.double(), dcb.double().sum(0)
+            assert ((dw.double() - ref_w).norm() / ref_w.norm()).item() < 1e-5, (M, N, K)
+            assert ((db.double() - ref_b).norm() / ref_b.norm()).item() < 1e-5, (M, N, K)
+
+
 def test_linear_wgrad_strided(P):
     full = synth.uniform((3000, 576), 63).cuda()
     a = synth.uniform((3000, 192), 64).cuda()
