@@ -130,7 +130,7 @@ __device__ __forceinline__ void bf16_epilogue(f32x4 (&acc)[4][2 * TN], unsigned 
       if (f < 16 * CPR) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(ep + row * EP_LD + ch * 16);
         const unsigned off = col < N ? ((unsigned)(wave_m0 + row) * (unsigned)ldc + (unsigned)col) * 2u : 0xFFFFFFFFu;
-        __builtin_amdgcn_raw_buffer_store_b128(v, c_rsrc, (int)off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v, c_rsrc, (int)off, 0, 2);
       }
     }
   }

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_ln_residual_bf16_kernel(
       const int row = i * 16 + f / CPR, ch = f % CPR;
       const u32x4 v = *reinterpret_cast<const u32x4*>(ep + row * EP_LD + ch * 16);
       const unsigned off = ((unsigned)(wave_m0 + row) * (unsigned)ldo + (unsigned)(wave_n0 + ch * 8)) * 2u;
-      __builtin_amdgcn_raw_buffer_store_b128(v, o_rsrc, (int)off, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(v, o_rsrc, (int)off, 0, 2);
     }
   }
 }

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_bf16_kernel(const u16* __restr
           const u32x4 v = *reinterpret_cast<const u32x4*>(ep + row * EP_LD + ch * 16);
           const unsigned off = col < N ? ((unsigned)(m_cur + mt * 16 + row) * (unsigned)ldc + (unsigned)col) * (OUT_F32 ? 4u : 2u)
                                        : 0xFFFFFFFFu;
-          __builtin_amdgcn_raw_buffer_store_b128(v, c_rsrc, (int)off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(v, c_rsrc, (int)off, 0, 2);
         }
       }
     }
