@@ -8,6 +8,7 @@
 // applies gamma / beta / branch scale, adds the shortcut (read as the same 16-B row segments) and stores.
 // Saves the branch's HBM round trip: the standalone LN-residual kernel is HBM-bound (3 passes over N x C).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -201,14 +202,22 @@ __global__ __launch_bounds__(256, 3) void gemm_ln_residual_f32_kernel(const floa
 
 }  // namespace
 
+int pangu_linear_ln_f32_dma(hipStream_t s, const float* A, int lda, const float* W, const float* bias, const float* shortcut,
+                            int lds, const float* gamma, const float* beta, float* out, int ldo, int M, int N, int K,
+                            float branch_scale);      // gemm_ln_f32_dma.hip
+
 extern "C" int pangu_linear_ln_residual_fwd(pangu_stream_t stream, const float* A, int lda, const float* W, const float* bias,
                                             const float* shortcut, int lds, const float* gamma, const float* beta, float* out,
                                             int ldo, int M, int N, int K, float branch_scale) {
   if (!A || !W || !shortcut || !gamma || !beta || !out) return PANGU_E_NULL;
   if (M <= 0 || K <= 0 || (K % BK) != 0 || lda < K || (lda & 3) || ldo < N || (ldo & 3) || lds < N || (lds & 3))
     return PANGU_E_SHAPE;
-  if (N != BN) return PANGU_E_SHAPE;                       // the tile must span the whole row
   hipStream_t s = (hipStream_t)stream;
+  // default: the LDS-DMA kernels (gemm_ln_f32_dma.hip: N = 192 and N = 384); PANGU_LN_DMA=0 keeps the register-staged N = 192 one
+  static const int dma = getenv("PANGU_LN_DMA") ? atoi(getenv("PANGU_LN_DMA")) : 1;
+  if (dma && (N == 192 || N == 384))
+    return pangu_linear_ln_f32_dma(s, A, lda, W, bias, shortcut, lds, gamma, beta, out, ldo, M, N, K, branch_scale);
+  if (N != BN) return PANGU_E_SHAPE;                       // the tile must span the whole row
   dim3 g((M + BM - 1) / BM), blk(256);
   if (bias)
     hipLaunchKernelGGL(gemm_ln_residual_f32_kernel<true>, g, blk, 0, s, A, lda, W, bias, shortcut, lds, gamma, beta, out, ldo, M,

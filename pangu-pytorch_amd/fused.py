@@ -67,7 +67,7 @@ def earth_block(blk, x, Z, H, W, roll, out=None):
         o = torch.cat([ops.window_attention(qkv[b * N:(b + 1) * N], att.linear1.bias, esb, Z, H, W,
                                             att.head_number, roll) for b in range(B)], 0) if B > 1 else \
             ops.window_attention(qkv, att.linear1.bias, esb, Z, H, W, att.head_number, roll)
-        if _FUSE_LN and C == 192:     # projection + post-norm residual in one launch (the tile spans the row at C = 192)
+        if _FUSE_LN and C in (192, 384):     # projection + post-norm residual in one launch (the GEMM tile spans the row)
             x1 = ops.linear_ln_residual(o, att.linear2.weight, att.linear2.bias, x2, blk.norm1.weight, blk.norm1.bias,
                                         branch_scale=s1)
         else:
@@ -77,7 +77,7 @@ def earth_block(blk, x, Z, H, W, roll, out=None):
         x1 = x2
     if s2 != 0.0:
         o2 = _tok2d(out) if out is not None else None
-        if _FUSE_LN and C == 192:
+        if _FUSE_LN and C in (192, 384):
             h = ops.linear(x1, blk.linear.linear1.weight, blk.linear.linear1.bias, act=ops.ACT_GELU)
             x2o = ops.linear_ln_residual(h, blk.linear.linear2.weight, blk.linear.linear2.bias, x1, blk.norm2.weight,
                                          blk.norm2.bias, out=o2, branch_scale=s2)

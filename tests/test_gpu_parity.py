@@ -90,9 +90,9 @@ def test_linear_add_epilogue(P, M, N, K, bias):
 @pytest.mark.parametrize("M,K,bias,scale", [(1000, 192, True, 1.0), (4099, 768, True, 1.25), (777, 192, False, 1.0),
                                               (128, 16, True, 0.5)])
 @pytest.mark.parametrize("strided", [False, True])
-def test_linear_ln_residual(P, M, K, bias, scale, strided):
+@pytest.mark.parametrize("N", [192, 384])
+def test_linear_ln_residual(P, M, K, bias, scale, strided, N):
     """Fused projection + post-norm residual == linear -> LayerNorm -> shortcut + scale * (.) (reference layers.py:250-251)."""
-    N = 192
     a = synth.uniform((M, K), 81)
     w = synth.uniform((N, K), 82, 1.0 / K ** 0.5)
     b = synth.uniform((N,), 83, 0.5) if bias else None

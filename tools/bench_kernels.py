@@ -74,7 +74,8 @@ def gemm_bf16(lib_compare):
 
 
 def gemm_ln():
-    for M, N, K, name in ((521280, 192, 192, "s0 proj+LN"), (521280, 192, 768, "s0 mlp2+LN")):
+    for M, N, K, name in ((521280, 192, 192, "s0 proj+LN"), (521280, 192, 768, "s0 mlp2+LN"), (131040, 384, 384, "s1 proj+LN"),
+                          (131040, 384, 1536, "s1 mlp2+LN")):
         a = torch.randn(M, K, device="cuda")
         w = torch.randn(N, K, device="cuda") / K ** 0.5
         b, g, be = torch.randn(N, device="cuda"), torch.ones(N, device="cuda"), torch.zeros(N, device="cuda")
