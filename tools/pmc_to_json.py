@@ -7,7 +7,7 @@ mfma_busy = sum SQ_VALU_MFMA_BUSY_CYCLES / (sum GRBM_GUI_ACTIVE * 128)   (GUI_AC
 over the 1024 SIMDs)."""
 import collections, csv, glob, json, os, sys
 
-FAMILIES = {"gemm": ("gemm_tn_f32_dma_kernel", "gemm_tn_f32_kernel"), "gemm_ln": ("gemm_ln_residual_f32_kernel",),
+FAMILIES = {"gemm": ("gemm_tn_f32_dma_kernel", "gemm_tn_f32_kernel"), "gemm_ln": ("gemm_ln_residual_f32",),
             "attn": ("window_attn_f32_kernel",)}
 
 
