@@ -39,7 +39,7 @@ def mlp(m, x2d):
 
 
 def earth_block(blk, x, Z, H, W, roll, out=None):
-    """x (B,N,C) -> (B,N,C).  reference layers.py:183-253 as 7 kernel launches per sample."""
+    """x (B,N,C) -> (B,N,C).  reference layers.py:183-253 as 5 kernel launches per sample (qkv, attention core, proj+LN+residual, MLP-up+GELU, MLP-down+LN+residual)."""
     B, N, C = x.shape
     att = blk.attention
     dp = blk.drop_path
