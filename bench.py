@@ -139,7 +139,8 @@ def main():
         out = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    gemm_ms, gemm_flop, gemm_launches = ops.timing_stop("linear")
+    gemm_ms, gemm_flop, gemm_launches, other = ops.timing_stop("linear", also=("linear_ln",))
+    fused_ms, fused_flop, fused_launches = other["linear_ln"]      # GEMMs with the fused LayerNorm+residual epilogue
     assert torch.isfinite(out[0]).all()
 
     if dist is not None:
@@ -266,7 +267,11 @@ def main():
                          "traffic": traffic, "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, profiles/pmc_traffic_f32.json)",
                          "algorithmic_flop_per_launch": gemm_flop / max(gemm_launches, 1),
                          "mfma_busy_frac_pmc": mfma_busy, "launches": gemm_launches, "avg_launch_ms": gemm_ms / max(gemm_launches, 1),
-                         "share_of_step": gemm_ms / (ms * args.steps)},
+                         "share_of_step": gemm_ms / (ms * args.steps),
+                         "fused_ln_gemm": {"kernel": "gemm_ln_residual_f32_dma_kernel (projection + LayerNorm + residual)",
+                                           "launches": fused_launches, "avg_launch_ms": fused_ms / max(fused_launches, 1),
+                                           "achieved": fused_flop / (fused_ms * 1e-3) / 1e12 if fused_ms > 0 else 0.0,
+                                           "share_of_step": fused_ms / (ms * args.steps)}},
         }
         if bf16_res is not None:
             res["bf16_forward"] = bf16_res

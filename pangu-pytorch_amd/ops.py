@@ -38,14 +38,20 @@ def timing_start():
     _timing = []
 
 
-def timing_stop(kind):
-    """-> (total ms, total algorithmic FLOP (or bytes), launches) of the launches tagged `kind`; stops timing."""
+def timing_stop(kind, also=()):
+    """-> (total ms, total algorithmic FLOP (or bytes), launches) of the launches tagged `kind`; stops timing.
+    With `also` (more tags) a dict {tag: (ms, work, launches)} for those tags is appended to the tuple."""
     global _timing
     rec, _timing = _timing or [], None
     torch.cuda.synchronize()
-    ms = sum(a.elapsed_time(b) for k, a, b, w in rec if k == kind)
-    work = sum(w for k, a, b, w in rec if k == kind)
-    return ms, work, sum(1 for r in rec if r[0] == kind)
+
+    def agg(tag):
+        sel = [(a.elapsed_time(b), w) for k, a, b, w in rec if k == tag]
+        return sum(t for t, _ in sel), sum(w for _, w in sel), len(sel)
+
+    if also:
+        return agg(kind) + ({t: agg(t) for t in also},)
+    return agg(kind)
 
 
 class _timed:
