@@ -104,7 +104,7 @@ def main():
     local_rank = local_rank % max(n_dev, 1)      # (functional tests may run several ranks on one GPU with gloo)
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("PANGU_DIST_FORCE") == "1":     # FORCE: run the RCCL path on a 1-rank communicator
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("PANGU_DIST_BACKEND", "nccl")      # "nccl" = RCCL over xGMI; "gloo" only for tests
@@ -150,16 +150,17 @@ def main():
 
     # ---- secondary metric: bf16 inference forward (BASELINE configs[2]/[4] precision), same inputs
     bf16_res = None
+    lsync = torch.cuda.synchronize      # no collectives inside the try: a rank that fails must not desynchronise the others
     if not args.no_bf16:
       try:
         model.set_compute_dtype(torch.bfloat16)
         for _ in range(2):
             step()
-        barrier()
+        lsync()
         tb = time.perf_counter()
         for _ in range(args.steps):
             out_b = step()
-        barrier()
+        lsync()
         tb = time.perf_counter() - tb
         ref = out[0].double()
         drift = ((out_b[0].double() - ref).norm() / ref.norm()).item()
@@ -167,21 +168,21 @@ def main():
         from pangu_pytorch_amd import rollout as R
         gs = R.GraphedStep(model, inp, inp_s, stats, maps, const_h)
         gs.step()
-        barrier()
+        lsync()
         tg = time.perf_counter()
         for _ in range(args.steps):
             gs.step()
-        barrier()
+        lsync()
         tg = time.perf_counter() - tg
         sl = (stats[0].view(1, 4, 1, 1), stats[1].view(1, 4, 1, 1),
               stats[2].reshape(13, 5).flip(0).t().reshape(1, 5, 13, 1, 1).contiguous(),
               stats[3].reshape(13, 5).flip(0).t().reshape(1, 5, 13, 1, 1).contiguous())
         gr = R.GraphedStep(model, inp, inp_s, stats, maps, const_h, stats_last=sl, feed_back=True)
-        barrier()
+        lsync()
         tr = time.perf_counter()
         for _ in range(7):
             gr.step()
-        barrier()
+        lsync()
         tr = time.perf_counter() - tr
         # per-step drift of the bf16 rollout against the SAME rollout in fp32 on this GPU (the
         # ONNX reference is unavailable)
@@ -193,6 +194,7 @@ def main():
         roll_drift = [((hb[0].double() - hf[0].double()).norm() / hf[0].double().norm()).item()
                       for hb, hf in zip(hist_b, hist_f)]
         del hist_b, hist_f
+        times = [tg, tb, tr]
         bf16_res = {"metric": "bf16 forward steps/s (bf16 activations+weights, fp32 LN/softmax/accumulate), hipGraph replay",
                     "value": world * args.steps / tg, "ms_per_step": tg / args.steps * 1e3,
                     "eager_ms_per_step": tb / args.steps * 1e3, "rel_l2_drift_vs_f32": drift,
@@ -203,6 +205,17 @@ def main():
       except Exception as e:      # secondary metrics must never take the headline line down
         bf16_res = {"error": repr(e)[:300]}
         model.set_compute_dtype(torch.float32)
+      if dist is not None:        # every rank gets here, failed or not: slowest rank's times, any rank's failure
+        ok = "error" not in bf16_res
+        t = torch.tensor((times if ok else [0.0, 0.0, 0.0]) + [0.0 if ok else 1.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if ok and t[3].item() > 0:
+            bf16_res = {"error": "another rank failed the bf16 section"}
+        elif ok:
+            tg, tb, tr = t[:3].tolist()
+            bf16_res.update(value=world * args.steps / tg, ms_per_step=tg / args.steps * 1e3,
+                            eager_ms_per_step=tb / args.steps * 1e3, model_tflops=FWD_GFLOP / (tg / args.steps * 1e3),
+                            rollout_7x24h_ms=tr * 1e3)
 
     # ---- secondary metric: DDP finetune step (BASELINE configs[3] shape: 1 sample/GPU, fwd + bwd + bucketed RCCL
     # gradient all-reduce overlapped with backward + Adam), reported beside the headline number
@@ -214,7 +227,7 @@ def main():
         model.train()
         tgt, tgt_s, *_ = synthetic_inputs(dev, seed=2000 + rank)      # synthetic targets of the input's shape
         opt = train.make_optimizer(model)      # Adam(lr=5e-6, weight_decay=3e-6), reference finetune_fully.py:121
-        sync = FlatGradSync(model) if world > 1 else None
+        sync = FlatGradSync(model, force_collective=True) if dist is not None else None
         batch = (inp, inp_s, tgt, tgt_s)
         for tag, dt in (("ddp_train", torch.float32), ("ddp_train_bf16", torch.bfloat16)):
             try:
@@ -262,7 +275,7 @@ def main():
                                    "depths 2-6-6-2, dims 192/384, random-init weights (BASELINE configs[1])",
                        "parallelism": f"dp{world}"},
             "model_tflops": FWD_GFLOP / ms,
-            "roofline": {"bound": "mfma", "kernel": "gemm_tn_f32_kernel (all projection GEMMs)", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "gemm_tn_f32_dma_kernel (plain projection GEMMs)", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                          "traffic": traffic, "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, profiles/pmc_traffic_f32.json)",
                          "algorithmic_flop_per_launch": gemm_flop / max(gemm_launches, 1),

@@ -67,10 +67,11 @@ class FlatGradSync:
     usage:   sync = FlatGradSync(model);   loss.backward();   sync.finish();   optimizer.step()
     """
 
-    def __init__(self, model, process_group=None, buckets=None, average=True):
+    def __init__(self, model, process_group=None, buckets=None, average=True, force_collective=False):
         self.group = process_group
         self.world = tdist.get_world_size(process_group) if tdist.is_initialized() else 1
         self.average = average
+        self.force = force_collective      # issue the collectives on a 1-rank group too (exercises the RCCL path)
         params = [p for p in model.parameters() if p.requires_grad]
         buckets = buckets if buckets is not None else default_buckets(model)
         buckets = [[p for p in b if p.requires_grad] for b in buckets]
@@ -114,7 +115,7 @@ class FlatGradSync:
             self._next += 1
 
     def _launch(self, bi):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         start, end, _ = self.buckets[bi]
         chunk = self.flat[start:end]

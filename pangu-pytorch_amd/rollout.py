@@ -36,7 +36,7 @@ class GraphedStep:
                 self._body()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.out, self.out_surface = self._body()
         # warm-up advanced the state when feed_back is on: restore the caller's initial fields
         self.inp.copy_(inp)
