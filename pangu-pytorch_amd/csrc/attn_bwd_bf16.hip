@@ -72,6 +72,9 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_bf16_kernel(
   const int lq = lane & 15, lg = lane >> 4;
   const int C3 = 3 * C;
   const float scale = 0.17677669529663687f;
+  constexpr float K_LOG2E = 1.4426950408889634f;
+  const float scale2 = scale * K_LOG2E;
+  constexpr float K_MASK2 = -100.0f * K_LOG2E;
   const u16* bias_tile = esb + (size_t)pair * PANGU_WTOK * PANGU_WTOK;
 
   bool zcut = false, hcut = false;
@@ -140,8 +143,10 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_bf16_kernel(
       d += __shfl_xor(d, 1, 64);
       d += __shfl_xor(d, 2, 64);
       if (ch == 0) {
-        del_s[n] = d;
-        lse_s[n] = tok >= 0 ? lse[(size_t)tok * heads + hd] : 1e30f;     // pad query: exp(S - lse) = 0
+        // row constants in the form the score epilogue consumes: p = exp2(S*scale*log2e + b*log2e - lse*log2e) and
+        // dS = p * (dP - delta) with -delta as the INITIAL ACCUMULATOR of the dP product
+        del_s[n] = -d;
+        lse_s[n] = tok >= 0 ? -K_LOG2E * lse[(size_t)tok * heads + hd] : -1e30f;     // pad query: p = exp2(-huge) = 0
       }
     }
     __syncthreads();
@@ -152,7 +157,9 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_bf16_kernel(
       const int qtok = tok_s[qn];
       const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qr + kswz(qn, lg));
       const bf16x8 gf = *reinterpret_cast<const bf16x8*>(Gr + kswz(qn, lg));
-      const float my_lse = lse_s[qn], my_del = del_s[qn];
+      const float nl2 = lse_s[qn], nl2m = nl2 + K_MASK2;          // -lse*log2e (and with the -100 mask folded in)
+      const float nd = del_s[qn];
+      const f32x4 ndel = {nd, nd, nd, nd};
       const u16* brow = bias_l + (size_t)qn * PANGU_WTOK + lg * 4;
       f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
       const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -168,15 +175,15 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_bf16_kernel(
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kr + kswz(j * 16 + lq, lg));
             const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vr + kswz(j * 16 + lq, lg));
             const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, zero, 0, 0, 0);
-            const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, gf, zero, 0, 0, 0);
+            const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, gf, ndel, 0, 0, 0);     // dP - delta
             const u32x2 bq = *reinterpret_cast<const u32x2*>(brow + j * 16);
             const float bb[4] = {bflo(bq[0]), bfhi(bq[0]), bflo(bq[1]), bfhi(bq[1])};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float sv = fmaf(s[r], scale, bb[r]);
-              if (SHIFTED) { if (masked(qn, j * 16 + lg * 4 + r)) sv += -100.0f; }
-              const float p = __expf(sv - my_lse);
-              dsp[h][r] = p * (dp[r] - my_del);
+              float c = nl2;
+              if (SHIFTED) { if (masked(qn, j * 16 + lg * 4 + r)) c = nl2m; }
+              const float p = __builtin_amdgcn_exp2f(fmaf(s[r], scale2, fmaf(bb[r], K_LOG2E, c)));
+              dsp[h][r] = p * dp[r];
             }
             dbias[j] += dsp[h];
           }
@@ -212,17 +219,18 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_bf16_kernel(
             const bf16x8 af = *reinterpret_cast<const bf16x8*>(Qr + kswz(i * 16 + lq, lg));
             const bf16x8 bf = *reinterpret_cast<const bf16x8*>(Gr + kswz(i * 16 + lq, lg));
             const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, kf, zero, 0, 0, 0);     // S[query 4lg+r][key lq]
-            const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, vf, zero, 0, 0, 0);
-            const f32x4 ls = *reinterpret_cast<const f32x4*>(&lse_s[i * 16 + lg * 4]);
-            const f32x4 dl = *reinterpret_cast<const f32x4*>(&del_s[i * 16 + lg * 4]);
+            const f32x4 dl = *reinterpret_cast<const f32x4*>(&del_s[i * 16 + lg * 4]);      // -delta
+            const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, vf, dl, 0, 0, 0);      // dP - delta
+            const f32x4 ls = *reinterpret_cast<const f32x4*>(&lse_s[i * 16 + lg * 4]);      // -lse*log2e
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int qn = i * 16 + lg * 4 + r;
-              float sv = fmaf(s[r], scale, bf1(bias_l[(size_t)qn * PANGU_WTOK + kn]));
-              if (SHIFTED) { if (masked(qn, kn)) sv += -100.0f; }
-              const float p = __expf(sv - ls[r]);
+              float c = ls[r];
+              if (SHIFTED) { if (masked(qn, kn)) c += K_MASK2; }
+              const float p = __builtin_amdgcn_exp2f(
+                  fmaf(s[r], scale2, fmaf(bf1(bias_l[(size_t)qn * PANGU_WTOK + kn]), K_LOG2E, c)));
               pp[h][r] = p;
-              dsp[h][r] = p * (dp[r] - dl[r]);
+              dsp[h][r] = p * dp[r];
             }
           }
         }
@@ -286,14 +294,8 @@ extern "C" int pangu_window_attn_bwd_bf16(pangu_stream_t stream, const void* qkv
   const size_t shm = 4 * (size_t)ROWIMG + 3 * (size_t)TIMG + 3 * PANGU_WTOK * sizeof(float) + 64 * sizeof(float) +
                      (size_t)PANGU_WTOK * PANGU_WTOK * sizeof(u16);
   hipStream_t s = (hipStream_t)stream;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_bwd_bf16_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_bwd_bf16_kernel<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    attr_set = true;
-  }
+  PANGU_ENSURE_DYN_LDS(window_attn_bwd_bf16_kernel<true>, shm);
+  PANGU_ENSURE_DYN_LDS(window_attn_bwd_bf16_kernel<false>, shm);
   if (shifted)
     hipLaunchKernelGGL(window_attn_bwd_bf16_kernel<true>, dim3(n_pairs), dim3(NT), shm, s, (const u16*)qkv,
                        (const u16*)qkv_bias, (const u16*)esb, (const u16*)out, lse, (const u16*)dout, (u16*)dqkv, dqkv_bias,

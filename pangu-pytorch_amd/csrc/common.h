@@ -144,6 +144,24 @@ __device__ inline float group_sum(float v) {
 }
 __device__ inline float wave_sum(float v) { return group_sum<64>(v); }
 
+// hipFuncSetAttribute is per (function, DEVICE): remember it per device so that a process driving several GPUs
+// (or a model moved to another GPU) works, while the steady state stays one thread-local hipGetDevice per launch.
+// Runs on the first launch per device, i.e. during warm-up, outside any later graph capture.
+static inline void pangu_ensure_dyn_lds(const void* kern, int bytes, unsigned long long* done_mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(*done_mask & bit)) {
+    (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    *done_mask |= bit;
+  }
+}
+#define PANGU_ENSURE_DYN_LDS(kern, bytes)                                                      \
+  do {                                                                                         \
+    static unsigned long long pangu_lds_done_ = 0ull;                                          \
+    pangu_ensure_dyn_lds(reinterpret_cast<const void*>(kern), (int)(bytes), &pangu_lds_done_); \
+  } while (0)
+
 static inline int pangu_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? PANGU_OK : (int)e;

@@ -347,30 +347,18 @@ int launch_bf16(hipStream_t s, const u16* A, int lda, const u16* W, const float*
   do {                                                                                                                \
     if (glds && glds_mode == 2) {                                                                                     \
       auto kern = gemm_tn_bf16_glds_kernel<TN, ACT, HB, OUT_F32, 2>;                                                  \
-      static bool attr_set_g2 = false;                                                                                \
-      if (!attr_set_g2) {                                                                                             \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
-        attr_set_g2 = true;                                                                                           \
-      }                                                                                                               \
+      PANGU_ENSURE_DYN_LDS(kern, shm);                                                                                \
       hipLaunchKernelGGL(kern, g, blk, shm, s, A, lda, W, bias, C, ldc, M, N, K, m_tiles, n_tiles, aux);              \
       break;                                                                                                          \
     }                                                                                                                 \
     if (glds) {                                                                                                       \
       auto kern = gemm_tn_bf16_glds_kernel<TN, ACT, HB, OUT_F32, GST>;                                                \
-      static bool attr_set_g = false;                                                                                 \
-      if (!attr_set_g) {                                                                                              \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
-        attr_set_g = true;                                                                                            \
-      }                                                                                                               \
+      PANGU_ENSURE_DYN_LDS(kern, shm);                                                                                \
       hipLaunchKernelGGL(kern, g, blk, shm, s, A, lda, W, bias, C, ldc, M, N, K, m_tiles, n_tiles, aux);              \
       break;                                                                                                          \
     }                                                                                                                 \
     auto kern = gemm_tn_bf16_kernel<TN, ACT, HB, OUT_F32>;                                                            \
-    static bool attr_set = false; /* once per instantiation, outside any later graph capture */                       \
-    if (!attr_set) {                                                                                                  \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
-      attr_set = true;                                                                                                \
-    }                                                                                                                 \
+    PANGU_ENSURE_DYN_LDS(kern, shm);                                                                                  \
     hipLaunchKernelGGL(kern, g, blk, shm, s, A, lda, W, bias, C, ldc, M, N, K, m_tiles, n_tiles, aux);                \
   } while (0)
   if (act == PANGU_ACT_GELU) {

@@ -217,11 +217,7 @@ int launch_x3(hipStream_t s, const float* A, int lda, const float* W, const floa
 #define PANGU_X3(ACT, HB)                                                                                             \
   do {                                                                                                                \
     auto kern = gemm_tn_f32x3_kernel<TN, ACT, HB>;                                                                    \
-    static bool attr_set = false;                                                                                     \
-    if (!attr_set) {                                                                                                  \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
-      attr_set = true;                                                                                                \
-    }                                                                                                                 \
+    PANGU_ENSURE_DYN_LDS(kern, shm);                                                                                  \
     hipLaunchKernelGGL(kern, g, blk, shm, s, A, lda, W, bias, C, ldc, M, N, K, m_tiles, n_tiles, aux);                \
   } while (0)
   if (act == PANGU_ACT_GELU) {

@@ -193,11 +193,7 @@ int launch_ln(hipStream_t s, const u16* A, int lda, const u16* W, const float* b
   const size_t epi = (size_t)2 * WNW * 64 * (96 * 2 + 16) + (size_t)2 * WNW * 64 * 2 * sizeof(float);
   const size_t shm = stages > epi ? stages : epi;
   auto kern = gemm_ln_residual_bf16_kernel<WNW>;
-  static bool attr_set = false;               // once per instantiation, outside any later graph capture
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    attr_set = true;
-  }
+  PANGU_ENSURE_DYN_LDS(kern, shm);
   hipLaunchKernelGGL(kern, dim3((M + LBM - 1) / LBM), dim3(128 * WNW), shm, s, A, lda, W, bias, shortcut, gamma, beta, out, ldo,
                      M, K);
   return pangu_launch_status();

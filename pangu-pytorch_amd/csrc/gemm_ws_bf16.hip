@@ -181,11 +181,7 @@ int launch_ws(hipStream_t s, const u16* A, int lda, const u16* W, const float* b
 #define PANGU_WS(ACT, HB)                                                                                             \
   do {                                                                                                                \
     auto kern = gemm_ws_bf16_kernel<BNW, KMAX, ACT, HB, OUT_F32>;                                                     \
-    static bool attr_set = false;                                                                                     \
-    if (!attr_set) {                                                                                                  \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
-      attr_set = true;                                                                                                \
-    }                                                                                                                 \
+    PANGU_ENSURE_DYN_LDS(kern, shm);                                                                                  \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), shm, s, A, lda, W, bias, C, ldc, M, N, K, n_slices, m_tiles, aux); \
   } while (0)
   if (act == PANGU_ACT_GELU) {

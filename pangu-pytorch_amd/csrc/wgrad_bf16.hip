@@ -184,11 +184,7 @@ int launch_wgrad_bf16(hipStream_t s, const u16* dC, int lddc, const u16* A, int 
   split = ((M + rows - 1) / rows + 7) & ~7;                         // grid padded to whole XCD rounds (empty slabs exit)
   const size_t shm = 2 * (size_t)WB_M * (D_LD + BKC * 2 + 32);
   auto kern = wgrad_bf16_kernel<TK, WB_M>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    attr_set = true;
-  }
+  PANGU_ENSURE_DYN_LDS(kern, shm);
   hipLaunchKernelGGL(kern, dim3(tiles * split), dim3(256), shm, s, dC, lddc, A, lda, dW, db, M, N, K, n_tiles, k_tiles, rows);
   return pangu_launch_status();
 }

@@ -131,6 +131,24 @@ def attn_bf16():
             print(f"attn_bf16 C={C} shifted={int(sh)}: {ms:7.3f} ms  {fl / ms / 1e9:6.1f} TF/s  {by / ms / 1e6:7.1f} GB/s (algorithmic)")
 
 
+def attn_bwd():
+    """backward of the window attention, both dtypes: 5 useful GEMMs (dP, dV, dQ, dK + recomputed S) = 10*Np*144*C flop"""
+    from pangu_pytorch_amd import ops_bf16 as ob
+    for C, Z, H, W, heads, types in ((192, 8, 181, 360, 6, 124), (384, 8, 91, 180, 12, 64)):
+        N = Z * H * W
+        Np = (Z // 2) * ((H + 5) // 6) * (W // 12) * 144
+        for mod, dt, tag in ((ops, torch.float32, "f32 "), (ob, torch.bfloat16, "bf16")):
+            qkv = torch.randn(N, 3 * C, device="cuda").to(dt)
+            b1 = torch.randn(3 * C, device="cuda").to(dt)
+            esb = (torch.randn(types, heads, 144, 144, device="cuda") * 0.1).to(dt)
+            dout = torch.randn(N, C, device="cuda").to(dt)
+            for sh in (False, True):
+                out, lse = mod.window_attention(qkv, b1, esb, Z, H, W, heads, sh, want_lse=True)
+                ms = timeit(lambda: mod.window_attention_bwd(qkv, b1, esb, out, lse, dout, Z, H, W, heads, sh))
+                print(f"attn_bwd {tag} C={C} shifted={int(sh)}: {ms:7.3f} ms  {10.0 * Np * 144 * C / ms / 1e9:6.1f} TF/s")
+            del qkv, esb, dout, out, lse
+
+
 def attn():
     for C, Z, H, W, heads, types in ((192, 8, 181, 360, 6, 124), (384, 8, 91, 180, 12, 64)):
         N = Z * H * W
@@ -165,6 +183,6 @@ def rows():
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
-    {"gemm": lambda: gemm("--lib-compare" in sys.argv), "attn": attn, "rows": rows,
+    {"gemm": lambda: gemm("--lib-compare" in sys.argv), "attn": attn, "attn_bwd": attn_bwd, "rows": rows,
      "gemm_bf16": lambda: gemm_bf16("--lib-compare" in sys.argv), "attn_bf16": attn_bf16, "gemm_ln_bf16": gemm_ln_bf16, "gemm_ln": gemm_ln,
      "wgrad_bf16": lambda: wgrad(True), "wgrad": lambda: wgrad(False)}[what]()
