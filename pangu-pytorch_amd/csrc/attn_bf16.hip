@@ -110,11 +110,12 @@ __device__ __forceinline__ void attn_tile(const unsigned char* Ks, const unsigne
   mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
   float sum = 0.f;
+  const float nmx = -mx * 1.4426950408889634f;      // exp(s - mx) = exp2(s*log2e - mx*log2e): one fma + v_exp_f32
 #pragma unroll
   for (int j = 0; j < 9; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float e = __expf(s[j][r] - mx);
+      const float e = __builtin_amdgcn_exp2f(fmaf(s[j][r], 1.4426950408889634f, nmx));
       s[j][r] = e;
       sum += e;
     }

@@ -39,6 +39,7 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
   const int lq = lane & 15, lg = lane >> 4;
   const int C3 = 3 * C;
   const float scale = 0.17677669529663687f;
+  constexpr float K_LOG2E = 1.4426950408889634f;
   const float* bias_tile = esb + (size_t)pair * PANGU_WTOK * PANGU_WTOK;
 
   bool zcut = false, hcut = false;
@@ -90,9 +91,11 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
       d += __shfl_xor(d, 2, 64);
       d += __shfl_xor(d, 4, 64);
       if ((f & 7) == 0) {
-        del_s[n] = d;
-        // a pad query's row of P must vanish (its output is discarded): lse = +huge makes exp(S - lse) = 0
-        lse_s[n] = tok >= 0 ? lse[(size_t)tok * heads + hd] : 1e30f;
+        // row constants in the form the score epilogue consumes: p = exp2(S*log2e - lse*log2e), and -delta as the
+        // INITIAL ACCUMULATOR of the dP product (dS = p * (dP - delta)).  A pad query's row of P must vanish (its
+        // output is discarded): -huge makes exp2(..) = 0
+        del_s[n] = -d;
+        lse_s[n] = tok >= 0 ? -K_LOG2E * lse[(size_t)tok * heads + hd] : -1e30f;
       }
     }
     __syncthreads();
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
       const f32x4 q1 = *reinterpret_cast<const f32x4*>(&Qs[qn * KV_LD + lg * 8 + 4]);
       const f32x4 g0 = *reinterpret_cast<const f32x4*>(&Gs[qn * KV_LD + lg * 8]);
       const f32x4 g1 = *reinterpret_cast<const f32x4*>(&Gs[qn * KV_LD + lg * 8 + 4]);
-      const float my_lse = lse_s[qn], my_del = del_s[qn];
+      const float nl2 = lse_s[qn], nd = del_s[qn];           // -lse*log2e, -delta
       const float* brow = bias_l + (size_t)qn * PANGU_WTOK + lg * 4;
       f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
         const f32x4 k1 = *reinterpret_cast<const f32x4*>(&Ks[krow + 4]);
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(&Vs[krow]);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(&Vs[krow + 4]);
-        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {nd, nd, nd, nd};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           s = __builtin_amdgcn_mfma_f32_16x16x4f32(k0[ks], q0[ks], s, 0, 0, 0);
@@ -134,8 +137,8 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
         for (int r = 0; r < 4; ++r) {
           float sv = s[r];
           if (SHIFTED) { if (masked(qn, j * 16 + lg * 4 + r)) sv += -100.0f; }
-          const float p = __expf(sv - my_lse);
-          ds[r] = p * (dp[r] - my_del);
+          const float p = __builtin_amdgcn_exp2f(fmaf(sv, K_LOG2E, nl2));
+          ds[r] = p * dp[r];
         }
         dbias[j] += ds;
         // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
@@ -169,7 +172,8 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
         const f32x4 a1 = *reinterpret_cast<const f32x4*>(&Qs[qrow + 4]);
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(&Gs[qrow]);
         const f32x4 b1 = *reinterpret_cast<const f32x4*>(&Gs[qrow + 4]);
-        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 ls = *reinterpret_cast<const f32x4*>(&lse_s[i * 16 + lg * 4]);      // -lse*log2e
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = *reinterpret_cast<const f32x4*>(&del_s[i * 16 + lg * 4]);      // -delta
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           s = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[ks], k0[ks], s, 0, 0, 0);
@@ -181,16 +185,14 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
           dp = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[ks], v1[ks], dp, 0, 0, 0);
         }
         // lane: [query = 16i + 4lg + r][key = kn]
-        const f32x4 ls = *reinterpret_cast<const f32x4*>(&lse_s[i * 16 + lg * 4]);
-        const f32x4 dl = *reinterpret_cast<const f32x4*>(&del_s[i * 16 + lg * 4]);
         f32x4 p, ds;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int qn = i * 16 + lg * 4 + r;
           float sv = s[r] + bias_l[(size_t)qn * PANGU_WTOK + kn];
           if (SHIFTED) { if (masked(qn, kn)) sv += -100.0f; }
-          p[r] = __expf(sv - ls[r]);
-          ds[r] = p[r] * (dp[r] - dl[r]);
+          p[r] = __builtin_amdgcn_exp2f(fmaf(sv, K_LOG2E, ls[r]));
+          ds[r] = p[r] * dp[r];
         }
         // dV[key][d] += P[query][key] dO[query][d];  dK[key][d] += dS[query][key] Qs[query][d]
 #pragma unroll

@@ -98,11 +98,12 @@ __device__ __forceinline__ float softmax_max(f32x4 (&s)[9], int qn, bool zcut, b
 template <int JLO, int JHI>
 __device__ __forceinline__ float softmax_exp(f32x4 (&s)[9], float mx) {
   float sum = 0.f;
+  const float nmx = -mx * 1.4426950408889634f;      // exp(s - mx) = exp2(s*log2e - mx*log2e): one fma + v_exp_f32
 #pragma unroll
   for (int j = JLO; j < JHI; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float e = __expf(s[j][r] - mx);
+      const float e = __builtin_amdgcn_exp2f(fmaf(s[j][r], 1.4426950408889634f, nmx));
       s[j][r] = e;
       sum += e;
     }
