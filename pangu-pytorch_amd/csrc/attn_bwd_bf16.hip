@@ -178,10 +178,10 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_bf16_kernel(
             const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, gf, ndel, 0, 0, 0);     // dP - delta
             const u32x2 bq = *reinterpret_cast<const u32x2*>(brow + j * 16);
             const float bb[4] = {bflo(bq[0]), bfhi(bq[0]), bflo(bq[1]), bfhi(bq[1])};
+            float c = nl2;                  // the 4 keys of a lane share the mask (cuts fall on multiples of 12 and at 72)
+            if (SHIFTED) { if (masked(qn, j * 16 + lg * 4)) c = nl2m; }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float c = nl2;
-              if (SHIFTED) { if (masked(qn, j * 16 + lg * 4 + r)) c = nl2m; }
               const float p = __builtin_amdgcn_exp2f(fmaf(s[r], scale2, fmaf(bb[r], K_LOG2E, c)));
               dsp[h][r] = p * dp[r];
             }
@@ -222,13 +222,13 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_bf16_kernel(
             const f32x4 dl = *reinterpret_cast<const f32x4*>(&del_s[i * 16 + lg * 4]);      // -delta
             const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, vf, dl, 0, 0, 0);      // dP - delta
             const f32x4 ls = *reinterpret_cast<const f32x4*>(&lse_s[i * 16 + lg * 4]);      // -lse*log2e
+            float cm = 0.f;                 // the 4 queries of a lane share the mask
+            if (SHIFTED) { if (masked(i * 16 + lg * 4, kn)) cm = K_MASK2; }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int qn = i * 16 + lg * 4 + r;
-              float c = ls[r];
-              if (SHIFTED) { if (masked(qn, kn)) c += K_MASK2; }
               const float p = __builtin_amdgcn_exp2f(
-                  fmaf(s[r], scale2, fmaf(bf1(bias_l[(size_t)qn * PANGU_WTOK + kn]), K_LOG2E, c)));
+                  fmaf(s[r], scale2, fmaf(bf1(bias_l[(size_t)qn * PANGU_WTOK + kn]), K_LOG2E, ls[r] + cm)));
               pp[h][r] = p;
               dsp[h][r] = p * dp[r];
             }

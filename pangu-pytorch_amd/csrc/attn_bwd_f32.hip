@@ -1,23 +1,29 @@
 // Backward of the Earth-specific window attention, fp32, gfx950.
 //
-// One workgroup of 9 waves per (window type t, head); it walks the nLon longitude windows that share the
-// bias tile esb[t][head], so the bias gradient d_esb[t][head] = sum_l dS stays in registers (36 per wave) and
-// is written once: no atomics, no (..,144,144) tensor in HBM.
+// One workgroup of 12 waves (9 tile owners + 3 helpers) per (window type t, head); it walks the nLon longitude windows
+// that share the bias tile esb[t][head], so the bias gradient d_esb[t][head] = sum_l dS stays in registers (36 per
+// owner wave) and is written once: no atomics, no (..,144,144) tensor in HBM.
 // Per window, Q(scaled), K, V, dO (144 x 32 each) are staged in LDS; P is recomputed from the saved
 // log-sum-exp.  Wave w owns QUERY tile w for {dQ, d_esb} and KEY tile w for {dK, dV}; the scores are computed in
 // both orientations (S^T for the first, S for the second) so that every probability / dS accumulator is
 // directly an MFMA operand of the next product (no LDS transposes, no cross-wave reductions):
 //   phase A (S^T[key][query], query tile w):  dP^T = V dO^T,  dS^T = P^T o (dP^T - delta),  dQ^T = K^T dS^T
 //   phase B (S[query][key],  key tile w):     dP = dO V^T,    dS = P o (dP - delta),  dV = P^T dO,  dK = dS^T Qs
-// 504 v_mfma_f32_16x16x4_f32 per wave and window.  Zero-pad slots (q/k/v = linear1.bias) send their k/v gradient
+// 504 v_mfma_f32_16x16x4_f32 per key/query tile and window.  The workgroup is alone on its CU, and nine waves would sit
+// 3/2/2/2 on the four SIMDs with the full one setting the pace of every window: three helper waves take the last four
+// query tiles of every key tile's phase B (partial dK/dV handed back through LDS), so that each SIMD runs three waves
+// of 376-384 MFMAs (+20 % unshifted).  The shift mask is window-invariant and constant over the 4 tokens a lane holds
+// per tile: one bit per tile, built once before the window loop (+38 % shifted).  Zero-pad slots (q/k/v = linear1.bias) send their k/v gradient
 // to dqkv_bias with atomics (2.7 % of slots); every real token row of dqkv is written exactly once.
 #include "common.h"
 
 namespace {
 
 constexpr int KV_LD = 36;
-constexpr int NW = 9;                      // waves per workgroup = query tiles = key tiles
+constexpr int NQ = 9;                      // query tiles = key tiles (16 tokens each)
+constexpr int NW = 12;                     // waves per workgroup: 9 tile owners + 3 helpers (three waves on every SIMD)
 constexpr int NT = NW * 64;
+constexpr int I_SPLIT = 5;                 // phase B: the owner of key tile k sums query tiles [0,5), a helper [5,9)
 
 template <bool SHIFTED>
 __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
@@ -32,6 +38,7 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
   __shared__ __attribute__((aligned(16))) float del_s[PANGU_WTOK];
   __shared__ int tok_s[PANGU_WTOK];
   __shared__ float pad_s[64];            // [2][32]: dK, dV summed over the zero-pad keys of this (type, head)
+  __shared__ __attribute__((aligned(16))) f32x4 part_s[NQ * 4 * 64];      // helpers' partial dK/dV per key tile
 
   const int pair = blockIdx.x;
   const int t = pair / heads, hd = pair - t * heads;
@@ -58,6 +65,29 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
   f32x4 dbias[9];
 #pragma unroll
   for (int j = 0; j < 9; ++j) dbias[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // An owner (wave < 9) sums query tiles [0, I_SPLIT) for its key tile in phase B (and keeps the sums in registers);
+  // helper h sums [I_SPLIT, 9) for key tiles 3h .. 3h+2 and hands the partial sums over through LDS: 216 + 160 MFMAs
+  // per owner, 3 x 128 per helper -- every SIMD runs three waves with the same load (nine waves alone would put three
+  // on one SIMD and two on the others, and the full SIMD sets the pace of every window)
+  const bool owner = wave < NQ;
+  const int ntask = owner ? 1 : 3, i0 = owner ? 0 : I_SPLIT, i1 = owner ? I_SPLIT : NQ;
+  // The mask does not depend on the window, and it is the same for the 4 tokens 16x + 4lg + r a lane holds (the cuts
+  // fall on multiples of 12 and at 72): one bit per 16-token tile, built once.  maskA bit j: key tile j against this
+  // lane's query (phase A); maskB bit 9*kk + i: query tile i against this lane's key of task kk (phase B).
+  unsigned maskA = 0u, maskB = 0u;
+  if (SHIFTED) {
+    if (zcut || hcut) {
+      if (owner)
+        for (int j = 0; j < 9; ++j)
+          if (masked(wave * 16 + lq, j * 16 + lg * 4)) maskA |= 1u << j;
+      for (int kk = 0; kk < ntask; ++kk) {
+        const int kn = (owner ? wave : 3 * (wave - NQ) + kk) * 16 + lq;
+        for (int i = 0; i < 9; ++i)
+          if (masked(i * 16 + lg * 4, kn)) maskB |= 1u << (9 * kk + i);
+      }
+    }
+  }
 
   for (int l = 0; l < g.nLon; ++l) {
     __syncthreads();                               // previous window's LDS reads are done
@@ -100,8 +130,8 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
     }
     __syncthreads();
 
-    // =========================== phase A: query tile `wave`, S^T orientation ===========================
-    {
+    // =========================== phase A: query tile `wave`, S^T orientation (tile owners) =============
+    if (wave < NQ) {
       const int qn = wave * 16 + lq;
       const int qtok = tok_s[qn];
       const f32x4 q0 = *reinterpret_cast<const f32x4*>(&Qs[qn * KV_LD + lg * 8]);
@@ -109,6 +139,7 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
       const f32x4 g0 = *reinterpret_cast<const f32x4*>(&Gs[qn * KV_LD + lg * 8]);
       const f32x4 g1 = *reinterpret_cast<const f32x4*>(&Gs[qn * KV_LD + lg * 8 + 4]);
       const float nl2 = lse_s[qn], nd = del_s[qn];           // -lse*log2e, -delta
+      const float nl2m = nl2 - 100.0f * K_LOG2E;
       const float* brow = bias_l + (size_t)qn * PANGU_WTOK + lg * 4;
       f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -133,11 +164,11 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
         // lane: [key = 16j + 4lg + r][query = qn]
         s += *reinterpret_cast<const f32x4*>(brow + j * 16);
         f32x4 ds;
+        float c = nl2;                      // mask folded into the row constant
+        if (SHIFTED) { if ((maskA >> j) & 1u) c = nl2m; }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float sv = s[r];
-          if (SHIFTED) { if (masked(qn, j * 16 + lg * 4 + r)) sv += -100.0f; }
-          const float p = __builtin_amdgcn_exp2f(fmaf(sv, K_LOG2E, nl2));
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[r], K_LOG2E, c));
           ds[r] = p * dp[r];
         }
         dbias[j] += ds;
@@ -157,16 +188,15 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
       }
     }
 
-    // =========================== phase B: key tile `wave`, S orientation ===========================
-    {
-      const int kn = wave * 16 + lq;                        // this lane's key column
+    // =========================== phase B: key tile kt, S orientation, query tiles [i0, i1) ===============
+    auto phase_b = [&](int kt, unsigned mbits, f32x4& dv0, f32x4& dv1, f32x4& dk0, f32x4& dk1) {
+      const int kn = kt * 16 + lq;                          // this lane's key column
       const f32x4 k0 = *reinterpret_cast<const f32x4*>(&Ks[kn * KV_LD + lg * 8]);
       const f32x4 k1 = *reinterpret_cast<const f32x4*>(&Ks[kn * KV_LD + lg * 8 + 4]);
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(&Vs[kn * KV_LD + lg * 8]);
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(&Vs[kn * KV_LD + lg * 8 + 4]);
-      f32x4 dv0 = {0.f, 0.f, 0.f, 0.f}, dv1 = dv0, dk0 = dv0, dk1 = dv0;
 #pragma unroll 1
-      for (int i = 0; i < 9; ++i) {
+      for (int i = i0; i < i1; ++i) {
         const int qrow = (i * 16 + lq) * KV_LD + lg * 8;
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(&Qs[qrow]);
         const f32x4 a1 = *reinterpret_cast<const f32x4*>(&Qs[qrow + 4]);
@@ -186,12 +216,13 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
         }
         // lane: [query = 16i + 4lg + r][key = kn]
         f32x4 p, ds;
+        float cm = 0.f;
+        if (SHIFTED) { if ((mbits >> i) & 1u) cm = -100.0f * K_LOG2E; }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int qn = i * 16 + lg * 4 + r;
-          float sv = s[r] + bias_l[(size_t)qn * PANGU_WTOK + kn];
-          if (SHIFTED) { if (masked(qn, kn)) sv += -100.0f; }
-          p[r] = __builtin_amdgcn_exp2f(fmaf(sv, K_LOG2E, ls[r]));
+          const float sv = s[r] + bias_l[(size_t)qn * PANGU_WTOK + kn];
+          p[r] = __builtin_amdgcn_exp2f(fmaf(sv, K_LOG2E, ls[r] + cm));
           ds[r] = p[r] * dp[r];
         }
         // dV[key][d] += P[query][key] dO[query][d];  dK[key][d] += dS[query][key] Qs[query][d]
@@ -204,6 +235,22 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
           dk1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[r], Qs[qn * KV_LD + 16 + lq], dk1, 0, 0, 0);
         }
       }
+    };
+    f32x4 dv0, dv1, dk0, dk1;
+#pragma unroll 1
+    for (int kk = 0; kk < ntask; ++kk) {
+      const int kt = owner ? wave : 3 * (wave - NQ) + kk;
+      dv0 = f32x4{0.f, 0.f, 0.f, 0.f}; dv1 = dv0; dk0 = dv0; dk1 = dv0;
+      phase_b(kt, maskB >> (9 * kk), dv0, dv1, dk0, dk1);
+      if (!owner) {
+        f32x4* dst = part_s + kt * 4 * 64 + lane;
+        dst[0] = dv0; dst[64] = dv1; dst[128] = dk0; dst[192] = dk1;
+      }
+    }
+    __syncthreads();
+    if (wave < NQ) {
+      const f32x4* src = part_s + wave * 4 * 64 + lane;
+      dv0 += src[0]; dv1 += src[64]; dk0 += src[128]; dk1 += src[192];
       // lane: dK/dV[key = 16*wave + 4lg + r][d = 16dt + lq]
       bool any_pad = false;
 #pragma unroll
@@ -240,9 +287,11 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
   __syncthreads();
   if (tid < 64 && pad_s[tid] != 0.f) atomicAdd(dqkv_bias + (tid < 32 ? C : 2 * C) + hd * 32 + (tid & 31), pad_s[tid]);
   // ---- bias gradient tile: lane holds sum_l dS^T[key = 16j + 4lg + r][query = 16*wave + lq]
-  float* drow = d_esb + (size_t)pair * PANGU_WTOK * PANGU_WTOK + (size_t)(wave * 16 + lq) * PANGU_WTOK + lg * 4;
+  if (wave < NQ) {
+    float* drow = d_esb + (size_t)pair * PANGU_WTOK * PANGU_WTOK + (size_t)(wave * 16 + lq) * PANGU_WTOK + lg * 4;
 #pragma unroll
-  for (int j = 0; j < 9; ++j) *reinterpret_cast<f32x4*>(drow + j * 16) = dbias[j];
+    for (int j = 0; j < 9; ++j) *reinterpret_cast<f32x4*>(drow + j * 16) = dbias[j];
+  }
 }
 
 }  // namespace
