@@ -300,3 +300,32 @@ def test_block_droppath_branches(P, s1, s2):
             assert q.grad is None or float(q.grad.abs().max()) == 0.0, k
         else:
             assert rel_err(q.grad, want) < TIGHT, k
+
+
+def test_block_backward_batch_of_two(P):
+    """A batch of two through the autograd path == the two samples run one by one: outputs per sample, input gradients
+    per sample, parameter gradients summed (the per-sample slicing is a view / one unbind, never a SelectBackward)."""
+    C, roll, W = 384, True, 12
+    st = cases.STAGES[C]
+    blk = P.layers.EarthSpecificBlock(C, 0.0, st["heads"], device="cuda").cuda().eval()
+    pre = cases.block_prefix(C, roll)
+    blk.load_state_dict({k: synth.synth_param(pre + k, s, "cuda") for k, s in cases.block_param_shapes(C).items()})
+    x0 = cases.block_input(C, W, "cuda")
+    x1 = synth.uniform(x0.shape, 4242, device="cuda")
+    cot = cases.cotangent("b2", (2,) + tuple(x0.shape[1:]), "cuda")
+    xb = torch.cat([x0, x1], 0).requires_grad_(True)
+    yb = blk(xb, st["Z"], st["H"], W, roll)
+    (yb * cot).sum().backward()
+    gb = {k: q.grad.clone() for k, q in blk.named_parameters()}
+    blk.zero_grad(set_to_none=True)
+    singles = []
+    for i, xi in enumerate((x0, x1)):
+        xi = xi.clone().requires_grad_(True)
+        yi = blk(xi, st["Z"], st["H"], W, roll)
+        (yi * cot[i:i + 1]).sum().backward()
+        singles.append((yi.detach(), xi.grad))
+    for i, (yi, gi) in enumerate(singles):
+        assert torch.equal(yb[i:i + 1].detach(), yi)
+        assert torch.equal(xb.grad[i:i + 1], gi)
+    for k, q in blk.named_parameters():
+        assert rel_err(gb[k], q.grad) < 1e-5, k         # sums of two atomically accumulated gradients: order may differ
