@@ -182,6 +182,10 @@ int launch_wgrad(hipStream_t s, const float* dC, int lddc, const float* A, int l
 
 }  // namespace
 
+// wgrad_f32_dma.hip: LDS-DMA variant for N % (64*TNN) == 0, K % 192 == 0; returns 1 when the shape is not covered
+int pangu_linear_wgrad_f32_dma(hipStream_t s, const float* dC, int lddc, const float* A, int lda, float* dW, float* db,
+                               int M, int N, int K, int tnn, int target);
+
 extern "C" int pangu_linear_wgrad(pangu_stream_t stream, const float* dC, int lddc, const float* A, int lda, float* dW,
                                   float* db, int M, int N, int K) {
   if (!dC || !A || !dW) return PANGU_E_NULL;
@@ -192,6 +196,12 @@ extern "C" int pangu_linear_wgrad(pangu_stream_t stream, const float* dC, int ld
   // measured (tools/bench_kernels.py wgrad): 192-row tiles win where 128-row tiles would be part empty (N = 192, 576, 160)
   // and at N = 1152 (12 instead of 18 tiles per slab); 128-row tiles win at N = 384, 768, 1536
   const bool wide = force_tnn ? force_tnn == 3 : (N % 192 == 0 && N % 384 != 0) || (N > 128 && N < 192) || N == 1152;
+  static const int use_dma = getenv("PANGU_WGRAD_DMA") ? atoi(getenv("PANGU_WGRAD_DMA")) : 1;      // A/B knob
+  static const int dma_target = getenv("PANGU_WGRAD_DMA_WGS") ? atoi(getenv("PANGU_WGRAD_DMA_WGS")) : 768;    // measured sweep 768 / 1024 / 1536 / 2048: 768 best (1536 within 1 %)
+  if (use_dma) {
+    const int rc = pangu_linear_wgrad_f32_dma(s, dC, lddc, A, lda, dW, db, M, N, K, wide ? 3 : 2, dma_target);
+    if (rc != 1) return rc;
+  }
   if (wide) {
     if (K % 192 == 0) return launch_wgrad<3, 3>(s, dC, lddc, A, lda, dW, db, M, N, K);
     if (K % 128 == 0) return launch_wgrad<3, 2>(s, dC, lddc, A, lda, dW, db, M, N, K);
