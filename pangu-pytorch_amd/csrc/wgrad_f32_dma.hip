@@ -158,8 +158,8 @@ int launch_wgrad_dma(hipStream_t s, const float* dC, int lddc, const float* A, i
 // -> PANGU_OK when launched, 1 when the shape is not covered (the caller falls back to the register-staged kernel)
 int pangu_linear_wgrad_f32_dma(hipStream_t s, const float* dC, int lddc, const float* A, int lda, float* dW, float* db,
                                int M, int N, int K, int tnn, int target) {
-  // the VGPR offset of the last token row must stay a 32-bit byte offset
-  if ((size_t)M * (size_t)lddc * 4u >= 0xFFFF0000ull || (size_t)M * (size_t)lda * 4u >= 0xFFFF0000ull) return 1;
+  // the VGPR byte offset of the last slab's rows (up to M + 15, plus one row of columns) must not wrap 32 bits
+  if (((size_t)M + 32) * (size_t)lddc * 4u >= 0xFFFFFFFFull || ((size_t)M + 32) * (size_t)lda * 4u >= 0xFFFFFFFFull) return 1;
   if (K % 192 != 0) return 1;
   if (tnn == 3 && N % 192 == 0) return launch_wgrad_dma<3, 3>(s, dC, lddc, A, lda, dW, db, M, N, K, target);
   if (tnn == 2 && N % 128 == 0) return launch_wgrad_dma<2, 3>(s, dC, lddc, A, lda, dW, db, M, N, K, target);
