@@ -33,6 +33,8 @@ extern "C" {
 #define PANGU_E_NULL (-2)      /* required pointer is NULL */
 #define PANGU_E_DTYPE (-3)     /* unsupported dtype tag */
 #define PANGU_E_ARG (-4)       /* other invalid argument */
+#define PANGU_E_RANGE (-5)     /* a row-strided matrix spans 4 GB or more: the linear / wgrad entries use 32-bit byte
+                                  offsets (range-checked buffer addressing); split the call by rows */
 
 #define PANGU_F32 0
 #define PANGU_BF16 1

@@ -10,6 +10,7 @@ extern "C" const char* pangu_error_string(int code) {
     case PANGU_E_NULL: return "null pointer";
     case PANGU_E_DTYPE: return "unsupported dtype";
     case PANGU_E_ARG: return "invalid argument";
+    case PANGU_E_RANGE: return "matrix spans 4 GB or more (32-bit byte offsets): split the call by rows";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
   }
 }

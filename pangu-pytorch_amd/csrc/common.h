@@ -162,6 +162,13 @@ static inline void pangu_ensure_dyn_lds(const void* kern, int bytes, unsigned lo
     pangu_ensure_dyn_lds(reinterpret_cast<const void*>(kern), (int)(bytes), &pangu_lds_done_); \
   } while (0)
 
+// The GEMM-family kernels address their operands through buffer descriptors with 32-bit BYTE offsets (that is what
+// makes the range-checked, branch-free tails possible): a matrix whose last row starts at or beyond 4 GB cannot be
+// addressed and is refused with PANGU_E_RANGE (the Python layer splits such calls by rows, ops._row_chunks).
+static inline bool pangu_fits_u32(long long rows, long long ld, int elem_bytes) {
+  return (rows + 256) * ld * elem_bytes < 0xFFFFFFFFll;
+}
+
 static inline int pangu_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? PANGU_OK : (int)e;

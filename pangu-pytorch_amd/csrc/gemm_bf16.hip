@@ -385,6 +385,7 @@ extern "C" int pangu_linear_fwd_bf16(pangu_stream_t stream, const void* A, int l
                                      void* C, int ldc, int M, int N, int K, int act, void* aux, int out_dtype) {
   if (!A || !W || !C) return PANGU_E_NULL;
   if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (N & 7) || lda < K || ldc < N || (lda & 7) || (ldc & 3)) return PANGU_E_SHAPE;
+  if (!pangu_fits_u32(M, lda, 2) || !pangu_fits_u32(M, ldc, 4)) return PANGU_E_RANGE;
   if (act != PANGU_ACT_NONE && act != PANGU_ACT_GELU && act != PANGU_ACT_GELU_BWD && act != PANGU_ACT_ADD) return PANGU_E_ARG;
   if (act == PANGU_ACT_GELU_BWD && (!aux || bias)) return PANGU_E_ARG;
   if (act == PANGU_ACT_ADD && !aux) return PANGU_E_ARG;

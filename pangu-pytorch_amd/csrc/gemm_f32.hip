@@ -219,6 +219,7 @@ extern "C" int pangu_linear_fwd(pangu_stream_t stream, const float* A, int lda, 
     return PANGU_E_SHAPE;
   if (act != PANGU_ACT_NONE && act != PANGU_ACT_GELU && act != PANGU_ACT_GELU_BWD && act != PANGU_ACT_ADD) return PANGU_E_ARG;
   if ((act == PANGU_ACT_GELU_BWD || act == PANGU_ACT_ADD) && !aux) return PANGU_E_NULL;
+  if (!pangu_fits_u32(M, lda, 4) || !pangu_fits_u32(M, ldc, 4)) return PANGU_E_RANGE;
   hipStream_t s = (hipStream_t)stream;
   static const int force_tn = getenv("PANGU_GEMM_TN") ? atoi(getenv("PANGU_GEMM_TN")) : 0;   // tuning knob
   if (force_tn == 1) return launch_tn<1>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);

@@ -237,6 +237,7 @@ extern "C" int pangu_linear_fwd_f32x3(pangu_stream_t stream, const float* A, int
                                       float* C, int ldc, int M, int N, int K, int act, float* aux) {
   if (!A || !W || !C) return PANGU_E_NULL;
   if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (N & 3) || lda < K || ldc < N || (lda & 3) || (ldc & 3)) return PANGU_E_SHAPE;
+  if (!pangu_fits_u32(M, lda, 4) || !pangu_fits_u32(M, ldc, 4)) return PANGU_E_RANGE;
   if (act != PANGU_ACT_NONE && act != PANGU_ACT_GELU && act != PANGU_ACT_GELU_BWD) return PANGU_E_ARG;
   if (act == PANGU_ACT_GELU_BWD && !aux) return PANGU_E_NULL;
   hipStream_t s = (hipStream_t)stream;

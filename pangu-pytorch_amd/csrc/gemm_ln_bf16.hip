@@ -206,6 +206,7 @@ extern "C" int pangu_linear_ln_residual_fwd_bf16(pangu_stream_t stream, const vo
                                                  const float* beta, void* out, int ldo, int M, int N, int K) {
   if (!A || !W || !shortcut || !gamma || !beta || !out) return PANGU_E_NULL;
   if (M <= 0 || K <= 0 || (K & 7) || lda < K || (lda & 7) || ldo < N || (ldo & 7)) return PANGU_E_SHAPE;
+  if (!pangu_fits_u32(M, lda, 2) || !pangu_fits_u32(M, ldo, 2)) return PANGU_E_RANGE;
   if (N != 192 && N != 384) return PANGU_E_SHAPE;          // the tile must span the whole row
   hipStream_t s = (hipStream_t)stream;
   if (N == 192)

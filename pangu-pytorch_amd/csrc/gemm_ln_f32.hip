@@ -212,6 +212,7 @@ extern "C" int pangu_linear_ln_residual_fwd(pangu_stream_t stream, const float* 
   if (!A || !W || !shortcut || !gamma || !beta || !out) return PANGU_E_NULL;
   if (M <= 0 || K <= 0 || (K % BK) != 0 || lda < K || (lda & 3) || ldo < N || (ldo & 3) || lds < N || (lds & 3))
     return PANGU_E_SHAPE;
+  if (!pangu_fits_u32(M, lda, 4) || !pangu_fits_u32(M, ldo, 4) || !pangu_fits_u32(M, lds, 4)) return PANGU_E_RANGE;
   hipStream_t s = (hipStream_t)stream;
   // default: the LDS-DMA kernels (gemm_ln_f32_dma.hip: N = 192 and N = 384); PANGU_LN_DMA=0 keeps the register-staged N = 192 one
   static const int dma = getenv("PANGU_LN_DMA") ? atoi(getenv("PANGU_LN_DMA")) : 1;

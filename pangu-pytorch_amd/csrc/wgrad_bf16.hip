@@ -195,6 +195,7 @@ extern "C" int pangu_linear_wgrad_bf16(pangu_stream_t stream, const void* dC, in
                                        float* db, int M, int N, int K) {
   if (!dC || !A || !dW) return PANGU_E_NULL;
   if (M <= 0 || N <= 0 || K <= 0 || (N & 7) || (K & 7) || lddc < N || lda < K || (lddc & 7) || (lda & 7)) return PANGU_E_SHAPE;
+  if (!pangu_fits_u32(M, lddc, 2) || !pangu_fits_u32(M, lda, 2)) return PANGU_E_RANGE;
   hipStream_t s = (hipStream_t)stream;
   const u16* d = (const u16*)dC;
   const u16* a = (const u16*)A;

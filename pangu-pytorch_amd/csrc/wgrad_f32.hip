@@ -191,6 +191,7 @@ extern "C" int pangu_linear_wgrad(pangu_stream_t stream, const float* dC, int ld
   if (!dC || !A || !dW) return PANGU_E_NULL;
   if (M <= 0 || N <= 0 || K <= 0 || (N & 3) || (K & 3) || lddc < N || lda < K || (lddc & 3) || (lda & 3))
     return PANGU_E_SHAPE;
+  if (!pangu_fits_u32(M, lddc, 4) || !pangu_fits_u32(M, lda, 4)) return PANGU_E_RANGE;
   hipStream_t s = (hipStream_t)stream;
   static const int force_tnn = getenv("PANGU_WGRAD_TNN") ? atoi(getenv("PANGU_WGRAD_TNN")) : 0;   // tuning knob
   // measured (tools/bench_kernels.py wgrad): 192-row tiles win where 128-row tiles would be part empty (N = 192, 576, 160)

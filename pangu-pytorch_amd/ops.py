@@ -93,6 +93,22 @@ def _rows(t, name):
     return t.data_ptr(), t.stride(0)
 
 
+_U32_BYTES = (1 << 32) - (1 << 24)
+
+
+def _row_chunks(M, *row_bytes):
+    """The GEMM-family kernels address operands with 32-bit byte offsets (PANGU_E_RANGE): row ranges [(m0, m1), ..] that
+    keep every operand below 4 GB, or None when the call fits as it is (every shape of the B <= 2 model does)."""
+    lim = _U32_BYTES // max(row_bytes) - 256          # the C entries keep 256 rows of slack for their tile tails
+    if M <= lim:
+        return None
+    if lim < 1:
+        raise RuntimeError(f"row stride of {max(row_bytes)} bytes is too large for the 32-bit addressed GEMM kernels")
+    if lim >= 64:
+        lim = lim // 64 * 64
+    return [(m, min(M, m + lim)) for m in range(0, M, lim)]
+
+
 def window_index(Z, H, W, shifted, device):
     lib = _lib.load()
     Hp = H + 5
@@ -125,6 +141,11 @@ def linear(a, weight, bias=None, act=ACT_NONE, out=None, aux=None):
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     op, ldc = _rows(out, "linear.out")
+    chunks = _row_chunks(M, 4 * lda, 4 * ldc)
+    if chunks is not None:
+        for m0, m1 in chunks:
+            linear(a[m0:m1], weight, bias, act, out[m0:m1], aux[m0:m1] if aux is not None else None)
+        return out
     split = _F32_SPLIT and K % 8 == 0 and act != ACT_ADD
     fn = lib.pangu_linear_fwd_f32x3 if split else lib.pangu_linear_fwd
     with _timed("linear_x3" if split else "linear", 2.0 * M * N * K):
@@ -145,6 +166,11 @@ def linear_ln_residual(a, weight, bias, shortcut, gamma, beta, out=None, branch_
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     op, ldo = _rows(out, "linear_ln.out")
+    chunks = _row_chunks(M, 4 * lda, 4 * ldo, 4 * lds)
+    if chunks is not None:
+        for m0, m1 in chunks:
+            linear_ln_residual(a[m0:m1], weight, bias, shortcut[m0:m1], gamma, beta, out[m0:m1], branch_scale)
+        return out
     with _timed("linear_ln", 2.0 * M * N * K):      # its own bucket: not the plain GEMM kernel of bench.py's roofline
         _lib.check(lib.pangu_linear_ln_residual_fwd(
             _stream(), ap, lda, _chk(weight, "linear_ln.weight"), _chk(bias, "linear_ln.bias") if bias is not None else None,
@@ -162,9 +188,11 @@ def linear_wgrad(dc, a, want_bias=True):
     buf = torch.zeros((N * K + (N if want_bias else 0),), dtype=torch.float32, device=dc.device)   # one fill launch
     dw = buf[:N * K].view(N, K)
     db = buf[N * K:] if want_bias else None
-    with _timed("wgrad", 2.0 * M * N * K):
-        _lib.check(lib.pangu_linear_wgrad(_stream(), dp, lddc, ap, lda, dw.data_ptr(),
-                                          db.data_ptr() if want_bias else None, M, N, K), "linear_wgrad")
+    esz = dc.element_size()
+    for m0, m1 in (_row_chunks(M, esz * lddc, esz * lda) or [(0, M)]):      # the kernel ADDS into dw / db
+        with _timed("wgrad", 2.0 * (m1 - m0) * N * K):
+            _lib.check(lib.pangu_linear_wgrad(_stream(), dp + m0 * lddc * esz, lddc, ap + m0 * lda * esz, lda, dw.data_ptr(),
+                                              db.data_ptr() if want_bias else None, m1 - m0, N, K), "linear_wgrad")
     return dw, db
 
 

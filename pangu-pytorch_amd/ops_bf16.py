@@ -2,7 +2,7 @@
 import torch
 
 from . import _lib
-from .ops import _stream, _timed
+from .ops import _row_chunks, _stream, _timed
 
 ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_ADD = 0, 1, 2, 3
 BF16, F32 = 1, 0
@@ -30,6 +30,11 @@ def linear(a, weight, bias=None, act=ACT_NONE, out=None, aux=None, out_dtype=tor
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=a.device)
     op, ldc = _rows(out, "linear.out")
+    chunks = _row_chunks(M, 2 * lda, out.element_size() * ldc)      # 32-bit byte offsets in the kernels (PANGU_E_RANGE)
+    if chunks is not None:
+        for m0, m1 in chunks:
+            linear(a[m0:m1], weight, bias, act, out[m0:m1], aux[m0:m1] if aux is not None else None, out_dtype)
+        return out
     with _timed("linear_bf16", 2.0 * M * N * K):
         _lib.check(lib.pangu_linear_fwd_bf16(_stream(), ap, lda, _p(weight, "weight"),
                                              _p(bias, "bias", torch.float32) if bias is not None else None, op, ldc, M,
@@ -63,6 +68,11 @@ def linear_ln_residual(a, weight, bias, shortcut, gamma, beta, out=None):
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
     op, ldo = _rows(out, "linear_ln.out")
+    chunks = _row_chunks(M, 2 * lda, 2 * ldo)
+    if chunks is not None:
+        for m0, m1 in chunks:
+            linear_ln_residual(a[m0:m1], weight, bias, shortcut[m0:m1], gamma, beta, out[m0:m1])
+        return out
     with _timed("linear_ln_bf16", 2.0 * M * N * K):
         _lib.check(lib.pangu_linear_ln_residual_fwd_bf16(
             _stream(), ap, lda, _p(weight, "weight"), _p(bias, "bias", torch.float32) if bias is not None else None,
@@ -130,9 +140,10 @@ def linear_wgrad(dc, a, want_bias=True):
     buf = torch.zeros((N * K + (N if want_bias else 0),), dtype=torch.float32, device=dc.device)   # one fill launch
     dw = buf[:N * K].view(N, K)
     db = buf[N * K:] if want_bias else None
-    with _timed("wgrad_bf16", 2.0 * M * N * K):
-        _lib.check(lib.pangu_linear_wgrad_bf16(_stream(), dp, lddc, ap, lda, dw.data_ptr(),
-                                               db.data_ptr() if want_bias else None, M, N, K), "linear_wgrad_bf16")
+    for m0, m1 in (_row_chunks(M, 2 * lddc, 2 * lda) or [(0, M)]):      # the kernel ADDS into dw / db
+        with _timed("wgrad_bf16", 2.0 * (m1 - m0) * N * K):
+            _lib.check(lib.pangu_linear_wgrad_bf16(_stream(), dp + m0 * lddc * 2, lddc, ap + m0 * lda * 2, lda, dw.data_ptr(),
+                                                   db.data_ptr() if want_bias else None, m1 - m0, N, K), "linear_wgrad_bf16")
     return dw, db
 
 

@@ -332,3 +332,28 @@ def test_window_attention_other_geometries(P, Z, H, W, heads, shifted):
     ref16, _ = O.window_attention_core(q16.float(), b16.float(), e16.float(), Z, H, W, heads, shifted)
     got16 = ob.window_attention(q16[0].cuda(), b16.cuda(), e16[0].cuda(), Z, H, W, heads, shifted)
     assert rel_err(got16, ref16[0]) < 1.0 / 64
+
+
+def test_linear_rows_beyond_4gb(P):
+    """The GEMM kernels use 32-bit byte offsets (range-checked buffer addressing): the C entry refuses a matrix whose
+    rows reach 4 GB (PANGU_E_RANGE, nothing launched) and the Python layer splits such calls by rows -- results equal."""
+    ops = P.ops
+    ld, M, K, N = 1 << 20, 1100, 64, 128                 # 1100 rows x 4 MB row stride = 4.6 GB
+    big = torch.empty((M, ld), dtype=torch.float32, device="cuda")
+    a = big[:, :K]
+    a.copy_(synth.uniform((M, K), 31, device="cuda"))
+    w = synth.uniform((N, K), 32, device="cuda")
+    b = synth.uniform((N,), 33, device="cuda")
+    out = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    lib = P._lib.load()
+    rc = lib.pangu_linear_fwd(torch.cuda.current_stream().cuda_stream, a.data_ptr(), ld, w.data_ptr(), b.data_ptr(),
+                              out.data_ptr(), N, M, N, K, 0, None)
+    assert rc == -5                                      # PANGU_E_RANGE
+    got = ops.linear(a, w, b)
+    ref = a.double() @ w.double().t() + b.double()
+    assert ((got.double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
+    dw, db = ops.linear_wgrad(a, a)                      # both operands beyond 4 GB: chunks accumulate into one dW
+    refw = a.double().t() @ a.double()
+    assert ((dw.double() - refw).abs().max() / refw.abs().max()).item() < 1e-5
+    assert ((db.double() - a.double().sum(0)).abs().max() / a.double().sum(0).abs().max()).item() < 1e-5
+    del big
