@@ -191,6 +191,10 @@ int launch_wgrad_bf16(hipStream_t s, const u16* dC, int lddc, const u16* A, int 
 
 }  // namespace
 
+// wgrad_bf16_dma.hip: LDS-DMA variant for K % 192 == 0; returns 1 when the shape is not covered
+int pangu_linear_wgrad_bf16_dma(hipStream_t s, const unsigned short* dC, int lddc, const unsigned short* A, int lda,
+                                float* dW, float* db, int M, int N, int K, int target);
+
 extern "C" int pangu_linear_wgrad_bf16(pangu_stream_t stream, const void* dC, int lddc, const void* A, int lda, float* dW,
                                        float* db, int M, int N, int K) {
   if (!dC || !A || !dW) return PANGU_E_NULL;
@@ -199,6 +203,16 @@ extern "C" int pangu_linear_wgrad_bf16(pangu_stream_t stream, const void* dC, in
   hipStream_t s = (hipStream_t)stream;
   const u16* d = (const u16*)dC;
   const u16* a = (const u16*)A;
+  // LDS-DMA kernel (three workgroups per CU) for the large products: +5-21 % at qkv / MLP shapes (>= 115 GFLOP); the small
+  // ones (proj, down/up-sampling, embed/recover: <= 77 GFLOP) end in the fp32 atomics of their tile sooner than the extra
+  // workgroups pay, and stay on the register-staged kernel (measured per shape, tools/bench_kernels.py wgrad_bf16).
+  // PANGU_WGRAD_BF16_DMA=0 / 2: never / always.
+  static const int dma_mode = getenv("PANGU_WGRAD_BF16_DMA") ? atoi(getenv("PANGU_WGRAD_BF16_DMA")) : 1;
+  static const int dma_target = getenv("PANGU_WGRAD_BF16_DMA_WGS") ? atoi(getenv("PANGU_WGRAD_BF16_DMA_WGS")) : 768;
+  if (dma_mode == 2 || (dma_mode == 1 && 2.0 * M * N * K >= 1.0e11)) {
+    const int rc = pangu_linear_wgrad_bf16_dma(s, d, lddc, a, lda, dW, db, M, N, K, dma_target);
+    if (rc != 1) return rc;
+  }
   if (K % 192 == 0) return launch_wgrad_bf16<3>(s, d, lddc, a, lda, dW, db, M, N, K);
   if (K % 128 == 0) return launch_wgrad_bf16<2>(s, d, lddc, a, lda, dW, db, M, N, K);
   return launch_wgrad_bf16<1>(s, d, lddc, a, lda, dW, db, M, N, K);

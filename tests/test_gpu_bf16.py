@@ -219,6 +219,24 @@ def test_linear_wgrad_bf16(P, M, N, K):
     assert rel_err(db, dc.double().sum(0)) < 2e-4
 
 
+@pytest.mark.parametrize("M,N,K,strided", [(131040, 1152, 384, False), (131040 + 37, 384, 1536, True),
+                                           (400000, 192, 768, False)])
+def test_linear_wgrad_bf16_model_size(P, M, N, K, strided):
+    """The large products (>= 1e11 FLOP) run the LDS-DMA kernel (wgrad_bf16_dma.hip: source-side swizzled slabs, bias
+    gradient as an MFMA column); N = 192 leaves the second 128-column tile half empty, M is ragged against the 32-token
+    K-step, the operands may be row-strided views.  Reference: fp64 on the GPU over the same bf16 values."""
+    from pangu_pytorch_amd import ops_bf16 as ob
+    assert 2.0 * M * N * K >= 1.0e11
+    dc = synth.uniform((M, N + (64 if strided else 0)), 63, device="cuda").to(BF)[:, :N]
+    a = synth.uniform((M, K + (128 if strided else 0)), 64, device="cuda").to(BF)[:, :K]
+    dw, db = ob.linear_wgrad(dc, a)
+    ref_w = torch.zeros((N, K), dtype=torch.float64, device="cuda")
+    for m0 in range(0, M, 32768):                       # chunked: keeps the fp64 copies small
+        ref_w += dc[m0:m0 + 32768].double().t() @ a[m0:m0 + 32768].double()
+    assert rel_err(dw, ref_w) < 2e-4
+    assert rel_err(db, dc.double().sum(0)) < 2e-4
+
+
 @pytest.mark.parametrize("C", [192, 384])
 def test_ln_residual_bwd_bf16(P, C):
     from pangu_pytorch_amd import ops_bf16 as ob
