@@ -39,6 +39,10 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
   __shared__ int tok_s[PANGU_WTOK];
   __shared__ float pad_s[64];            // [2][32]: dK, dV summed over the zero-pad keys of this (type, head)
   __shared__ __attribute__((aligned(16))) f32x4 part_s[NQ * 4 * 64];      // helpers' partial dK/dV per key tile
+  // the last DB_LDS of the nine d_esb accumulator quads live in LDS (lane-private slots): at the 168-VGPR cap the
+  // compiler would keep them in scratch instead (read-modify-write through L2/HBM every window: +1.6 GB per launch)
+  constexpr int DB_LDS = 4, DB_REG = 9 - DB_LDS;
+  __shared__ __attribute__((aligned(16))) f32x4 dbias_s[DB_LDS * NQ * 64];
 
   const int pair = blockIdx.x;
   const int t = pair / heads, hd = pair - t * heads;
@@ -62,9 +66,13 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
   };
 
   if (tid < 64) pad_s[tid] = 0.f;
-  f32x4 dbias[9];
+  f32x4 dbias[DB_REG];
 #pragma unroll
-  for (int j = 0; j < 9; ++j) dbias[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < DB_REG; ++j) dbias[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (tid < NQ * 64) {
+#pragma unroll
+    for (int j = 0; j < DB_LDS; ++j) dbias_s[j * NQ * 64 + tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   // An owner (wave < 9) sums query tiles [0, I_SPLIT) for its key tile in phase B (and keeps the sums in registers);
   // helper h sums [I_SPLIT, 9) for key tiles 3h .. 3h+2 and hands the partial sums over through LDS: 216 + 160 MFMAs
@@ -171,7 +179,8 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
           const float p = __builtin_amdgcn_exp2f(fmaf(s[r], K_LOG2E, c));
           ds[r] = p * dp[r];
         }
-        dbias[j] += ds;
+        if (j < DB_REG) dbias[j] += ds;
+        else dbias_s[(j - DB_REG) * NQ * 64 + tid] += ds;          // own slot only: no barrier
         // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -290,7 +299,8 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
   if (wave < NQ) {
     float* drow = d_esb + (size_t)pair * PANGU_WTOK * PANGU_WTOK + (size_t)(wave * 16 + lq) * PANGU_WTOK + lg * 4;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) *reinterpret_cast<f32x4*>(drow + j * 16) = dbias[j];
+    for (int j = 0; j < 9; ++j)
+      *reinterpret_cast<f32x4*>(drow + j * 16) = j < DB_REG ? dbias[j] : dbias_s[(j - DB_REG) * NQ * 64 + tid];
   }
 }
 
