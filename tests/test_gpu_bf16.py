@@ -362,3 +362,43 @@ def test_block_bf16_nograd_droppath(P, s1, s2):
         m = O.mlp(x1, g("linear.linear1.weight"), g("linear.linear1.bias"), g("linear.linear2.weight"), g("linear.linear2.bias"))
         ref = x1 + s2 * torch.nn.functional.layer_norm(m, (C,), g("norm2.weight"), g("norm2.bias"))
     assert y.dtype == BF and rel_err(y, ref[0]) < 3e-2
+
+
+def test_bf16_batch_of_two(P):
+    """bf16 path, batch of two: the forward equals the two samples run one by one (bit for bit), and the autograd path
+    gives per-sample input-independent parameter gradients that sum (checked on the loss and on every gradient)."""
+    from pangu_pytorch_amd import train
+    m = P.PanguModel(device="cuda").cuda().eval()
+    m.load_state_dict(synth.fill_state_dict(cases.model_param_shapes(), "cuda"))
+    m.set_compute_dtype(BF)
+    inp, inp_s, stats, maps, const_h = cases.model_inputs("cuda")
+    tgt, tgt_s = cases.model_targets("cuda")
+    inp2 = torch.cat((inp, synth.uniform(inp.shape, 4242, device="cuda")), 0)
+    inp_s2 = torch.cat((inp_s, synth.uniform(inp_s.shape, 4243, device="cuda")), 0)
+    tgt2, tgt_s2 = torch.cat((tgt, tgt), 0), torch.cat((tgt_s, tgt_s), 0)
+    with torch.no_grad():
+        o2, os2 = m(inp2, inp_s2, stats, maps, const_h)
+        oa, osa = m(inp2[:1], inp_s2[:1], stats, maps, const_h)
+        ob_, osb = m(inp2[1:], inp_s2[1:], stats, maps, const_h)
+    assert o2.shape == (2, 5, 13, 721, 1440)
+    assert torch.equal(o2[0], oa[0]) and torch.equal(o2[1], ob_[0]) and torch.equal(os2[0], osa[0]) and torch.equal(os2[1], osb[0])
+    del o2, os2, oa, osa, ob_, osb
+    # autograd path: mean loss over the batch of two == mean of the two single-sample losses; gradients likewise
+    out, out_s = m(inp2, inp_s2, stats, maps, const_h)
+    l2 = train.weighted_l1_loss(out, out_s, tgt2, tgt_s2)
+    l2.backward()
+    g2 = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.zero_grad(set_to_none=True)
+    del out, out_s
+    ls = []
+    for i in range(2):
+        out, out_s = m(inp2[i:i + 1], inp_s2[i:i + 1], stats, maps, const_h)
+        li = train.weighted_l1_loss(out, out_s, tgt, tgt_s)
+        (0.5 * li).backward()
+        ls.append(li.item())
+        del out, out_s
+    assert abs(l2.item() - 0.5 * (ls[0] + ls[1])) < 1e-5 * abs(l2.item())
+    worst = max((((p.grad.double() - g2[k].double()).norm() / g2[k].double().norm().clamp_min(1e-30)).item(), k)
+                for k, p in m.named_parameters())
+    assert worst[0] < 1e-3, worst
+    m.set_compute_dtype(torch.float32)
