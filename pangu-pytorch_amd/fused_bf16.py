@@ -40,6 +40,7 @@ class WeightShadow:
 
 
 _FUSE_LN = os.environ.get("PANGU_BF16_FUSE_LN", "1") != "0"      # A/B knob: 0 = separate GEMM + LN-residual launches
+_FUSE_LN384 = int(os.environ.get("PANGU_BF16_FUSE_LN384", "0"))   # C = 384: 0 = never, 1 = attention projection only, 2 = both
 
 
 def _block(blk, sh, x, Z, H, W, roll, out=None):
@@ -52,11 +53,14 @@ def _block(blk, sh, x, Z, H, W, roll, out=None):
     C = x.shape[1]
     # projection + post-norm residual in one launch (the branch never round-trips HBM); C = 384: the 8-wave 128x384 tile
     # loses what the fusion saves (measured), so stage 1/2 keeps the separate launches
-    fuse = _FUSE_LN and C == 192 and x.is_contiguous() and s1 == 1.0 and s2 == 1.0
+    ok = _FUSE_LN and x.is_contiguous() and s1 == 1.0 and s2 == 1.0
+    fuse = ok and C == 192
+    fuse_proj = fuse or (ok and C == 384 and _FUSE_LN384 >= 1)
+    fuse_mlp = fuse or (ok and C == 384 and _FUSE_LN384 >= 2)
     if s1 != 0.0:
         qkv = ob.linear(x, sh.get(att.linear1.weight), att.linear1.bias)
         o = ob.window_attention(qkv, sh.get(att.linear1.bias), sh.get(att.earth_specific_bias), Z, H, W, att.head_number, roll)
-        if fuse:
+        if fuse_proj:
             x1 = ob.linear_ln_residual(o, sh.get(att.linear2.weight), att.linear2.bias, x, blk.norm1.weight, blk.norm1.bias)
         else:
             y = ob.linear(o, sh.get(att.linear2.weight), att.linear2.bias)
@@ -69,7 +73,7 @@ def _block(blk, sh, x, Z, H, W, roll, out=None):
             return out
         return x1
     h = ob.linear(x1, sh.get(blk.linear.linear1.weight), blk.linear.linear1.bias, act=ob.ACT_GELU)
-    if fuse:
+    if fuse_mlp:
         return ob.linear_ln_residual(h, sh.get(blk.linear.linear2.weight), blk.linear.linear2.bias, x1, blk.norm2.weight,
                                      blk.norm2.bias, out=out)
     m = ob.linear(h, sh.get(blk.linear.linear2.weight), blk.linear.linear2.bias)
