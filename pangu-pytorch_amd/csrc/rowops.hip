@@ -129,13 +129,14 @@ __global__ __launch_bounds__(256) void patch_embed_gather_kernel(
     const float* __restrict__ s_std, const float* __restrict__ u_mean, const float* __restrict__ u_std,
     const float* __restrict__ maps, const float* __restrict__ const_h, float* __restrict__ a_surface,
     float* __restrict__ a_upper, int LAT, int LON, int H4, int W4, int chunks) {
-  __shared__ float tile[EMB_TOK * 193];
+  constexpr int TLD = 196;               // tile row stride in floats: 16-B aligned, 8 tokens x 4 dwords cover the 32 banks
+  __shared__ __attribute__((aligned(16))) float tile[EMB_TOK * TLD];
   const int chunk = blockIdx.x % chunks, h4 = (blockIdx.x / chunks) % H4, zp = blockIdx.x / (chunks * H4);
   const int w0 = chunk * EMB_TOK;
   const int ntok = min(EMB_TOK, W4 - w0);
   const int tid = threadIdx.x;
   const int ncol = zp == 0 ? 112 : 192;
-  const int nrun = ncol / 4;            // (c, [pz,] ph) combinations; each is a run of 4*ntok longitudes
+  const int nrun = ncol / 4;            // (c, [pz,] ph) combinations; each is a run of ntok float4 (the 4 longitudes of a token)
   const size_t plane = (size_t)LAT * LON;
   for (int run = tid >> 6; run < nrun; run += 4) {
     // decode run -> channel c, level offset pz, lat offset ph
@@ -161,21 +162,25 @@ __global__ __launch_bounds__(256) void patch_embed_gather_kernel(
       }
     }
     const bool norm = (zp == 0) ? (c < 4) : (c < 5);
-    for (int i = (tid & 63); i < 4 * ntok; i += 64) {
-      float v = 0.f;
+    for (int tk = (tid & 63); tk < ntok; tk += 64) {      // LON % 4 == 0: a token's 4 longitudes are one aligned float4
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (valid) {
-        v = src[4 * w0 + i];
-        if (norm) v = (v - mean) / sd;
+        v = *reinterpret_cast<const f32x4*>(src + 4 * (w0 + tk));
+        if (norm) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (v[e] - mean) / sd;
+        }
       }
-      tile[(i >> 2) * 193 + run * 4 + (i & 3)] = v;
+      *reinterpret_cast<f32x4*>(&tile[tk * TLD + run * 4]) = v;
     }
   }
   __syncthreads();
   float* dst = zp == 0 ? a_surface + ((size_t)h4 * W4 + w0) * 112
                        : a_upper + (((size_t)(zp - 1) * H4 + h4) * W4 + w0) * 192;
-  for (int i = tid; i < ntok * ncol; i += 256) {
-    const int tk = i / ncol, col = i - tk * ncol;
-    dst[i] = tile[tk * 193 + col];
+  const int c4n = ncol / 4;
+  for (int i = tid; i < ntok * c4n; i += 256) {
+    const int tk = i / c4n, c4 = i - tk * c4n;
+    reinterpret_cast<f32x4*>(dst)[i] = *reinterpret_cast<const f32x4*>(&tile[tk * TLD + c4 * 4]);
   }
 }
 

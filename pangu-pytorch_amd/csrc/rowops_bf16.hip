@@ -193,7 +193,8 @@ __global__ __launch_bounds__(256) void patch_embed_gather_bf16_kernel(
     const float* __restrict__ s_std, const float* __restrict__ u_mean, const float* __restrict__ u_std,
     const float* __restrict__ maps, const float* __restrict__ const_h, u16* __restrict__ a_surface,
     u16* __restrict__ a_upper, int LAT, int LON, int H4, int W4, int chunks) {
-  __shared__ u16 tile[EMB_TOK * 194];
+  constexpr int TLD = 200;               // tile row stride in bf16: rows 16-B aligned
+  __shared__ __attribute__((aligned(16))) u16 tile[EMB_TOK * TLD];
   const int chunk = blockIdx.x % chunks, h4 = (blockIdx.x / chunks) % H4, zp = blockIdx.x / (chunks * H4);
   const int w0 = chunk * EMB_TOK;
   const int ntok = min(EMB_TOK, W4 - w0);
@@ -224,21 +225,26 @@ __global__ __launch_bounds__(256) void patch_embed_gather_bf16_kernel(
       }
     }
     const bool norm = (zp == 0) ? (c < 4) : (c < 5);
-    for (int i = (tid & 63); i < 4 * ntok; i += 64) {
-      float v = 0.f;
+    for (int tk = (tid & 63); tk < ntok; tk += 64) {      // LON % 4 == 0: a token's 4 longitudes are one aligned float4
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (valid) {
-        v = src[4 * w0 + i];
-        if (norm) v = (v - mean) / sd;
+        v = *reinterpret_cast<const f32x4*>(src + 4 * (w0 + tk));
+        if (norm) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (v[e] - mean) / sd;
+        }
       }
-      tile[(i >> 2) * 194 + run * 4 + (i & 3)] = f2bf(v);
+      *reinterpret_cast<u32x2*>(&tile[tk * TLD + run * 4]) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
     }
   }
   __syncthreads();
   const int ocol = zp == 0 ? 128 : 192;
   u16* dst = zp == 0 ? a_surface + ((size_t)h4 * W4 + w0) * 128 : a_upper + (((size_t)(zp - 1) * H4 + h4) * W4 + w0) * 192;
-  for (int i = tid; i < ntok * ocol; i += 256) {
-    const int tk = i / ocol, col = i - tk * ocol;
-    dst[i] = col < ncol ? tile[tk * 194 + col] : (u16)0;
+  const int c8n = ocol / 8;
+  for (int i = tid; i < ntok * c8n; i += 256) {
+    const int tk = i / c8n, c8 = i - tk * c8n;
+    reinterpret_cast<u32x4*>(dst)[i] =
+        c8 * 8 < ncol ? *reinterpret_cast<const u32x4*>(&tile[tk * TLD + c8 * 8]) : u32x4{0u, 0u, 0u, 0u};
   }
 }
 
