@@ -15,6 +15,14 @@ def norm_back(upper, surface, stats_last):
     return upper * u_std + u_mean, surface * s_std + s_mean
 
 
+def norm_back_into(upper, surface, stats_last, dst_upper, dst_surface):
+    """norm_back written straight into existing buffers (the rollout's next-step inputs): the same two roundings
+    (multiply, then add) as the reference expression, without the temporaries and the copy pass."""
+    s_mean, s_std, u_mean, u_std = stats_last
+    torch.mul(upper, u_std, out=dst_upper).add_(u_mean)
+    torch.mul(surface, s_std, out=dst_surface).add_(s_mean)
+
+
 class GraphedStep:
     """One model step captured as a hipGraph (static shapes, B fixed, no host syncs inside the path).
 
@@ -45,9 +53,7 @@ class GraphedStep:
     def _body(self):
         out, out_s = self.model(self.inp, self.inp_surface, *self.consts)
         if self.feed_back:
-            up, sf = norm_back(out, out_s, self.stats_last)
-            self.inp.copy_(up)
-            self.inp_surface.copy_(sf)
+            norm_back_into(out, out_s, self.stats_last, self.inp, self.inp_surface)
         return out, out_s
 
     def load(self, inp, inp_surface):
