@@ -45,6 +45,14 @@ class EarthBlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        C = dout.shape[-1]
+        # every atomically accumulated gradient buffer of the block (4 weight+bias pairs, 2 LayerNorm pairs, the pad-slot
+        # bias gradient: 12 C^2 + 16 C floats) comes out of ONE zero fill
+        with ops.zero_arena(12 * C * C + 64 * C, dout.device):
+            return EarthBlockFn._backward(ctx, dout)
+
+    @staticmethod
+    def _backward(ctx, dout):
         Z, H, W, heads, shifted = ctx.geom
         s1, s2 = ctx.s1, ctx.s2
         sv = list(ctx.saved_tensors)

@@ -35,6 +35,14 @@ class EarthBlockFnBF16(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        C = dout.shape[-1]
+        # every atomically accumulated gradient buffer of the block (4 weight+bias pairs, 2 LayerNorm pairs, the pad-slot
+        # bias gradient: 12 C^2 + 16 C floats) comes out of ONE zero fill
+        with ops.zero_arena(12 * C * C + 64 * C, dout.device):
+            return EarthBlockFnBF16._backward(ctx, dout)
+
+    @staticmethod
+    def _backward(ctx, dout):
         Z, H, W, heads, shifted = ctx.geom
         s1, s2, sh = ctx.s1, ctx.s2, ctx.sh
         n1w, n2w, m1w, m2w, esb, a1w, a1b, a2w = ctx.params

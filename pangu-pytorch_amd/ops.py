@@ -93,6 +93,41 @@ def _rows(t, name):
     return t.data_ptr(), t.stride(0)
 
 
+_zero_arena = None        # [flat fp32 zeros, used elements]: see zero_arena
+
+
+class zero_arena:
+    """One zero fill for all the atomically accumulated gradient buffers of a backward step (weight / bias / LayerNorm /
+    pad-slot gradients): inside the context `_zeros` hands out 16-B aligned slices of ONE zeroed fp32 buffer instead of
+    launching a fill kernel per buffer (seven per block, 6.4 us each: 2.4 % of the bf16 training step)."""
+
+    def __init__(self, numel, device):
+        self.numel, self.device = int(numel), device
+
+    def __enter__(self):
+        global _zero_arena
+        self.prev = _zero_arena
+        _zero_arena = [torch.zeros((self.numel,), dtype=torch.float32, device=self.device), 0]
+        return self
+
+    def __exit__(self, *exc):
+        global _zero_arena
+        _zero_arena = self.prev
+
+
+def _zeros(shape, device):
+    """fp32 zeros of `shape`: a slice of the active zero_arena when one is open on this device and has room."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    a = _zero_arena
+    if a is not None and a[0].device == torch.device(device) and a[1] + n <= a[0].numel():
+        t = a[0][a[1]:a[1] + n].view(shape)
+        a[1] += (n + 3) & ~3
+        return t
+    return torch.zeros(shape, dtype=torch.float32, device=device)
+
+
 _U32_BYTES = (1 << 32) - (1 << 24)
 
 
@@ -185,7 +220,7 @@ def linear_wgrad(dc, a, want_bias=True):
     ap, lda = _rows(a, "wgrad.a")
     M, N = dc.shape
     K = a.shape[1]
-    buf = torch.zeros((N * K + (N if want_bias else 0),), dtype=torch.float32, device=dc.device)   # one fill launch
+    buf = _zeros((N * K + (N if want_bias else 0),), dc.device)   # one fill launch (none inside a zero_arena)
     dw = buf[:N * K].view(N, K)
     db = buf[N * K:] if want_bias else None
     esz = dc.element_size()
@@ -218,7 +253,7 @@ def window_attention_bwd(qkv, qkv_bias, esb, out, lse, dout, Z, H, W, heads, shi
     N, C3 = qkv.shape
     C = C3 // 3
     dqkv = torch.empty_like(qkv)
-    dqb = torch.zeros((C3,), dtype=torch.float32, device=qkv.device)
+    dqb = _zeros((C3,), qkv.device)
     desb = torch.empty_like(esb)
     Np = (Z // 2) * ((H + 5) // 6) * (W // 12) * 144
     with _timed("attn_bwd", 14.0 * Np * 144 * C):
@@ -235,7 +270,7 @@ def ln_residual_bwd(dout, y, gamma, branch_scale=1.0):
     N, C = y.shape
     dp, lddo = _rows(dout, "ln_bwd.dout")
     dy = torch.empty_like(y)
-    dg, db = torch.zeros((2, C), dtype=torch.float32, device=y.device).unbind(0)
+    dg, db = _zeros((2, C), y.device).unbind(0)
     _lib.check(lib.pangu_ln_residual_bwd(_stream(), dp, lddo, _chk(y, "ln_bwd.y"), _chk(gamma, "gamma"), dy.data_ptr(),
                                          dg.data_ptr(), db.data_ptr(), N, C, float(branch_scale)), "ln_residual_bwd")
     return dy, dg, db
@@ -246,7 +281,7 @@ def downsample_ln_bwd(dout, x, gamma, Z, H, W):
     xp, ldx = _rows(x, "downsample_bwd.x")
     C = x.shape[1]
     dx = torch.empty((Z * H * W, C), dtype=torch.float32, device=x.device)
-    dg, db = torch.zeros((2, 4 * C), dtype=torch.float32, device=x.device).unbind(0)
+    dg, db = _zeros((2, 4 * C), x.device).unbind(0)
     _lib.check(lib.pangu_downsample_ln_bwd(_stream(), _chk(dout, "dout"), xp, ldx, _chk(gamma, "gamma"), dx.data_ptr(),
                                            dg.data_ptr(), db.data_ptr(), Z, H, W, C), "downsample_ln_bwd")
     return dx, dg, db
@@ -256,7 +291,7 @@ def upsample_ln_bwd(dout, y, gamma, Z, H2, W2, H):
     lib = _lib.load()
     Co = y.shape[1] // 4
     dy = torch.empty_like(y)
-    dg, db = torch.zeros((2, Co), dtype=torch.float32, device=y.device).unbind(0)
+    dg, db = _zeros((2, Co), y.device).unbind(0)
     _lib.check(lib.pangu_upsample_ln_bwd(_stream(), _chk(dout, "dout"), _chk(y, "y"), _chk(gamma, "gamma"),
                                          dy.data_ptr(), dg.data_ptr(), db.data_ptr(), Z, H2, W2, H, Co),
                "upsample_ln_bwd")

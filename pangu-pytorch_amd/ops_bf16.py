@@ -2,7 +2,7 @@
 import torch
 
 from . import _lib
-from .ops import _row_chunks, _stream, _timed
+from .ops import _row_chunks, _stream, _timed, _zeros
 
 ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_ADD = 0, 1, 2, 3
 BF16, F32 = 1, 0
@@ -137,7 +137,7 @@ def linear_wgrad(dc, a, want_bias=True):
     ap, lda = _rows(a, "wgrad.a")
     M, N = dc.shape
     K = a.shape[1]
-    buf = torch.zeros((N * K + (N if want_bias else 0),), dtype=torch.float32, device=dc.device)   # one fill launch
+    buf = _zeros((N * K + (N if want_bias else 0),), dc.device)   # one fill launch (none inside a zero_arena)
     dw = buf[:N * K].view(N, K)
     db = buf[N * K:] if want_bias else None
     for m0, m1 in (_row_chunks(M, 2 * lddc, 2 * lda) or [(0, M)]):      # the kernel ADDS into dw / db
@@ -152,7 +152,7 @@ def window_attention_bwd(qkv, qkv_bias, esb, out, lse, dout, Z, H, W, heads, shi
     N, C3 = qkv.shape
     C = C3 // 3
     dqkv = torch.empty_like(qkv)
-    dqb = torch.zeros((C3,), dtype=torch.float32, device=qkv.device)
+    dqb = _zeros((C3,), qkv.device)
     desb = torch.empty(esb.shape, dtype=torch.float32, device=qkv.device)
     Np = (Z // 2) * ((H + 5) // 6) * (W // 12) * 144
     with _timed("attn_bwd_bf16", 14.0 * Np * 144 * C):
@@ -168,7 +168,7 @@ def ln_residual_bwd(dout, y, gamma, branch_scale=1.0):
     N, C = y.shape
     dp, lddo = _rows(dout, "ln_bwd.dout")
     dy = torch.empty_like(y)
-    dg, db = torch.zeros((2, C), dtype=torch.float32, device=y.device).unbind(0)
+    dg, db = _zeros((2, C), y.device).unbind(0)
     _lib.check(lib.pangu_ln_residual_bwd_bf16(_stream(), dp, lddo, _p(y, "y"), _p(gamma, "gamma", torch.float32),
                                               dy.data_ptr(), dg.data_ptr(), db.data_ptr(), N, C, float(branch_scale)),
                "ln_residual_bwd_bf16")
@@ -180,7 +180,7 @@ def downsample_ln_bwd(dout, x, gamma, Z, H, W):
     xp, ldx = _rows(x, "x")
     C = x.shape[1]
     dx = torch.empty((Z * H * W, C), dtype=torch.bfloat16, device=x.device)
-    dg, db = torch.zeros((2, 4 * C), dtype=torch.float32, device=x.device).unbind(0)
+    dg, db = _zeros((2, 4 * C), x.device).unbind(0)
     _lib.check(lib.pangu_downsample_ln_bwd_bf16(_stream(), _p(dout, "dout"), xp, ldx, _p(gamma, "gamma", torch.float32),
                                                 dx.data_ptr(), dg.data_ptr(), db.data_ptr(), Z, H, W, C),
                "downsample_ln_bwd_bf16")
@@ -191,7 +191,7 @@ def upsample_ln_bwd(dout, y, gamma, Z, H2, W2, H):
     lib = _lib.load()
     Co = y.shape[1] // 4
     dy = torch.empty_like(y)
-    dg, db = torch.zeros((2, Co), dtype=torch.float32, device=y.device).unbind(0)
+    dg, db = _zeros((2, Co), y.device).unbind(0)
     _lib.check(lib.pangu_upsample_ln_bwd_bf16(_stream(), _p(dout, "dout"), _p(y, "y"), _p(gamma, "gamma", torch.float32),
                                               dy.data_ptr(), dg.data_ptr(), db.data_ptr(), Z, H2, W2, H, Co),
                "upsample_ln_bwd_bf16")
