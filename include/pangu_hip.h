@@ -198,6 +198,15 @@ int pangu_ln_residual_fwd_bf16(pangu_stream_t stream, const void* y, const void*
 int pangu_linear_ln_residual_fwd_bf16(pangu_stream_t stream, const void* A, int lda, const void* W, const float* bias,
                                       const void* shortcut, const float* gamma, const float* beta, void* out, int ldo, int M,
                                       int N, int K);
+/* Whole MLP branch + post-norm residual in one launch (inference path of reference models/layers.py:251 with
+ * Mlp.forward :264-270 inside):
+ *   out[M,C] = x[M,C] + branch_scale * ( LayerNorm( GELU(x W1^T + b1) W2^T + b2 ) * gamma + beta ),   C = 192 or 384.
+ * x (row stride ldx), out (row stride ldo) bf16; b1 [4C], b2/gamma/beta [C] fp32; w_packed = the bf16 chunk image of
+ * (W1 [4C][C], W2 [C][4C]) laid out as csrc/mlp_fused_bf16.hip documents (4C/32 chunks of 64*C elements).  The hidden
+ * activation (M x 4C) never reaches memory.  Replaces two pangu_linear_fwd_bf16 + pangu_ln_residual_fwd_bf16. */
+int pangu_mlp_ln_residual_fwd_bf16(pangu_stream_t stream, const void* x, int ldx, const void* w_packed, const float* b1,
+                                   const float* b2, const float* gamma, const float* beta, void* out, int ldo, int M,
+                                   int C, float branch_scale);
 int pangu_downsample_ln_fwd_bf16(pangu_stream_t stream, const void* x, int ldx, const float* gamma, const float* beta,
                                  void* out, int Z, int H, int W, int C);
 int pangu_upsample_ln_fwd_bf16(pangu_stream_t stream, const void* y, const float* gamma, const float* beta, void* out,

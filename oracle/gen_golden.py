@@ -1,6 +1,6 @@
 """Generate golden vectors by running the REFERENCE itself (build container only; needs /root/reference).
 
-TEST INFRASTRUCTURE. Usage:  python oracle/gen_golden.py [index] [blocks] [layers] [model] [model_bwd] [model_bwd_smooth]
+TEST INFRASTRUCTURE. Usage:  python oracle/gen_golden.py [index] [blocks] [layers] [model] [model_bwd] [model_bwd_smooth] [extras] [rollout2]
 Outputs small fixtures (fingerprints: samples + sums, index tensors, packed masks) under tests/golden/.
 Inputs and parameters are closed-form (oracle/synth.py), so tests regenerate them bit-identically.
 """
@@ -210,6 +210,37 @@ def gen_model_smooth(L, M):
     save("model_bwd_smooth.npz", d)
 
 
+def stats_last_of(stats):
+    """The `weatherStatistics_output` view of the input statistics (reference era5_data/utils_data.py:214-236):
+    surface (1,4,1,1); upper (13,1,1,5) -> levels reversed -> (1,5,13,1,1)."""
+    s_mean, s_std, u_mean, u_std = stats
+    rev = lambda u: torch.from_numpy(np.transpose(u.numpy()[::-1].copy(), (1, 3, 0, 2)))[..., None].contiguous()
+    return s_mean.view(1, 4, 1, 1), s_std.view(1, 4, 1, 1), rev(u_mean), rev(u_std)
+
+
+def gen_rollout(L, M, steps=2):
+    """`steps` chained REFERENCE forwards: the loop of inference/inference_singleOutput.py:97-105 (output of one 24 h
+    step = input of the next) with the torch model's normalised outputs taken back to physical units by normBackData
+    (era5_data/utils_data.py:324-330; era5_data cannot be imported here, its 2-line body is restated)."""
+    model = build_model(M).eval()
+    inp, inp_s, stats, maps, const_h = cases.model_inputs()
+    s_mean, s_std, u_mean, u_std = stats_last_of(stats)
+    d = {}
+    up, sf = inp, inp_s
+    for k in range(steps):
+        t = time.time()
+        with torch.no_grad():
+            out, out_s = model(up, sf, stats, maps, const_h)
+        print("rollout step %d ref %.1fs" % (k + 1, time.time() - t))
+        d.update(cases.summarize(out, f"rollout.step{k + 1}.out"))
+        d.update(cases.summarize(out_s, f"rollout.step{k + 1}.out_surface"))
+        up = out * u_std + u_mean                    # normBackData, utils_data.py:327
+        sf = out_s * s_std + s_mean                  # :328
+    d.update(cases.summarize(up, "rollout.final_upper"))
+    d.update(cases.summarize(sf, "rollout.final_surface"))
+    save("rollout2.npz", d)
+
+
 def gen_model(L, M, backward):
     model = build_model(M).eval()
     inp, inp_s, stats, maps, const_h = cases.model_inputs()
@@ -258,3 +289,5 @@ if __name__ == "__main__":
         gen_extras(L, M)
     if "model_bwd_smooth" in what:
         gen_model_smooth(L, M)
+    if "rollout2" in what:
+        gen_rollout(L, M, steps=2)

@@ -35,6 +35,7 @@ SIGNATURES = {
     "pangu_window_attn_fwd_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I],
     "pangu_ln_residual_fwd_bf16": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _F],
     "pangu_linear_ln_residual_fwd_bf16": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
+    "pangu_mlp_ln_residual_fwd_bf16": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F],
     "pangu_downsample_ln_fwd_bf16": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I],
     "pangu_upsample_ln_fwd_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I],
     "pangu_patch_embed_gather_bf16": [_P] * 11 + [_I, _I],

@@ -7,40 +7,56 @@ import torch
 from . import ops, ops_bf16 as ob
 
 
+def _stamp(p):
+    """What identifies the CONTENT of a parameter as far as it can be observed cheaply: in-place updates through the
+    parameter bump `_version` (optimizer steps, `copy_` under no_grad); `param.data = w` (the reference's own import idiom,
+    models/onnx2torch.py:37-52) swaps the storage, i.e. `data_ptr()`.  In-place edits made THROUGH `param.data`
+    (`p.data.copy_(..)`, `p.data.add_(..)`) change neither: after such an edit call `model.invalidate_shadows()`."""
+    return (p._version, p.data_ptr(), tuple(p.shape), p.device)
+
+
 class WeightShadow:
-    """bf16 copies of the projection weights and bias tables, re-cast only when a parameter changed
-    (`Tensor._version` bumps on every in-place update).  Plain tensors in a dict: deepcopy / pickle safe."""
+    """bf16 copies of the projection weights and bias tables (and the packed weight images of the fused kernels),
+    re-made when a parameter's stamp changes.  Never pickled / deep-copied with the model (PanguModel.__getstate__)."""
 
     def __init__(self):
         self.cache = {}
 
-    def get(self, p, pad_k=None):
-        key = id(p)
+    def clear(self):
+        self.cache.clear()
+
+    def _lookup(self, key, params, make):
+        stamp = tuple(_stamp(p) for p in params)
         hit = self.cache.get(key)
-        if hit is not None and hit[0] == p._version and hit[1].device == p.device:
+        if hit is not None and hit[0] == stamp:
             return hit[1]
-        w = p.detach().reshape(p.shape[0], -1) if p.dim() == 3 else p.detach()
-        if p.dim() == 5:
-            w = w[0]
-        if pad_k is not None and w.shape[1] < pad_k:
-            w = torch.nn.functional.pad(w, (0, pad_k - w.shape[1]))
-        w = w.to(torch.bfloat16).contiguous()
-        self.cache[key] = (p._version, w)
+        w = make()
+        self.cache[key] = (stamp, w)
         return w
+
+    def get(self, p, pad_k=None):
+        def make():
+            w = p.detach().reshape(p.shape[0], -1) if p.dim() == 3 else p.detach()
+            if p.dim() == 5:
+                w = w[0]
+            if pad_k is not None and w.shape[1] < pad_k:
+                w = torch.nn.functional.pad(w, (0, pad_k - w.shape[1]))
+            return w.to(torch.bfloat16).contiguous()
+        return self._lookup(id(p), (p,), make)
 
     def get_t(self, p):
         """Transposed bf16 shadow (in, out): the `W` operand of the input-gradient GEMM dA = dC @ W."""
-        key = ("t", id(p))
-        hit = self.cache.get(key)
-        if hit is not None and hit[0] == p._version and hit[1].device == p.device:
-            return hit[1]
-        w = p.detach().reshape(p.shape[0], -1).t().to(torch.bfloat16).contiguous()
-        self.cache[key] = (p._version, w)
-        return w
+        return self._lookup(("t", id(p)), (p,),
+                            lambda: p.detach().reshape(p.shape[0], -1).t().to(torch.bfloat16).contiguous())
+
+    def get_mlp(self, w1, w2):
+        """Packed chunk image of an Mlp's two weights for the fused MLP kernel (ops_bf16.pack_mlp_weights)."""
+        return self._lookup(("mlp", id(w1), id(w2)), (w1, w2), lambda: ob.pack_mlp_weights(w1.detach(), w2.detach()))
 
 
 _FUSE_LN = os.environ.get("PANGU_BF16_FUSE_LN", "1") != "0"      # A/B knob: 0 = separate GEMM + LN-residual launches
 _FUSE_LN384 = int(os.environ.get("PANGU_BF16_FUSE_LN384", "0"))   # C = 384: 0 = never, 1 = attention projection only, 2 = both
+_FUSE_MLP = os.environ.get("PANGU_BF16_FUSE_MLP", "1") != "0"    # A/B knob: 0 = MLP-up, MLP-down(+LN) as separate launches
 
 
 def _block(blk, sh, x, Z, H, W, roll, out=None):
@@ -72,6 +88,11 @@ def _block(blk, sh, x, Z, H, W, roll, out=None):
             out.copy_(x1)
             return out
         return x1
+    if _FUSE_MLP and C in (192, 384):
+        # whole MLP branch + LayerNorm + residual in one launch: the (N, 4C) hidden activation never reaches HBM
+        return ob.mlp_ln_residual(x1, sh.get_mlp(blk.linear.linear1.weight, blk.linear.linear2.weight),
+                                  blk.linear.linear1.bias, blk.linear.linear2.bias, blk.norm2.weight, blk.norm2.bias,
+                                  out=out, branch_scale=s2)
     h = ob.linear(x1, sh.get(blk.linear.linear1.weight), blk.linear.linear1.bias, act=ob.ACT_GELU)
     if fuse_mlp:
         return ob.linear_ln_residual(h, sh.get(blk.linear.linear2.weight), blk.linear.linear2.bias, x1, blk.norm2.weight,

@@ -81,6 +81,50 @@ def linear_ln_residual(a, weight, bias, shortcut, gamma, beta, out=None):
     return out
 
 
+def pack_mlp_weights(w1, w2):
+    """Chunk image of an Mlp's weights for `mlp_ln_residual` (layout: csrc/mlp_fused_bf16.hip header).  w1 (4C, C), w2 (C, 4C),
+    any float dtype, C in (192, 384) -> bf16 (4C/32, 64*C): per 32 hidden units the W1 rows (16-B chunks XOR-swizzled for
+    conflict-free fragment reads) followed by the W2 columns in the k order the first product's accumulators come in."""
+    HID, C = w1.shape
+    if C not in (192, 384) or HID != 4 * C or tuple(w2.shape) != (C, HID):
+        raise RuntimeError(f"pack_mlp_weights: w1 {tuple(w1.shape)} w2 {tuple(w2.shape)}")
+    dev = w1.device
+    nch, sw = HID // 32, (15 if C == 384 else 7)
+    hr = torch.arange(32, device=dev)
+    pos = torch.arange(C // 8, device=dev)
+    src = pos[None, :] ^ (hr[:, None] & sw)                                   # logical chunk stored at (row, position)
+    w1b = w1.to(torch.bfloat16).reshape(nch, 32, C // 8, 8)
+    w1img = w1b[:, hr[:, None], src, :]                                       # (nch, 32, C/8, 8)
+    perm = torch.tensor([4 * g + j if j < 4 else 16 + 4 * g + j - 4 for g in range(4) for j in range(8)], device=dev)
+    w2img = w2.to(torch.bfloat16).reshape(C, nch, 32)[:, :, perm].reshape(C, nch, 4, 8).permute(1, 2, 0, 3)
+    return torch.cat([w1img.reshape(nch, 32 * C), w2img.reshape(nch, 32 * C)], 1).contiguous()
+
+
+def mlp_ln_residual(x, w_packed, b1, b2, gamma, beta, out=None, branch_scale=1.0):
+    """out = x + branch_scale * LayerNorm(GELU(x W1^T + b1) W2^T + b2) * gamma + beta in ONE launch (reference
+    layers.py:251 with Mlp.forward :264-270 inside); the hidden activation never reaches memory.  x (M, C) bf16 rows,
+    w_packed from pack_mlp_weights, biases / LayerNorm parameters fp32."""
+    lib = _lib.load()
+    xp, ldx = _rows(x, "mlp.x")
+    M, C = x.shape
+    if x.dtype != torch.bfloat16 or tuple(w_packed.shape) != (C // 8, 64 * C):
+        raise RuntimeError(f"mlp_ln_residual: x {tuple(x.shape)} {x.dtype} vs packed weights {tuple(w_packed.shape)}")
+    if out is None:
+        out = torch.empty((M, C), dtype=torch.bfloat16, device=x.device)
+    op, ldo = _rows(out, "mlp.out")
+    chunks = _row_chunks(M, 2 * ldx, 2 * ldo)
+    if chunks is not None:
+        for m0, m1 in chunks:
+            mlp_ln_residual(x[m0:m1], w_packed, b1, b2, gamma, beta, out[m0:m1], branch_scale)
+        return out
+    with _timed("mlp_fused_bf16", 16.0 * M * C * C):
+        _lib.check(lib.pangu_mlp_ln_residual_fwd_bf16(
+            _stream(), xp, ldx, _p(w_packed, "w_packed"), _p(b1, "b1", torch.float32), _p(b2, "b2", torch.float32),
+            _p(gamma, "gamma", torch.float32), _p(beta, "beta", torch.float32), op, ldo, M, C, float(branch_scale)),
+            "mlp_ln_residual_fwd_bf16")
+    return out
+
+
 def ln_residual(y, shortcut, gamma, beta, out=None, branch_scale=1.0):
     lib = _lib.load()
     N, C = y.shape

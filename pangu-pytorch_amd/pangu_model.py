@@ -55,7 +55,33 @@ class PanguModel(nn.Module):
         # f32_split (fp32 only, opt-in): projections evaluate their fp32 products as split-bf16 triples on the bf16
         # matrix pipe (csrc/gemm_f32x3.hip): ~5x fewer matrix cycles, ~1e-5 instead of ~1e-7 relative error
         self.f32_split = bool(f32_split) and dtype == torch.float32
+        self.invalidate_shadows()
         return self
+
+    def invalidate_shadows(self):
+        """Drop the bf16 weight shadows / packed weight images (they are re-made on the next bf16 forward).  Called by
+        load_state_dict, .to()/.cuda()/.half() (`_apply`) and set_compute_dtype; call it yourself after editing weights
+        through `param.data` in place (`p.data.copy_(..)`), which leaves no trace the cache could check."""
+        if self._shadow is not None:
+            self._shadow.clear()
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_shadows()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        if getattr(self, "_shadow", None) is not None:
+            self._shadow.clear()
+        return out
+
+    def __getstate__(self):
+        """Pickling (`torch.save(model)`) and `copy.deepcopy(model)` (reference models/pangu_sample.py:162-164) carry the
+        module tree only, never the ~0.5 GB of derived bf16 shadows (keyed by id() of the ORIGINAL parameters)."""
+        state = self.__dict__.copy()
+        state["_shadow"] = None
+        return state
 
     def _init_weights(self, m):                                                # reference pangu_model.py:41-48
         if isinstance(m, nn.Linear):

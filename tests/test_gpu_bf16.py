@@ -86,6 +86,47 @@ def test_linear_ln_residual_bf16(P, M, N, K, strided_out):
         assert float(full[:, :N].float().abs().max()) == 0.0
 
 
+def _mlp_ref(x, w1, b1, w2, b2, g, be, scale):
+    """fp64 reference of layers.py:251 + :264-270 on the bf16-rounded operands; the hidden activation is rounded to bf16
+    like the kernel's second-product operand."""
+    xd = x.double()
+    h = torch.nn.functional.gelu(xd @ w1.double().t() + b1.double()).to(BF).double()
+    y = h @ w2.double().t() + b2.double()
+    return xd + scale * torch.nn.functional.layer_norm(y, (x.shape[1],), g.double(), be.double(), 1e-5)
+
+
+@pytest.mark.parametrize("C,M", [(192, 256), (192, 1000), (192, 4099), (384, 128), (384, 777), (384, 2600)])
+@pytest.mark.parametrize("strided_out,scale", [(False, 1.0), (True, 1.0), (False, 1.25)])
+def test_mlp_ln_residual_fused_bf16(P, C, M, strided_out, scale):
+    """One-launch MLP branch (csrc/mlp_fused_bf16.hip) == Linear -> GELU(erf) -> Linear -> LayerNorm -> residual
+    (reference layers.py:251, :264-270), ragged M, strided output (the skip-concat buffer), DropPath branch scale."""
+    from pangu_pytorch_amd import ops_bf16 as ob
+    x = synth.uniform((M, C), 81, 1.5).to(BF)
+    w1 = synth.uniform((4 * C, C), 82, 1.5 / C ** 0.5).to(BF)
+    w2 = synth.uniform((C, 4 * C), 83, 1.0 / (2 * C ** 0.5)).to(BF)
+    b1, b2 = synth.uniform((4 * C,), 84, 0.5), synth.uniform((C,), 85, 0.5)
+    g, be = synth.uniform((C,), 86, 0.5, 1.0), synth.uniform((C,), 87, 0.3)
+    ref = _mlp_ref(x, w1, b1, w2, b2, g, be, scale)
+    img = ob.pack_mlp_weights(w1.cuda(), w2.cuda())
+    out = None
+    if strided_out:
+        full = torch.zeros((M, 2 * C), dtype=BF, device="cuda")
+        out = full[:, C:]
+    got = ob.mlp_ln_residual(x.cuda(), img, b1.cuda(), b2.cuda(), g.cuda(), be.cuda(), out=out, branch_scale=scale)
+    assert got.dtype == BF and got.shape == (M, C)
+    err = (got.double().cpu() - ref).abs()
+    # bf16 output rounding (2^-9 of |out| <= ~6) + the GELU fit (2.7e-4 per hidden unit, averaged down by the second product)
+    assert err.max().item() < 2.5 * ROUND * ref.abs().max().item() / 2, err.max().item()
+    assert (err.norm() / ref.norm()).item() < 3e-3
+    if strided_out:
+        assert float(full[:, :C].float().abs().max()) == 0.0
+    # and the three-launch path it replaces agrees at the same level
+    h = ob.linear(x.cuda(), w1.cuda(), b1.cuda(), act=ob.ACT_GELU)
+    sep = ob.linear_ln_residual(h, w2.cuda(), b2.cuda(), x.cuda(), g.cuda(), be.cuda()) if scale == 1.0 else None
+    if sep is not None:
+        assert ((sep.double().cpu() - ref).norm() / ref.norm()).item() < 3e-3
+
+
 def test_linear_bf16_random_shapes(P):
     """Ragged M, K % 8 == 0, every kernel family (weights-stationary, LDS-DMA ring, register-staged), bias / GELU / add."""
     import random

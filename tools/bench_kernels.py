@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-shape kernel micro-benchmarks on one MI355X (development tool, not the headline bench).
 
-  python tools/bench_kernels.py gemm|attn|rows [--lib-compare]
+  python tools/bench_kernels.py gemm|attn|rows|mlp_fused|... [--lib-compare]
 `--lib-compare` also times torch.matmul (hipBLASLt/rocBLAS) on the same shapes as an external yardstick."""
 import os
 import sys
@@ -71,6 +71,31 @@ def gemm_bf16(lib_compare):
             ms2 = timeit(f)
             line += f"   | torch {ms2:7.3f} ms {2.0 * M * N * K / ms2 / 1e9:6.1f} TF/s"
         print(line)
+
+
+def mlp_fused():
+    """One-launch MLP branch (csrc/mlp_fused_bf16.hip) vs the launches it replaces (MLP-up+GELU, MLP-down(+LN), LN)."""
+    from pangu_pytorch_amd import ops_bf16 as ob
+    bf = torch.bfloat16
+    for M, C, name in ((521280, 192, "s0 mlp"), (131040, 384, "s1 mlp")):
+        x = torch.randn(M, C, device="cuda").to(bf)
+        w1 = (torch.randn(4 * C, C, device="cuda") / C ** 0.5).to(bf)
+        w2 = (torch.randn(C, 4 * C, device="cuda") / (4 * C) ** 0.5).to(bf)
+        b1, b2 = torch.randn(4 * C, device="cuda"), torch.randn(C, device="cuda")
+        g, be = torch.randn(C, device="cuda"), torch.randn(C, device="cuda")
+        img = ob.pack_mlp_weights(w1, w2)
+        out = torch.empty_like(x)
+        ms = timeit(lambda: ob.mlp_ln_residual(x, img, b1, b2, g, be, out=out))
+
+        def sep():
+            h = ob.linear(x, w1, b1, act=ob.ACT_GELU)
+            if C == 192:
+                return ob.linear_ln_residual(h, w2, b2, x, g, be, out=out)
+            return ob.ln_residual(ob.linear(h, w2, b2), x, g, be, out=out)
+        ms2 = timeit(sep)
+        fl = 16.0 * M * C * C
+        print(f"{name:8s} M={M:6d} C={C:3d}  fused {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF/s ({fl / ms / 2.5e12 * 100:4.1f} % of 2.5 PF)"
+              f"   | separate launches {ms2:7.3f} ms {fl / ms2 / 1e9:7.1f} TF/s")
 
 
 def gemm_ln():
@@ -184,5 +209,5 @@ def rows():
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
     {"gemm": lambda: gemm("--lib-compare" in sys.argv), "attn": attn, "attn_bwd": attn_bwd, "rows": rows,
-     "gemm_bf16": lambda: gemm_bf16("--lib-compare" in sys.argv), "attn_bf16": attn_bf16, "gemm_ln_bf16": gemm_ln_bf16, "gemm_ln": gemm_ln,
+     "gemm_bf16": lambda: gemm_bf16("--lib-compare" in sys.argv), "attn_bf16": attn_bf16, "gemm_ln_bf16": gemm_ln_bf16, "mlp_fused": mlp_fused, "gemm_ln": gemm_ln,
      "wgrad_bf16": lambda: wgrad(True), "wgrad": lambda: wgrad(False)}[what]()
