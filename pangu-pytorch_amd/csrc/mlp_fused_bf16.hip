@@ -14,25 +14,28 @@
 //        H^T[hidden][token] = W1[hidden][:] . x^T          (K = C)
 //        Y^T[c][token]     += W2[c][hidden chunk] . GELU(H^T)[hidden chunk][token]     (K = 32 per chunk)
 //    so the accumulator of the first product (hidden on the register index, token on the lane) IS the B operand of the
-//    second one after bias + GELU + bf16 packing: two 16-row hidden tiles give each lane the eight k values
-//    {4g..4g+3} u {16+4g..16+4g+3} of a 32-deep k-step; the W2 fragment is stored in that k order by the host-side
-//    packing, so nothing crosses lanes and nothing goes through LDS between the two products;
+//    second one after GELU + bf16 packing (the bias is the accumulator's initial value): two 16-row hidden tiles give
+//    each lane the eight k values {4g..4g+3} u {16+4g..16+4g+3} of a 32-deep k-step; the W2 fragment is stored in that
+//    k order by the host-side packing, so nothing crosses lanes and nothing goes through LDS between the two products;
 //  * Y^T (C x 16T per wave, fp32) stays in 4*(C/16)*T accumulator registers over all hidden chunks;
-//  * the weights stream L2 -> LDS by LDS-DMA in chunks of 32 hidden units (W1 rows + W2 columns of the chunk, 128*C
-//    bytes, packed contiguously by the host: pangu_pack_mlp_weights_bf16's layout below), ring of NST chunks, one raw
-//    s_barrier per chunk, counted vmcnt; every fragment read is a conflict-free ds_read_b128 feeding T MFMAs;
-//  * software pipeline over chunks: the bias + GELU + pack of chunk i-1 (VALU) is issued between the MFMAs of the first
-//    product of chunk i, then the second product of chunk i-1 runs -- with one wave per SIMD nothing else would cover
-//    the VALU work;
+//  * the weights stream L2 -> LDS by LDS-DMA in chunks of 32 hidden units, W1 rows and W2 columns as two streams with
+//    a ring of 3 slots each (the host packs both contiguously, layout below), one raw s_barrier per chunk, counted
+//    vmcnt (two chunks ahead); every fragment read is a conflict-free ds_read_b128 feeding T MFMAs;
+//  * three-stage software pipeline over chunks -- with one wave per SIMD nothing but the wave's own instruction order
+//    overlaps VALU, LDS and DMA-issue work with the matrix pipe: iteration i runs the SECOND product of chunk i-2, then
+//    the FIRST product of chunk i, and spreads the GELU + pack of chunk i-1 and the LDS-DMA requests of chunks i+2 / i
+//    between the MFMAs of both (step boundaries pinned with sched_barrier, MFMA : VALU interleave inside a step with
+//    sched_group_barrier);
 //  * epilogue per 16-token tile: shortcut rows staged into a per-wave LDS patch (coalesced 16-B loads), LayerNorm
 //    statistics in fp32 over the lane's 4*C/16 values + two cross-lane adds, normalise / gamma / beta / scale / residual
 //    in the MFMA layout against the patch, rows read back and stored as whole 16-B segments.
 //
-// Packed weight image (u16 elements), chunk ch = 0 .. 4C/32-1, 64*C elements each:
-//   [0, 32C):   W1 part, row hr = 0..31 (hidden 32ch+hr), 16-B chunk position p = 0..C/8-1 holds the eight K values
-//               8q..8q+7 of that row with q = p ^ (hr & SW), SW = 15 (C = 384) / 7 (C = 192)   (bank swizzle)
-//   [32C, 64C): W2 part, plane g = 0..3, row c = 0..C-1, 8 elements j: W2[c][32ch + (j<4 ? 4g+j : 16+4g+j-4)]
+// Packed weight image (u16 elements) [2][4C/32][32*C]: plane 0 = W1 stream, plane 1 = W2 stream, chunk ch each:
+//   W1 chunk: row hr = 0..31 (hidden 32ch+hr), 16-B chunk position p = 0..C/8-1 holds the eight K values
+//             8q..8q+7 of that row with q = p ^ (hr & SW), SW = 15 (C = 384) / 7 (C = 192)   (bank swizzle)
+//   W2 chunk: plane g = 0..3, row c = 0..C-1, 8 elements j: W2[c][32ch + (j<4 ? 4g+j : 16+4g+j-4)]
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -42,27 +45,21 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr float LN_EPS = 1e-5f;
 
-// Development knob (tools/ablate_mlp.py builds timing-only variants with -DPANGU_MLP_ABLATE=mask; the product is 0):
-// 1 no in-loop weight requests, 2 no GELU, 4 no first product, 8 no second product, 16 no epilogue.
+// Development knobs (tools/ablate_mlp.py builds timing variants with -D...; the product uses the defaults).
 #ifndef PANGU_MLP_ABLATE
-#define PANGU_MLP_ABLATE 0
+#define PANGU_MLP_ABLATE 0      // timing only: 1 no in-loop weight requests, 2 no GELU, 4 / 8 no first / second product
 #endif
-constexpr int ABL = PANGU_MLP_ABLATE;
 #ifndef PANGU_MLP_PD1
-#define PANGU_MLP_PD1 3
+#define PANGU_MLP_PD1 2         // fragment-read distance (k-steps ahead of the MFMAs), first product
 #endif
 #ifndef PANGU_MLP_PD2
-#define PANGU_MLP_PD2 6
-#endif
-#ifndef PANGU_MLP_DMA_G1
-#define PANGU_MLP_DMA_G1 1
+#define PANGU_MLP_PD2 4         // the same (row tiles ahead), second product
 #endif
 #ifndef PANGU_MLP_IGLP
-#define PANGU_MLP_IGLP 3
+#define PANGU_MLP_IGLP 3        // VALU instructions placed behind each MFMA of a step (0 = leave it to the scheduler)
 #endif
-constexpr bool DMA_IN_G1 = PANGU_MLP_DMA_G1;
-constexpr int IGLP = PANGU_MLP_IGLP;
-constexpr int PD1 = PANGU_MLP_PD1, PD2 = PANGU_MLP_PD2;      // fragment-read distance (steps ahead of the MFMAs) in the two products
+constexpr int ABL = PANGU_MLP_ABLATE;
+constexpr int PD1 = PANGU_MLP_PD1, PD2 = PANGU_MLP_PD2, IGLP = PANGU_MLP_IGLP;
 
 __device__ inline float bflo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ inline float bfhi(unsigned u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
@@ -80,34 +77,41 @@ __device__ __forceinline__ float gelu1(float x) {
   const float e = __builtin_amdgcn_exp2f(x * w);                    // exp(-x (c0 + c1 x^2)); +inf for x << 0 -> result 0
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
-__device__ __forceinline__ f32x4 gelu4(f32x4 v) { return f32x4{gelu1(v[0]), gelu1(v[1]), gelu1(v[2]), gelu1(v[3])}; }
 
-template <int C, int T, int NST, int NW>
-__global__ __launch_bounds__(64 * NW, NW / 4) void mlp_ln_residual_bf16_kernel(
+template <bool B>
+using Flag = std::integral_constant<bool, B>;
+template <int N>
+using Int = std::integral_constant<int, N>;
+
+template <int C, int T>
+__global__ __launch_bounds__(256, 1) void mlp_ln_residual_bf16_kernel(
     const u16* __restrict__ X, int ldx, const u16* __restrict__ Wimg, const float* __restrict__ b1,
     const float* __restrict__ b2, const float* __restrict__ gamma, const float* __restrict__ beta,
     u16* __restrict__ Out, int ldo, int M, float scale) {
   constexpr int HID = 4 * C, NCH = HID / 32, KS = C / 32, RT = C / 16;
-  constexpr int W1B = 64 * C;                 // bytes of the W1 part of a chunk image
-  constexpr int CHB = 128 * C;                // bytes per chunk image
-  constexpr int LPW = CHB / 1024 / NW;        // LDS-DMA instructions per wave and chunk (1 KB each)
-  constexpr int D = NST - 2;                  // chunks requested ahead of the one being computed
+  constexpr int WB = 64 * C;                  // bytes of one W1 (or W2) chunk
+  constexpr int NS = 3;                       // ring slots per stream
+  constexpr int LPS = WB / 4096;              // LDS-DMA instructions per wave, chunk and stream (1 KB each)
+  constexpr int LPW = 2 * LPS;                // ... per wave and iteration
   constexpr int SW = C == 384 ? 15 : 7;
   constexpr int PLD = 2 * C + 16;             // bytes per row of an epilogue patch
   constexpr int CPR = C / 8;                  // 16-B chunks per activation row
-  static_assert(D >= 1 && NCH > NST && RT % LPW == 0 && KS % LPW == 0, "ring");
+  constexpr int E = 8 * T;                    // GELU elements per lane and chunk: [tt][ht][r]
+  static_assert(KS % LPS == 0 && RT % LPS == 0 && NCH > 4, "shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* b1s = reinterpret_cast<float*>(smem + NST * CHB);
+  unsigned char* const ring1 = smem;                      // W1 stream, NS slots
+  unsigned char* const ring2 = smem + NS * WB;            // W2 stream, NS slots
+  float* const b1s = reinterpret_cast<float*>(smem + 2 * NS * WB);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lq = lane & 15, lg = lane >> 4;
-  const int m0 = blockIdx.x * (16 * T * NW) + wave * (16 * T);
+  const int m0 = blockIdx.x * (64 * T) + wave * (16 * T);
 
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<u16*>(X), 0, (int)(((size_t)(M - 1) * ldx + C) * sizeof(u16)), 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<u16*>(Wimg), 0, NCH * CHB, 0x00020000);
+      const_cast<u16*>(Wimg), 0, 2 * NCH * WB, 0x00020000);
 
   // ---- activations of this wave: fragment (ks, tt) = x[m0 + 16tt + lq][32ks + 8lg .. +7]  (rows >= M read as zeros)
   bf16x8 xf[KS][T];
@@ -120,23 +124,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_ln_residual_bf16_kernel(
                                                   x_rsrc, (int)((row * (unsigned)ldx + 32 * ks + 8 * lg) * 2u), 0, 0));
   }
   // ---- b1 -> LDS (fp32)
-  for (int i = tid; i < HID / 4; i += 64 * NW)
+  for (int i = tid; i < HID / 4; i += 256)
     reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(b1)[i];
 
-  // chunk ch -> ring slot ch % NST; instruction i of wave w copies bytes [(4i + w) KB, +1 KB) of the chunk image
-  auto issue_piece = [&](int ch, int slot, int i) {
-    if (ABL & 1) return;
-    const int q = i * NW + wave;
-    auto dst = (__attribute__((address_space(3))) void*)(smem + slot * CHB + q * 1024);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, dst, 16, lane * 16, ch * CHB + q * 1024, 0, 0);
-  };
-  auto issue = [&](int ch, int slot) {
-#pragma unroll
-    for (int i = 0; i < LPW; ++i) {
-      const int q = i * NW + wave;
-      auto dst = (__attribute__((address_space(3))) void*)(smem + slot * CHB + q * 1024);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, dst, 16, lane * 16, ch * CHB + q * 1024, 0, 0);
-    }
+  // piece i (0 .. LPS-1) of this wave for chunk ch of stream st (0 = W1, 1 = W2) -> ring slot `slot` of that stream
+  auto issue_piece = [&](int st, int ch, int slot, int i) {
+    const int q = i * 4 + wave;
+    auto dst = (__attribute__((address_space(3))) void*)((st ? ring2 : ring1) + slot * WB + q * 1024);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, dst, 16, lane * 16, (st * NCH + ch) * WB + q * 1024, 0, 0);
   };
 
   f32x4 yacc[RT][T];
@@ -144,153 +139,164 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_ln_residual_bf16_kernel(
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int tt = 0; tt < T; ++tt) yacc[rt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 hacc[2][T];
+  f32x4 hacc[2][T];          // first product of the current chunk (bias included)
+  f32x4 hg[2][T];            // first product of the previous chunk, GELU applied element by element during this iteration
+  bf16x8 hf[T];              // packed GELU output of the chunk before that: B operand of the second product
 
-  // first product of one chunk; STEP(ks) is called between k-steps (hook for the interleaved VALU work)
-  auto gemm1 = [&](const unsigned char* w1, int ch, auto&& step) {
-    // the accumulators start from the bias of this lane's hidden rows 4lg .. 4lg+3 of both 16-row tiles
-    const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b1s + 32 * ch + 4 * lg);
-    const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1s + 32 * ch + 16 + 4 * lg);
+  // One iteration: G2 = second product of chunk ch-2 (operand hf), GE = GELU of chunk ch-1 (hg), G1 = first product of
+  // chunk ch (-> hacc); I1 / I2: request W1 chunk ch+2 / W2 chunk ch.  All flags are compile-time (peeled prologue /
+  // drain iterations), so the steady-state body is one basic block.
+  auto iteration = [&](int ch, int a /* ch % 3 */, auto g2, auto ge, auto g1, auto i1, auto i2) {
+    constexpr bool G2 = decltype(g2)::value, GE = decltype(ge)::value, G1 = decltype(g1)::value;
+    constexpr bool I1 = decltype(i1)::value && !(ABL & 1), I2 = decltype(i2)::value && !(ABL & 1);
+    const int a1 = a + 1 >= NS ? a + 1 - NS : a + 1, a2 = a + 2 >= NS ? a + 2 - NS : a + 2;
+    const unsigned char* w1 = ring1 + a * WB;              // W1 chunk ch
+    const unsigned char* w2 = ring2 + a1 * WB;             // W2 chunk ch-2  ((ch-2) % 3 == (ch+1) % 3)
+    // GELU element e of hg in the order [tt][ht][r]: the first half is done beside the second product, the rest beside
+    // the first product
+    auto gelu_elems = [&](int e0, int e1) {
 #pragma unroll
-    for (int tt = 0; tt < T; ++tt) {
-      hacc[0][tt] = bv0;
-      hacc[1][tt] = bv1;
-    }
-    // Fragment reads run one k-step ahead of their MFMAs (one wave per SIMD: nothing else hides the LDS latency).  Left
-    // alone, the scheduler sinks every ds_read next to its MFMAs (read -> lgkmcnt(0) -> MFMA, the LDS latency exposed
-    // every step): the step boundaries are pinned with sched_barrier, inside a step it is free.
-    auto rd = [&](int ks, int ht) {
-      const int pc = (4 * ks + lg) ^ (lq & SW);
-      return *reinterpret_cast<const bf16x8*>(w1 + (16 * ht + lq) * (2 * C) + pc * 16);
+      for (int e = e0; e < e1; ++e) {
+        const int tt = e >> 3, ht = (e >> 2) & 1, r = e & 3;
+        if (!(ABL & 2)) hg[ht][tt][r] = gelu1(hg[ht][tt][r]);
+      }
     };
-    bf16x8 fa[KS][2];
+    // ---- second product of chunk ch-2: RT steps of T MFMAs, fragment reads PD2 steps ahead
+    if constexpr (G2) {
+      auto rd = [&](int rt) { return *reinterpret_cast<const bf16x8*>(w2 + lg * (16 * C) + (16 * rt + lq) * 16); };
+      bf16x8 fa[RT];
 #pragma unroll
-    for (int ks = 0; ks < PD1 && ks < KS; ++ks) {
-      fa[ks][0] = rd(ks, 0);
-      fa[ks][1] = rd(ks, 1);
+      for (int rt = 0; rt < PD2 && rt < RT; ++rt) fa[rt] = rd(rt);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        if (rt + PD2 < RT) fa[rt + PD2] = rd(rt + PD2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(ABL & 8)) {
+#pragma unroll
+          for (int tt = 0; tt < T; ++tt)
+            yacc[rt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[rt], hf[tt], yacc[rt][tt], 0, 0, 0);
+        } else {
+          asm volatile("" ::"v"(fa[rt]), "v"(hf[0]));
+        }
+        if constexpr (GE) gelu_elems((E / 2) * rt / RT, (E / 2) * (rt + 1) / RT);
+        if (I2 && rt % (RT / LPS) == 0) issue_piece(1, ch, a, rt / (RT / LPS));
+        if (IGLP && GE) {
+#pragma unroll
+          for (int i = 0; i < T; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, IGLP, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      if constexpr (GE) gelu_elems(0, E / 2);
+      if (I2) {
+#pragma unroll
+        for (int i = 0; i < LPS; ++i) issue_piece(1, ch, a, i);
+      }
     }
+    // ---- first product of chunk ch: KS steps of 2T MFMAs, fragment reads PD1 steps ahead; accumulators start from the
+    // bias of this lane's hidden rows 4lg .. 4lg+3 of both 16-row tiles
+    if constexpr (G1) {
+      const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b1s + 32 * ch + 4 * lg);
+      const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1s + 32 * ch + 16 + 4 * lg);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (ks + PD1 < KS) {
-        fa[ks + PD1][0] = rd(ks + PD1, 0);
-        fa[ks + PD1][1] = rd(ks + PD1, 1);
+      for (int tt = 0; tt < T; ++tt) {
+        hacc[0][tt] = bv0;
+        hacc[1][tt] = bv1;
       }
-      __builtin_amdgcn_sched_barrier(0);
-      if (!(ABL & 4)) {
+      auto rd = [&](int ks, int ht) {
+        const int pc = (4 * ks + lg) ^ (lq & SW);
+        return *reinterpret_cast<const bf16x8*>(w1 + (16 * ht + lq) * (2 * C) + pc * 16);
+      };
+      bf16x8 fa[KS][2];
 #pragma unroll
-        for (int tt = 0; tt < T; ++tt) {
-          hacc[0][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][0], xf[ks][tt], hacc[0][tt], 0, 0, 0);
-          hacc[1][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][1], xf[ks][tt], hacc[1][tt], 0, 0, 0);
-        }
-      } else {
-        asm volatile("" ::"v"(fa[ks][0]), "v"(fa[ks][1]));
+      for (int ks = 0; ks < PD1 && ks < KS; ++ks) {
+        fa[ks][0] = rd(ks, 0);
+        fa[ks][1] = rd(ks, 1);
       }
-      step(ks);
-      if (IGLP) {                                          // MFMA, a few VALU, MFMA, ...: keeps the matrix pipe fed while
-#pragma unroll                                             // the GELU share of this step issues
-        for (int i = 0; i < 2 * T; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, IGLP, 0);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks + PD1 < KS) {
+          fa[ks + PD1][0] = rd(ks + PD1, 0);
+          fa[ks + PD1][1] = rd(ks + PD1, 1);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(ABL & 4)) {
+#pragma unroll
+          for (int tt = 0; tt < T; ++tt) {
+            hacc[0][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][0], xf[ks][tt], hacc[0][tt], 0, 0, 0);
+            hacc[1][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][1], xf[ks][tt], hacc[1][tt], 0, 0, 0);
+          }
+        } else {
+          asm volatile("" ::"v"(fa[ks][0]), "v"(fa[ks][1]));
+        }
+        if constexpr (GE) gelu_elems(E / 2 + (E / 2) * ks / KS, E / 2 + (E / 2) * (ks + 1) / KS);
+        if (I1 && ks % (KS / LPS) == 0) issue_piece(0, ch + 2, a2, ks / (KS / LPS));
+        if (IGLP && GE) {
+#pragma unroll
+          for (int i = 0; i < 2 * T; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, IGLP, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      if constexpr (GE) gelu_elems(E / 2, E);
+    }
+    // ---- rotate the pipeline registers: hf <- pack(GELU(chunk ch-1)), hg <- chunk ch
+    if constexpr (GE) {
+#pragma unroll
+      for (int tt = 0; tt < T; ++tt)
+        hf[tt] = __builtin_bit_cast(bf16x8, u32x4{pack_bf16x2(hg[0][tt][0], hg[0][tt][1]), pack_bf16x2(hg[0][tt][2], hg[0][tt][3]),
+                                                  pack_bf16x2(hg[1][tt][0], hg[1][tt][1]), pack_bf16x2(hg[1][tt][2], hg[1][tt][3])});
+    }
+    if constexpr (G1) {
+#pragma unroll
+      for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+        for (int tt = 0; tt < T; ++tt) hg[ht][tt] = hacc[ht][tt];
     }
   };
-  auto gemm2 = [&](const unsigned char* w2, const bf16x8 (&hf)[T], auto&& step) {
-    auto rd = [&](int rt) { return *reinterpret_cast<const bf16x8*>(w2 + lg * (16 * C) + (16 * rt + lq) * 16); };
-    bf16x8 fa[RT];
-#pragma unroll
-    for (int rt = 0; rt < PD2 && rt < RT; ++rt) fa[rt] = rd(rt);
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      if (rt + PD2 < RT) fa[rt + PD2] = rd(rt + PD2);             // PD2 row tiles ahead
-      __builtin_amdgcn_sched_barrier(0);
-      if (!(ABL & 8)) {
-#pragma unroll
-        for (int tt = 0; tt < T; ++tt)
-          yacc[rt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[rt], hf[tt], yacc[rt][tt], 0, 0, 0);
-      } else {
-        asm volatile("" ::"v"(fa[rt]), "v"(hf[0]));
-      }
-      step(rt);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
-  // ---- prologue: chunks 0 .. D requested, first product of chunk 0
-#pragma unroll
-  for (int c0 = 0; c0 <= D; ++c0) issue(c0, c0);
-  wait_vmcnt<D * LPW>();
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  gemm1(smem, 0, [](int) {});
-
-  f32x4 hprev[2][T];
-  int slot = 1, slot_prev = 0, slot_new = (1 + D) % NST;
-  for (int ch = 1; ch < NCH; ++ch) {
-    // chunk ch has landed (this wave's pieces), then for every wave; ring slot of chunk ch-2 is free after the barrier
-    const int newer = NCH - 1 - ch < D - 1 ? NCH - 1 - ch : D - 1;
-    if (D >= 3 && newer >= 2) wait_vmcnt<2 * LPW>();
-    else if (D >= 2 && newer >= 1) wait_vmcnt<LPW>();
-    else wait_vmcnt<0>();
+  // top of iteration ch: the request group of iteration ch-2 has landed (this wave's pieces: vmcnt leaves the N newest
+  // requests in flight; every wave's: barrier); the slots it re-requests now were last read in iteration ch-1
+  auto sync = [&](auto n) {
+    wait_vmcnt<decltype(n)::value>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+  };
+  using Y = Flag<true>;
+  using N_ = Flag<false>;
+
+  // ---- prologue: W1 chunks 0, 1 requested; iterations 0 and 1 have no second product yet
 #pragma unroll
-    for (int ht = 0; ht < 2; ++ht)
+  for (int i = 0; i < LPS; ++i) issue_piece(0, 0, 0, i);
 #pragma unroll
-      for (int tt = 0; tt < T; ++tt) hprev[ht][tt] = hacc[ht][tt];
-    // first product of chunk ch with bias + GELU of chunk ch-1 spread over its k-steps (EPS elements per step)
-    // (the LDS-DMA requests of chunk ch+D go out here too, one piece per k-step: their ring slot, that of chunk ch-2, is
-    // free since the barrier above, and they get a whole iteration of flight time)
-    const bool more = ch + D < NCH;
-    gemm1(smem + slot * CHB, ch, [&](int ks) {
-      constexpr int E = 8 * T, EPS = (E + KS - 1) / KS;
-#pragma unroll
-      for (int e = ks * EPS; e < (ks + 1) * EPS && e < E; ++e) {
-        const int q = e >> 2, r = e & 3, tt = q >> 1, ht = q & 1;
-        if (!(ABL & 2)) hprev[ht][tt][r] = gelu1(hprev[ht][tt][r]);
-      }
-      constexpr int EVERY = KS / LPW;
-      if (DMA_IN_G1 && C == 384 && ks % EVERY == 0 && more) issue_piece(ch + D, slot_new, ks / EVERY);
-    });
-    bf16x8 hf[T];
-#pragma unroll
-    for (int tt = 0; tt < T; ++tt)
-      hf[tt] = __builtin_bit_cast(bf16x8, u32x4{pack_bf16x2(hprev[0][tt][0], hprev[0][tt][1]),
-                                                pack_bf16x2(hprev[0][tt][2], hprev[0][tt][3]),
-                                                pack_bf16x2(hprev[1][tt][0], hprev[1][tt][1]),
-                                                pack_bf16x2(hprev[1][tt][2], hprev[1][tt][3])});
-    // second product of chunk ch-1
-    gemm2(smem + slot_prev * CHB + W1B, hf, [&](int rt) {
-      constexpr int EVERY = RT / LPW;
-      if (!(DMA_IN_G1 && C == 384) && rt % EVERY == 0 && more) issue_piece(ch + D, slot_new, rt / EVERY);
-    });
-    slot_prev = slot;
-    slot = slot + 1 == NST ? 0 : slot + 1;
-    slot_new = slot_new + 1 == NST ? 0 : slot_new + 1;
+  for (int i = 0; i < LPS; ++i) issue_piece(0, 1, 1, i);
+  sync(Int<LPS>{});                                       // W1 chunk 0 (and x, b1) landed; W1 chunk 1 in flight
+  iteration(0, 0, N_{}, N_{}, Y{}, Y{}, Y{});
+  sync(Int<LPW>{});
+  iteration(1, 1, N_{}, Y{}, Y{}, Y{}, Y{});
+  int a = 2;
+  for (int ch = 2; ch < NCH - 2; ++ch) {
+    sync(Int<LPW>{});
+    iteration(ch, a, Y{}, Y{}, Y{}, Y{}, Y{});
+    a = a + 1 == NS ? 0 : a + 1;
   }
-  {   // last chunk: bias + GELU + second product
-    bf16x8 hf[T];
-#pragma unroll
-    for (int tt = 0; tt < T; ++tt) {
-      const f32x4 v0 = gelu4(hacc[0][tt]), v1 = gelu4(hacc[1][tt]);
-      hf[tt] = __builtin_bit_cast(bf16x8, u32x4{pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]),
-                                                pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])});
-    }
-    gemm2(smem + slot_prev * CHB + W1B, hf, [](int) {});
-  }
-  __syncthreads();                               // every wave is done with the ring: the patches may reuse it
+  // ---- drain: chunks NCH-2, NCH-1 request no W1 any more; then two iterations without a first product
+  sync(Int<LPW>{});
+  iteration(NCH - 2, (NCH - 2) % NS, Y{}, Y{}, Y{}, N_{}, Y{});
+  sync(Int<LPS>{});
+  iteration(NCH - 1, (NCH - 1) % NS, Y{}, Y{}, Y{}, N_{}, Y{});
+  sync(Int<LPS>{});
+  iteration(NCH, NCH % NS, Y{}, Y{}, N_{}, N_{}, N_{});
+  sync(Int<0>{});
+  iteration(NCH + 1, (NCH + 1) % NS, Y{}, N_{}, N_{}, N_{}, N_{});
+  __syncthreads();                               // every wave is done with the rings: the patches may reuse them
 
   // ---- epilogue: lane holds Y^T[c = 16rt + 4lg + r][token m0 + 16tt + lq]
-  if (ABL & 16) {
-    float keep = 0.f;                                     // keeps every accumulator live
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int tt = 0; tt < T; ++tt) keep += (yacc[rt][tt][0] + yacc[rt][tt][1]) + (yacc[rt][tt][2] + yacc[rt][tt][3]);
-    if (keep == 123.456f) Out[tid] = 1;
-    return;
-  }
   unsigned char* patch = smem + wave * (16 * PLD);
   const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       Out, 0, (int)(((size_t)(M - 1) * ldo + C) * sizeof(u16)), 0x00020000);
@@ -347,18 +353,17 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_ln_residual_bf16_kernel(
   }
 }
 
-template <int C, int T, int NST, int NW>
+template <int C, int T>
 int launch_mlp(hipStream_t s, const u16* x, int ldx, const u16* wimg, const float* b1, const float* b2,
                const float* gamma, const float* beta, u16* out, int ldo, int M, float scale) {
-  constexpr int CHB = 128 * C;
-  constexpr size_t ring = (size_t)NST * CHB + 4 * C * sizeof(float);
-  constexpr size_t epi = (size_t)NW * 16 * (2 * C + 16);
+  constexpr size_t ring = (size_t)6 * 64 * C + 4 * C * sizeof(float);
+  constexpr size_t epi = (size_t)4 * 16 * (2 * C + 16);
   constexpr size_t shm = ring > epi ? ring : epi;
   static_assert(shm <= 160 * 1024, "LDS");
-  auto kern = mlp_ln_residual_bf16_kernel<C, T, NST, NW>;
+  auto kern = mlp_ln_residual_bf16_kernel<C, T>;
   PANGU_ENSURE_DYN_LDS(kern, shm);
-  const int grid = (M + 16 * T * NW - 1) / (16 * T * NW);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), shm, s, x, ldx, wimg, b1, b2, gamma, beta, out, ldo, M, scale);
+  const int grid = (M + 64 * T - 1) / (64 * T);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shm, s, x, ldx, wimg, b1, b2, gamma, beta, out, ldo, M, scale);
   return pangu_launch_status();
 }
 
@@ -371,15 +376,11 @@ extern "C" int pangu_mlp_ln_residual_fwd_bf16(pangu_stream_t stream, const void*
   if (M <= 0 || ldx < C || ldo < C || (ldx & 7) || (ldo & 7)) return PANGU_E_SHAPE;
   if (!pangu_fits_u32(M, ldx, 2) || !pangu_fits_u32(M, ldo, 2)) return PANGU_E_RANGE;
   hipStream_t s = (hipStream_t)stream;
-#ifndef PANGU_MLP_NW
-#define PANGU_MLP_NW 4
-#endif
-  constexpr int NW = PANGU_MLP_NW;
   if (C == 192)
-    return launch_mlp<192, 16 / NW, 4, NW>(s, (const u16*)x, ldx, (const u16*)w_packed, b1, b2, gamma, beta, (u16*)out, ldo,
-                                           M, branch_scale);
+    return launch_mlp<192, 4>(s, (const u16*)x, ldx, (const u16*)w_packed, b1, b2, gamma, beta, (u16*)out, ldo, M,
+                              branch_scale);
   if (C == 384)
-    return launch_mlp<384, 8 / NW, 3, NW>(s, (const u16*)x, ldx, (const u16*)w_packed, b1, b2, gamma, beta, (u16*)out, ldo,
-                                          M, branch_scale);
+    return launch_mlp<384, 2>(s, (const u16*)x, ldx, (const u16*)w_packed, b1, b2, gamma, beta, (u16*)out, ldo, M,
+                              branch_scale);
   return PANGU_E_SHAPE;
 }

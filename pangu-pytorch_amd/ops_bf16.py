@@ -83,8 +83,8 @@ def linear_ln_residual(a, weight, bias, shortcut, gamma, beta, out=None):
 
 def pack_mlp_weights(w1, w2):
     """Chunk image of an Mlp's weights for `mlp_ln_residual` (layout: csrc/mlp_fused_bf16.hip header).  w1 (4C, C), w2 (C, 4C),
-    any float dtype, C in (192, 384) -> bf16 (4C/32, 64*C): per 32 hidden units the W1 rows (16-B chunks XOR-swizzled for
-    conflict-free fragment reads) followed by the W2 columns in the k order the first product's accumulators come in."""
+    any float dtype, C in (192, 384) -> bf16 (2, 4C/32, 32*C): plane 0 = per 32 hidden units the W1 rows (16-B chunks XOR-swizzled
+    for conflict-free fragment reads), plane 1 = the W2 columns in the k order the first product's accumulators come in."""
     HID, C = w1.shape
     if C not in (192, 384) or HID != 4 * C or tuple(w2.shape) != (C, HID):
         raise RuntimeError(f"pack_mlp_weights: w1 {tuple(w1.shape)} w2 {tuple(w2.shape)}")
@@ -97,7 +97,7 @@ def pack_mlp_weights(w1, w2):
     w1img = w1b[:, hr[:, None], src, :]                                       # (nch, 32, C/8, 8)
     perm = torch.tensor([4 * g + j if j < 4 else 16 + 4 * g + j - 4 for g in range(4) for j in range(8)], device=dev)
     w2img = w2.to(torch.bfloat16).reshape(C, nch, 32)[:, :, perm].reshape(C, nch, 4, 8).permute(1, 2, 0, 3)
-    return torch.cat([w1img.reshape(nch, 32 * C), w2img.reshape(nch, 32 * C)], 1).contiguous()
+    return torch.stack([w1img.reshape(nch, 32 * C), w2img.reshape(nch, 32 * C)], 0).contiguous()
 
 
 def mlp_ln_residual(x, w_packed, b1, b2, gamma, beta, out=None, branch_scale=1.0):
@@ -107,7 +107,7 @@ def mlp_ln_residual(x, w_packed, b1, b2, gamma, beta, out=None, branch_scale=1.0
     lib = _lib.load()
     xp, ldx = _rows(x, "mlp.x")
     M, C = x.shape
-    if x.dtype != torch.bfloat16 or tuple(w_packed.shape) != (C // 8, 64 * C):
+    if x.dtype != torch.bfloat16 or tuple(w_packed.shape) != (2, C // 8, 32 * C):
         raise RuntimeError(f"mlp_ln_residual: x {tuple(x.shape)} {x.dtype} vs packed weights {tuple(w_packed.shape)}")
     if out is None:
         out = torch.empty((M, C), dtype=torch.bfloat16, device=x.device)

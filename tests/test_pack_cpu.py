@@ -32,7 +32,7 @@ def test_mlp_image_matches_kernel_addressing(C):
     w1 = torch.randn(HID, C, generator=g)
     w2 = torch.randn(C, HID, generator=g)
     img = ob.pack_mlp_weights(w1, w2)
-    assert img.shape == (nch, 64 * C) and img.dtype == torch.bfloat16
+    assert img.shape == (2, nch, 32 * C) and img.dtype == torch.bfloat16
     im = img.float().numpy()
     w1b, w2b = w1.to(torch.bfloat16).float().numpy(), w2.to(torch.bfloat16).float().numpy()
     for ch in (0, 1, nch - 1):
@@ -42,18 +42,18 @@ def test_mlp_image_matches_kernel_addressing(C):
                 for ht in range(2):
                     pc = (4 * ks + lg) ^ (lq & sw)
                     off = ((16 * ht + lq) * (2 * C) + pc * 16) // 2                      # element offset in the chunk
-                    np.testing.assert_array_equal(im[ch, off:off + 8],
+                    np.testing.assert_array_equal(im[0, ch, off:off + 8],
                                                   w1b[32 * ch + 16 * ht + lq, 32 * ks + 8 * lg:32 * ks + 8 * lg + 8])
             for rt in range(RT):
-                off = (64 * C + lg * 16 * C + (16 * rt + lq) * 16) // 2
+                off = (lg * 16 * C + (16 * rt + lq) * 16) // 2
                 hid = [32 * ch + (4 * lg + j if j < 4 else 16 + 4 * lg + j - 4) for j in range(8)]
-                np.testing.assert_array_equal(im[ch, off:off + 8], w2b[16 * rt + lq, hid])
+                np.testing.assert_array_equal(im[1, ch, off:off + 8], w2b[16 * rt + lq, hid])
     # bank conflicts of the fragment reads
     for ks in range(KS):
         for ht in range(2):
             assert _conflict_free(lambda l: (16 * ht + (l & 15)) * 2 * C + ((4 * ks + (l >> 4)) ^ ((l & 15) & sw)) * 16)
     for rt in range(RT):
-        assert _conflict_free(lambda l: 64 * C + (l >> 4) * 16 * C + (16 * rt + (l & 15)) * 16)
+        assert _conflict_free(lambda l: (l >> 4) * 16 * C + (16 * rt + (l & 15)) * 16)
 
 
 def test_shadow_cache_revalidates_on_data_swap_and_is_not_copied():
