@@ -189,6 +189,13 @@ int pangu_linear_fwd_bf16(pangu_stream_t stream, const void* A, int lda, const v
 int pangu_window_attn_fwd_bf16(pangu_stream_t stream, const void* qkv, const void* qkv_bias, const void* esb, void* out,
                                float* lse, int Z, int H, int W, int C, int heads, int shifted);
 
+/* The same attention with the QKV projection fused in (reference layers.py:365-374 + :378-415): q, k, v are computed
+ * per (window, head) from the window's input rows x [tokens][C] (row stride ldx, bf16) and linear1 (w_qkv [3C][C] bf16,
+ * b_qkv [3C] fp32) inside the kernel; the (tokens x 3C) qkv tensor is never materialised.  C = 192 or 384. */
+int pangu_window_attn_qkv_fwd_bf16(pangu_stream_t stream, const void* x, int ldx, const void* w_qkv, const float* b_qkv,
+                                   const void* esb, void* out, float* lse, int Z, int H, int W, int C, int heads,
+                                   int shifted);
+
 int pangu_ln_residual_fwd_bf16(pangu_stream_t stream, const void* y, const void* shortcut, int lds, const float* gamma,
                                const float* beta, void* out, int ldo, int N, int C, float branch_scale);
 /* Projection + post-norm residual in one launch (inference path of layers.py:250-251):

@@ -12,6 +12,7 @@
 // (s = acc*scale + bias).  All prologue loads are issued up front (closed-form tokens), there is one barrier, the bias row of
 // tile i+1 is prefetched under tile i, and the two heads sharing a token's 128-B line run back to back on one XCD.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -253,6 +254,188 @@ __global__ __launch_bounds__(192, 3) void window_attn_bf16_kernel(const u16* __r
   attn_tile<SHIFTED>(Ks, Vt, qf[2], b0, (wave + 6) * 16 + lq, qtok[2], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
 }
 
+// ---- QKV projection fused in ----------------------------------------------------------------------------------------
+// window_attn_qkv_bf16_kernel: the same (window, head) workgroup first COMPUTES its q, k, v from the window's 144 input
+// rows and the head's 96 rows of linear1 (reference layers.py:365-374) instead of reading a (tokens x 3C) qkv tensor that
+// a separate GEMM wrote: that tensor (0.6 GB per C = 192 block in bf16, written and read once) never exists.
+//   * K-loop over the C input channels in steps of 32: the step's x slice (144 rows x 64 B, gathered with the window's
+//     closed-form token indices; zero-pad rows arrive as zeros from the buffer range check, so their q/k/v are the bias,
+//     layers.py:192) and weight slice (96 rows x 64 B) travel L2 -> LDS by LDS-DMA into a ring of 3 slots (source-side
+//     XOR swizzle, counted vmcnt, one raw barrier per step); wave w owns token tiles 3w..3w+2 and all six 16-row weight
+//     tiles: 9 conflict-free ds_read_b128 feed 18 MFMAs per step;
+//   * q and k are computed transposed (weights as the A operand: d on the register index, token on the lane), v the
+//     other way round (token on the register index, d on the lane): the q accumulators, packed, ARE the B operand of the
+//     score product; a lane's eight k values are the d set {4g..4g+3} u {16+4g..16+4g+3} -- the same permuted order in
+//     q and k, which a dot product does not see -- and go to the K image as ONE 16-B write; a lane's four v values are
+//     four consecutive tokens of one d: one 8-B write into the transposed V image.  No transposes, no shuffles;
+//   * the biases are the accumulators' initial values; then the three query tiles of the wave run through attn_tile
+//     exactly as in the kernel above.
+constexpr int QK_ROWS = PANGU_WTOK + 96;                 // rows of one ring slot: 144 x rows, then q/k/v weight rows
+constexpr int QK_SLOT = QK_ROWS * 64;
+
+__device__ inline int kswz64(int row, int chunk) {      // 64-byte rows, 4 chunks: F = {0,2,3,1}[(row>>2)&3]
+  const int f = (0x78 >> (((row >> 2) & 3) * 2)) & 3;
+  return row * 64 + ((chunk ^ f) << 4);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <bool SHIFTED, int C, int QK_RING>
+__global__ __launch_bounds__(192, 2) void window_attn_qkv_bf16_kernel(const u16* __restrict__ x, int ldx,
+                                                                      const u16* __restrict__ wqkv,
+                                                                      const float* __restrict__ bqkv,
+                                                                      const u16* __restrict__ esb, u16* __restrict__ out,
+                                                                      float* __restrict__ lse, WinGeom g, int n_tok,
+                                                                      int heads, int n_pairs) {
+  constexpr int KS = C / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const ring = smem;                                  // QK_RING slots
+  unsigned char* const Ks = smem + QK_RING * QK_SLOT;                // [144][64 B]
+  unsigned char* const Vt = Ks + PANGU_WTOK * 64;                    // [32][VT_LD]
+
+  const int b = blockIdx.x;
+  const int xcd = b & 7, local = b >> 3;
+  int pair, l;
+  if (heads & 1) {
+    pair = (local / g.nLon) * 8 + xcd;
+    l = local % g.nLon;
+  } else {
+    const int sub = local & 1, wl = local >> 1;
+    const int unit = (wl / g.nLon) * 8 + xcd;
+    l = wl % g.nLon;
+    pair = 2 * unit + sub;
+  }
+  if (pair >= n_pairs) return;
+  const int t = pair / heads, hd = pair - t * heads;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lq = lane & 15, lg = lane >> 4;
+  const u16* bias_tile = esb + (size_t)pair * PANGU_WTOK * PANGU_WTOK;
+
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<u16*>(x), 0, (int)(((size_t)(n_tok - 1) * ldx + C) * sizeof(u16)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<u16*>(wqkv), 0, 3 * C * C * (int)sizeof(u16), 0x00020000);
+
+  // ---- LDS-DMA plan: instruction q covers ring rows 16q .. 16q+15 (1 KB); q = 0..8 the x rows, 9..14 the weight rows.
+  // Wave w issues q = w, w+3, .. (five per step).  This lane fills (row 16q + lane>>2, physical chunk lane&3) with the
+  // logical chunk (lane&3) ^ F(row).
+  unsigned voff[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int q = wave + 3 * i;
+    const int row = 16 * q + (lane >> 2);
+    const int f = (0x78 >> (((row >> 2) & 3) * 2)) & 3;
+    const int c = (lane & 3) ^ f;
+    if (q < 9) {
+      const int tok = win_src_token(g, l, t, row, SHIFTED);
+      voff[i] = tok >= 0 ? ((unsigned)tok * (unsigned)ldx + c * 8) * 2u : 0x7FFFFFF0u;       // pad row: out of range -> zeros
+    } else {
+      const int r = row - PANGU_WTOK, which = r >> 5, d = r & 31;
+      voff[i] = ((unsigned)(which * C + hd * 32 + d) * (unsigned)C + c * 8) * 2u;
+    }
+  }
+  auto issue = [&](int ks) {
+    unsigned char* base = ring + (ks % QK_RING) * QK_SLOT;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int q = wave + 3 * i;
+      auto dst = (__attribute__((address_space(3))) void*)(base + q * 1024);
+      if (q < 9) __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, dst, 16, (int)voff[i], ks * 64, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, dst, 16, (int)voff[i], ks * 64, 0, 0);
+    }
+  };
+  issue(0);
+  if (QK_RING >= 3) issue(1);
+
+  // the first tile's bias row and the query-token indices are requested / computed under the K-loop
+  const int tile0 = 3 * wave;
+  int qtok[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) qtok[i] = win_src_token(g, l, t, (tile0 + i) * 16 + lq, SHIFTED);
+
+  // ---- accumulators: [rt 0,1 = q | 2,3 = k][token tile] transposed (d = 4lg + r on the registers, token on the lane);
+  //      [rt 4,5 = v] token 4lg + r on the registers, d = 16(rt-4) + lq on the lane.  Initial value = bias.
+  f32x4 acc[6][3];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bqkv + (rt >> 1) * C + hd * 32 + (rt & 1) * 16 + 4 * lg);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[rt][i] = bv;
+  }
+#pragma unroll
+  for (int rt = 4; rt < 6; ++rt) {
+    const float bv = bqkv[2 * C + hd * 32 + (rt - 4) * 16 + lq];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[rt][i] = f32x4{bv, bv, bv, bv};
+  }
+
+  for (int ks = 0; ks < KS; ++ks) {
+    if (QK_RING >= 3 && ks + 1 < KS) wait_vmcnt<5>(); else wait_vmcnt<0>();     // step ks landed (ring of 3: step ks+1 may fly)
+    // every fragment read of the previous step must have RETURNED before this wave releases the barrier: behind it the other
+    // waves re-request that ring slot, and an LDS-DMA write can overtake a ds_read that is still queued (seen on MI355X as
+    // ~1 wrong workgroup in 3000 when the compiler had sunk the last reads' wait below the barrier)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                                // ... for every wave; the slot of step ks-1 is free
+    asm volatile("" ::: "memory");
+    if (ks + QK_RING - 1 < KS) issue(ks + QK_RING - 1);
+    const unsigned char* slot = ring + (ks % QK_RING) * QK_SLOT;
+    bf16x8 fx[3], fw[6];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) fx[i] = *reinterpret_cast<const bf16x8*>(slot + kswz64((tile0 + i) * 16 + lq, lg));
+#pragma unroll
+    for (int rt = 0; rt < 6; ++rt) fw[rt] = *reinterpret_cast<const bf16x8*>(slot + kswz64(PANGU_WTOK + rt * 16 + lq, lg));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) acc[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[rt], fx[i], acc[rt][i], 0, 0, 0);
+#pragma unroll
+      for (int rt = 4; rt < 6; ++rt) acc[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[i], fw[rt], acc[rt][i], 0, 0, 0);
+    }
+  }
+
+  // ---- q fragments (registers), K image and V^T image (LDS)
+  BiasRow b0 = load_bias_row(bias_tile, tile0 * 16 + lq, lg);
+  bf16x8 qf[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    qf[i] = __builtin_bit_cast(bf16x8, u32x4{pack2(acc[0][i][0], acc[0][i][1]), pack2(acc[0][i][2], acc[0][i][3]),
+                                             pack2(acc[1][i][0], acc[1][i][1]), pack2(acc[1][i][2], acc[1][i][3])});
+    const int n = (tile0 + i) * 16 + lq;
+    *reinterpret_cast<u32x4*>(Ks + kswz(n, lg)) = u32x4{pack2(acc[2][i][0], acc[2][i][1]), pack2(acc[2][i][2], acc[2][i][3]),
+                                                        pack2(acc[3][i][0], acc[3][i][1]), pack2(acc[3][i][2], acc[3][i][3])};
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+      *reinterpret_cast<u32x2*>(Vt + (dt * 16 + lq) * VT_LD + ((tile0 + i) * 16 + 4 * lg) * 2) =
+          u32x2{pack2(acc[4 + dt][i][0], acc[4 + dt][i][1]), pack2(acc[4 + dt][i][2], acc[4 + dt][i][3])};
+  }
+
+  bool zcut = false, hcut = false;
+  unsigned long long kz_bits = 0ull, kh_bits = 0ull;
+  if (SHIFTED) {
+    const int zwin = t / g.nHw, hwin = t - zwin * g.nHw;
+    zcut = zwin == g.nZw - 1;
+    hcut = hwin == g.nHw - 1;
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kn = key_of(j, lg * 4 + r);
+        if (kn >= 72) kz_bits |= 1ull << (4 * j + r);
+        if (((kn / 12) % 6) < 3) kh_bits |= 1ull << (4 * j + r);
+      }
+  }
+  __syncthreads();
+
+  const BiasRow b1 = load_bias_row(bias_tile, (tile0 + 1) * 16 + lq, lg);
+  attn_tile<SHIFTED>(Ks, Vt, qf[0], b0, tile0 * 16 + lq, qtok[0], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
+  b0 = load_bias_row(bias_tile, (tile0 + 2) * 16 + lq, lg);
+  attn_tile<SHIFTED>(Ks, Vt, qf[1], b1, (tile0 + 1) * 16 + lq, qtok[1], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
+  attn_tile<SHIFTED>(Ks, Vt, qf[2], b0, (tile0 + 2) * 16 + lq, qtok[2], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
+}
+
 }  // namespace
 
 extern "C" int pangu_window_attn_fwd_bf16(pangu_stream_t stream, const void* qkv, const void* qkv_bias, const void* esb,
@@ -270,5 +453,42 @@ extern "C" int pangu_window_attn_fwd_bf16(pangu_stream_t stream, const void* qkv
   else
     hipLaunchKernelGGL(window_attn_bf16_kernel<false>, dim3(grid), dim3(192), 0, s, (const u16*)qkv,
                        (const u16*)qkv_bias, (const u16*)esb, (u16*)out, lse, g, C, heads, n_pairs);
+  return pangu_launch_status();
+}
+
+extern "C" int pangu_window_attn_qkv_fwd_bf16(pangu_stream_t stream, const void* x, int ldx, const void* w_qkv,
+                                              const float* b_qkv, const void* esb, void* out, float* lse, int Z, int H, int W,
+                                              int C, int heads, int shifted) {
+  if (!x || !w_qkv || !b_qkv || !esb || !out) return PANGU_E_NULL;
+  if (Z <= 0 || H <= 0 || W <= 0 || Z % PANGU_WZ || (H + PANGU_PAD_H) % PANGU_WH || W % PANGU_WW) return PANGU_E_SHAPE;
+  if (heads <= 0 || C != heads * PANGU_HEAD_DIM || (C != 192 && C != 384) || ldx < C || (ldx & 7)) return PANGU_E_SHAPE;
+  const int n_tok = Z * H * W;
+  if (!pangu_fits_u32(n_tok, ldx, 2)) return PANGU_E_RANGE;
+  const WinGeom g = make_geom(Z, H, W);
+  const int n_pairs = g.types * heads;
+  const int grid = (heads & 1) ? ((n_pairs + 7) / 8) * 8 * g.nLon : ((n_pairs / 2 + 7) / 8) * 8 * g.nLon * 2;
+  static const int ring = getenv("PANGU_ATTN_QKV_RING") ? atoi(getenv("PANGU_ATTN_QKV_RING")) : 2;      // A/B knob
+  const size_t shm = (size_t)(ring == 3 ? 3 : 2) * QK_SLOT + PANGU_WTOK * 64 + 32 * VT_LD;
+  hipStream_t s = (hipStream_t)stream;
+#define PANGU_QKV_LAUNCH(SH, CC)                                                                                          \
+  do {                                                                                                                    \
+    if (ring == 3) {                                                                                                      \
+      auto kern = window_attn_qkv_bf16_kernel<SH, CC, 3>;                                                                 \
+      PANGU_ENSURE_DYN_LDS(kern, shm);                                                                                    \
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(192), shm, s, (const u16*)x, ldx, (const u16*)w_qkv, b_qkv,               \
+                         (const u16*)esb, (u16*)out, lse, g, n_tok, heads, n_pairs);                                      \
+      break;                                                                                                              \
+    }                                                                                                                     \
+    auto kern = window_attn_qkv_bf16_kernel<SH, CC, 2>;                                                                    \
+    PANGU_ENSURE_DYN_LDS(kern, shm);                                                                                      \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(192), shm, s, (const u16*)x, ldx, (const u16*)w_qkv, b_qkv,                 \
+                       (const u16*)esb, (u16*)out, lse, g, n_tok, heads, n_pairs);                                        \
+  } while (0)
+  if (C == 192) {
+    if (shifted) PANGU_QKV_LAUNCH(true, 192); else PANGU_QKV_LAUNCH(false, 192);
+  } else {
+    if (shifted) PANGU_QKV_LAUNCH(true, 384); else PANGU_QKV_LAUNCH(false, 384);
+  }
+#undef PANGU_QKV_LAUNCH
   return pangu_launch_status();
 }

@@ -263,6 +263,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ln_residual_bf16_kernel(
   // top of iteration ch: the request group of iteration ch-2 has landed (this wave's pieces: vmcnt leaves the N newest
   // requests in flight; every wave's: barrier); the slots it re-requests now were last read in iteration ch-1
   auto sync = [&](auto n) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // no fragment read of the slots re-requested next may still be queued
     wait_vmcnt<decltype(n)::value>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");

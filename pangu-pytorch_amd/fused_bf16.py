@@ -56,6 +56,7 @@ class WeightShadow:
 
 _FUSE_LN = os.environ.get("PANGU_BF16_FUSE_LN", "1") != "0"      # A/B knob: 0 = separate GEMM + LN-residual launches
 _FUSE_LN384 = int(os.environ.get("PANGU_BF16_FUSE_LN384", "0"))   # C = 384: 0 = never, 1 = attention projection only, 2 = both
+_FUSE_QKV = os.environ.get("PANGU_BF16_FUSE_QKV", "1") != "0"    # A/B knob: 0 = QKV projection as its own GEMM launch
 _FUSE_MLP = os.environ.get("PANGU_BF16_FUSE_MLP", "1") != "0"    # A/B knob: 0 = MLP-up, MLP-down(+LN) as separate launches
 
 
@@ -74,8 +75,14 @@ def _block(blk, sh, x, Z, H, W, roll, out=None):
     fuse_proj = fuse or (ok and C == 384 and _FUSE_LN384 >= 1)
     fuse_mlp = fuse or (ok and C == 384 and _FUSE_LN384 >= 2)
     if s1 != 0.0:
-        qkv = ob.linear(x, sh.get(att.linear1.weight), att.linear1.bias)
-        o = ob.window_attention(qkv, sh.get(att.linear1.bias), sh.get(att.earth_specific_bias), Z, H, W, att.head_number, roll)
+        if _FUSE_QKV and C in (192, 384):
+            # QKV projection inside the attention kernel: the (N, 3C) qkv tensor never reaches HBM
+            o = ob.window_attention_qkv(x, sh.get(att.linear1.weight), att.linear1.bias, sh.get(att.earth_specific_bias),
+                                        Z, H, W, att.head_number, roll)
+        else:
+            qkv = ob.linear(x, sh.get(att.linear1.weight), att.linear1.bias)
+            o = ob.window_attention(qkv, sh.get(att.linear1.bias), sh.get(att.earth_specific_bias), Z, H, W,
+                                    att.head_number, roll)
         if fuse_proj:
             x1 = ob.linear_ln_residual(o, sh.get(att.linear2.weight), att.linear2.bias, x, blk.norm1.weight, blk.norm1.bias)
         else:

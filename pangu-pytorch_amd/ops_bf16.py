@@ -57,6 +57,25 @@ def window_attention(qkv, qkv_bias, esb, Z, H, W, heads, shifted, want_lse=False
     return (out, lse) if want_lse else out
 
 
+def window_attention_qkv(x, w_qkv, b_qkv, esb, Z, H, W, heads, shifted, want_lse=False):
+    """Earth-specific window attention INCLUDING the QKV projection (reference layers.py:365-415 up to linear2): x (N, C)
+    bf16 rows, w_qkv (3C, C) bf16, b_qkv (3C,) fp32, esb (types, heads, 144, 144) bf16 -> (N, C) bf16.  The qkv tensor is
+    never written."""
+    lib = _lib.load()
+    xp, ldx = _rows(x, "attn_qkv.x")
+    N, C = x.shape
+    if N != Z * H * W or tuple(w_qkv.shape) != (3 * C, C) or x.dtype != torch.bfloat16:
+        raise RuntimeError(f"window_attention_qkv: x {tuple(x.shape)} {x.dtype}, w_qkv {tuple(w_qkv.shape)}, grid {(Z, H, W)}")
+    out = torch.empty((N, C), dtype=torch.bfloat16, device=x.device)
+    lse = torch.empty((N, heads), dtype=torch.float32, device=x.device) if want_lse else None
+    Np = (Z // 2) * ((H + 5) // 6) * (W // 12) * 144
+    with _timed("attn_qkv_bf16", 4.0 * Np * 144 * C + 6.0 * Np * C * C):
+        _lib.check(lib.pangu_window_attn_qkv_fwd_bf16(_stream(), xp, ldx, _p(w_qkv, "w_qkv"), _p(b_qkv, "b_qkv", torch.float32),
+                                                      _p(esb, "esb"), out.data_ptr(), lse.data_ptr() if want_lse else None,
+                                                      Z, H, W, C, heads, int(shifted)), "window_attn_qkv_fwd_bf16")
+    return (out, lse) if want_lse else out
+
+
 def linear_ln_residual(a, weight, bias, shortcut, gamma, beta, out=None):
     """out = shortcut + LayerNorm(a @ weight^T + bias) * gamma + beta in ONE launch (N = 192 or 384; inference path)."""
     lib = _lib.load()

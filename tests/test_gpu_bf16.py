@@ -187,6 +187,50 @@ def test_window_attention_bf16(P, C, shifted):
 
 
 @pytest.mark.parametrize("C", [192, 384])
+@pytest.mark.parametrize("shifted", [False, True])
+@pytest.mark.parametrize("ring", ["2", "3"])
+def test_window_attention_qkv_fused_bf16(P, C, shifted, ring, monkeypatch):
+    """QKV projection fused into the attention kernel (csrc/attn_bf16.hip window_attn_qkv_bf16_kernel) == Linear ->
+    window attention (reference layers.py:365-415) on the same bf16-rounded operands: q, k, v are rounded to bf16 once,
+    exactly where the two-launch path rounds them; padded rows take part with q = k = v = bias (layers.py:192)."""
+    from pangu_pytorch_amd import ops_bf16 as ob
+    st = cases.STAGES[C]
+    Z, H, W, heads = st["Z"], st["H"], 24, st["heads"]
+    N = Z * H * W
+    x = synth.uniform((N, C), 35, 1.5).to(BF)
+    w = synth.uniform((3 * C, C), 36, 1.5 / C ** 0.5).to(BF)
+    b = synth.uniform((3 * C,), 37, 0.5)
+    esb = synth.uniform((1, st["types"], heads, 144, 144), 38, 0.5).to(BF)
+    qkv = (x.double() @ w.double().t() + b.double()).to(BF)                      # the rounding point of the unfused path
+    ref, ref_lse = O.window_attention_core(qkv.float()[None], b.to(BF).float(), esb.float(), Z, H, W, heads, shifted)
+    # the oracle takes the pad rows' q/k/v from the (bf16-rounded) bias, the kernel computes them as 0 @ W + b -> same value
+    got, lse = ob.window_attention_qkv(x.cuda(), w.cuda(), b.cuda(), esb[0].cuda(), Z, H, W, heads, shifted, want_lse=True) \
+        if ring == "2" else _attn_qkv_ring3(ob, x, w, b, esb, Z, H, W, heads, shifted)
+    assert rel_err(got, ref[0]) < ROUND
+    assert rel_err(lse, ref_lse[0]) < 2e-3                 # scores from bf16 q, k: same inputs, fp32 accumulation order differs
+    # and the two-launch path on the GPU agrees
+    two = ob.window_attention(ob.linear(x.cuda(), w.cuda(), b.cuda()), b.to(BF).cuda(), esb[0].cuda(), Z, H, W, heads, shifted)
+    assert rel_err(got, two) < ROUND
+
+
+def _attn_qkv_ring3(ob, x, w, b, esb, Z, H, W, heads, shifted):
+    """The ring-of-3 instantiation is chosen by an environment variable read once per process: run it in a child."""
+    import subprocess
+    import sys
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        torch.save((x, w, b, esb, Z, H, W, heads, shifted), os.path.join(d, "in.pt"))
+        code = ("import sys, torch; sys.path.insert(0, %r); from pangu_pytorch_amd import ops_bf16 as ob\n"
+                "x, w, b, esb, Z, H, W, heads, shifted = torch.load(%r)\n"
+                "o, l = ob.window_attention_qkv(x.cuda(), w.cuda(), b.cuda(), esb[0].cuda(), Z, H, W, heads, shifted, want_lse=True)\n"
+                "torch.save((o.cpu(), l.cpu()), %r)\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                          os.path.join(d, "in.pt"), os.path.join(d, "out.pt"))
+        subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, PANGU_ATTN_QKV_RING="3"))
+        o, l = torch.load(os.path.join(d, "out.pt"))
+    return o.cuda(), l.cuda()
+
+
+@pytest.mark.parametrize("C", [192, 384])
 def test_ln_residual_bf16(P, C):
     from pangu_pytorch_amd import ops_bf16 as ob
     N = 1003

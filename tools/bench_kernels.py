@@ -156,6 +156,25 @@ def attn_bf16():
             print(f"attn_bf16 C={C} shifted={int(sh)}: {ms:7.3f} ms  {fl / ms / 1e9:6.1f} TF/s  {by / ms / 1e6:7.1f} GB/s (algorithmic)")
 
 
+def attn_qkv_bf16():
+    """QKV projection fused into the attention kernel vs the two launches it replaces."""
+    from pangu_pytorch_amd import ops_bf16 as ob
+    bf = torch.bfloat16
+    for C, Z, H, W, heads, types in ((192, 8, 181, 360, 6, 124), (384, 8, 91, 180, 12, 64)):
+        N = Z * H * W
+        x = torch.randn(N, C, device="cuda").to(bf)
+        w = (torch.randn(3 * C, C, device="cuda") / C ** 0.5).to(bf)
+        b = torch.randn(3 * C, device="cuda")
+        bb = b.to(bf)
+        esb = (torch.randn(types, heads, 144, 144, device="cuda") * 0.1).to(bf)
+        Np = (Z // 2) * ((H + 5) // 6) * (W // 12) * 144
+        fl = 4.0 * Np * 144 * C + 6.0 * Np * C * C
+        for sh in (False, True):
+            ms = timeit(lambda: ob.window_attention_qkv(x, w, b, esb, Z, H, W, heads, sh))
+            ms2 = timeit(lambda: ob.window_attention(ob.linear(x, w, b), bb, esb, Z, H, W, heads, sh))
+            print(f"attn_qkv_bf16 C={C} shifted={int(sh)}: fused {ms:7.3f} ms {fl / ms / 1e9:6.1f} TF/s   | qkv GEMM + attention {ms2:7.3f} ms")
+
+
 def attn_bwd():
     """backward of the window attention, both dtypes: 5 useful GEMMs (dP, dV, dQ, dK + recomputed S) = 10*Np*144*C flop"""
     from pangu_pytorch_amd import ops_bf16 as ob
@@ -209,5 +228,5 @@ def rows():
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
     {"gemm": lambda: gemm("--lib-compare" in sys.argv), "attn": attn, "attn_bwd": attn_bwd, "rows": rows,
-     "gemm_bf16": lambda: gemm_bf16("--lib-compare" in sys.argv), "attn_bf16": attn_bf16, "gemm_ln_bf16": gemm_ln_bf16, "mlp_fused": mlp_fused, "gemm_ln": gemm_ln,
+     "gemm_bf16": lambda: gemm_bf16("--lib-compare" in sys.argv), "attn_bf16": attn_bf16, "gemm_ln_bf16": gemm_ln_bf16, "mlp_fused": mlp_fused, "attn_qkv_bf16": attn_qkv_bf16, "gemm_ln": gemm_ln,
      "wgrad_bf16": lambda: wgrad(True), "wgrad": lambda: wgrad(False)}[what]()

@@ -1,10 +1,8 @@
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-rm -rf gpurun_out/pmc_mlp2; mkdir -p gpurun_out/pmc_mlp2
-O=$GRAFT_REPO_ROOT/gpurun_out/pmc_mlp2
-timeout 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d $O/p1 -- python3 tools/pmc_mlp_probe.py > $O/p1.log 2>&1
-timeout 120 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d $O/p2 -- python3 tools/pmc_mlp_probe.py > $O/p2.log 2>&1
-timeout 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $O/p3 -- python3 tools/pmc_mlp_probe.py > $O/p3.log 2>&1
-timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p4 -- python3 tools/pmc_mlp_probe.py > $O/p4.log 2>&1
-python3 tools/pmc_summary.py $O $O/summary.md > /dev/null 2>&1
-ls $O
+mkdir -p gpurun_out
+(timeout 900 python -m pytest tests/test_gpu_bf16.py -k "qkv_fused or mlp_ln_residual_fused" -x -q 2>&1 | tail -5) > gpurun_out/r2_s5_test.log 2>&1
+(timeout 300 python tools/bench_kernels.py attn_qkv_bf16 2>&1 | tail -4) > gpurun_out/r2_s5_bench.log 2>&1
+(PANGU_ATTN_QKV_RING=3 timeout 300 python tools/bench_kernels.py attn_qkv_bf16 2>&1 | tail -4) >> gpurun_out/r2_s5_bench.log 2>&1
+(timeout 300 python tools/bench_kernels.py mlp_fused 2>&1 | tail -2) >> gpurun_out/r2_s5_bench.log 2>&1
+(timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps(d['bf16_forward']))") > gpurun_out/r2_s5_fwd.log 2>&1
+cat gpurun_out/r2_s5_test.log gpurun_out/r2_s5_bench.log gpurun_out/r2_s5_fwd.log
