@@ -1,6 +1,6 @@
 """Generate golden vectors by running the REFERENCE itself (build container only; needs /root/reference).
 
-TEST INFRASTRUCTURE. Usage:  python oracle/gen_golden.py [index] [blocks] [layers] [model] [model_bwd] [model_bwd_smooth] [extras] [rollout2]
+TEST INFRASTRUCTURE. Usage:  python oracle/gen_golden.py [index] [blocks] [layers] [model] [model_bwd] [model_bwd_smooth] [extras] [rollout2] [keys_table]
 Outputs small fixtures (fingerprints: samples + sums, index tensors, packed masks) under tests/golden/.
 Inputs and parameters are closed-form (oracle/synth.py), so tests regenerate them bit-identically.
 """
@@ -241,6 +241,18 @@ def gen_rollout(L, M, steps=2):
     save("rollout2.npz", d)
 
 
+def gen_keys_table(L, M):
+    """The reference's torch_name -> onnx_name table (keys_all.csv, the lookup of models/onnx2torch.py:23-36) as a data
+    fixture: 223 name pairs, no weights."""
+    import csv
+    with open(os.path.join(ref_import.REF_ROOT, "keys_all.csv")) as f:
+        table = {r["torch_name"]: r["onnx_name"] for r in csv.DictReader(f) if r["torch_name"]}
+    assert len(table) == 223 and all(isinstance(v, str) and v for v in table.values())
+    with open(os.path.join(OUT, "keys_table.json"), "w") as f:
+        json.dump(table, f, indent=0)
+    print("wrote keys_table.json", len(table))
+
+
 def gen_model(L, M, backward):
     model = build_model(M).eval()
     inp, inp_s, stats, maps, const_h = cases.model_inputs()
@@ -289,5 +301,7 @@ if __name__ == "__main__":
         gen_extras(L, M)
     if "model_bwd_smooth" in what:
         gen_model_smooth(L, M)
+    if "keys_table" in what:
+        gen_keys_table(L, M)
     if "rollout2" in what:
         gen_rollout(L, M, steps=2)

@@ -13,6 +13,11 @@ import synth
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
 ROUND = 1.0 / 128        # bf16 has 8 significant bits: one output rounding <= 2^-8 relative, x2 margin
+# bf16 whole-model gradients vs the REFERENCE's fp32 autograd, worst of the 223 tensors, measured on MI355X with the goldens'
+# O(1)-activation synthetic weights (not contractive: 16 blocks of bf16 forward drift feed the backward): gradient mass
+# 2.2e-2 (median 2.1e-3), rel-L2 over a tensor's 256 samples 0.26 (deep Earth-specific bias tables; median 0.11)
+BF16_GRAD_SAMPLE_TOL = 0.35
+BF16_GRAD_MASS_TOL = 3e-2
 
 
 @pytest.fixture(scope="module")
@@ -287,8 +292,8 @@ def test_full_model_bf16_drift(P, golden_dir):
     l2 = ((out - ref).double().norm() / ref.double().norm()).item()
     l2s = ((out_s - ref_s).double().norm() / ref_s.double().norm()).item()
     print(f"bf16 vs fp32 rel-L2 drift: upper {l2:.3e} surface {l2s:.3e}")
-    assert l2 < 5e-2 and l2s < 5e-2
-    assert cases.compare_summary(out, g, "model.out", 1.0) < 0.2
+    assert l2 < 3e-2 and l2s < 3e-2                         # measured 0.7-1.5e-2 (O(1)-activation synthetic weights)
+    assert cases.compare_summary(out, g, "model.out", 1.0) < 0.1     # worst fingerprint element vs the REFERENCE forward
 
 
 # ------------------------------------------------------------------------------------------------ bf16 backward
@@ -420,6 +425,36 @@ def test_full_training_step_bf16(P):
     print("bf16 training step: loss fp32 %.6f bf16 %.6f; worst grad rel-L2:" % (l32.item(), lb.item()), errs[:3])
     med = errs[len(errs) // 2][0]
     assert med < 0.1, med
+
+
+def test_full_backward_smooth_bf16_vs_reference(P, golden_dir):
+    """bf16 whole-model forward + backward under the smooth loss sum(out * cotangent) / numel against the REFERENCE's fp32
+    autograd (tests/golden/model_bwd_smooth.npz): every one of the 223 gradient tensors, WORST tensor bounded -- gradient
+    mass (sum |g|) and the rel-L2 error over the 256 stored samples of each tensor."""
+    g = np.load(os.path.join(golden_dir, "model_bwd_smooth.npz"))
+    m = P.PanguModel(device="cuda").cuda().eval()
+    m.load_state_dict(synth.fill_state_dict(cases.model_param_shapes(), "cuda"))
+    m.set_compute_dtype(BF)
+    inp, inp_s, stats, maps, const_h = cases.model_inputs("cuda")
+    out, out_s = m(inp, inp_s, stats, maps, const_h)
+    loss = ((out * cases.cotangent("model_out", out.shape, "cuda")).sum() +
+            (out_s * cases.cotangent("model_out_s", out_s.shape, "cuda")).sum()) / out.numel()
+    loss.backward()
+    l2s, masses = [], []
+    for k, p in m.named_parameters():
+        flat = p.grad.detach().float().flatten()
+        assert torch.isfinite(flat).all(), k
+        pos = synth.sample_positions(flat.numel(), cases.NSAMP, synth.name_seed("pos_model.d_" + k), device=flat.device)[:256]
+        gs = torch.as_tensor(g[f"model.d_{k}.samples"]).double()
+        gabs = float(g[f"model.d_{k}.abs_sum"][0])
+        l2s.append((((flat[pos].cpu().double() - gs).norm() / gs.norm().clamp_min(1e-30)).item(), k))
+        masses.append((abs(flat.double().abs().sum().item() - gabs) / gabs, k))
+    l2s.sort(reverse=True)
+    masses.sort(reverse=True)
+    print("BF16GRAD worst sample rel-L2:", l2s[:4], "median", l2s[len(l2s) // 2][0])
+    print("BF16GRAD worst mass:", masses[:4], "median", masses[len(masses) // 2][0])
+    assert l2s[0][0] < BF16_GRAD_SAMPLE_TOL, l2s[0]
+    assert masses[0][0] < BF16_GRAD_MASS_TOL, masses[0]
 
 
 @pytest.mark.parametrize("s1,s2", [(0.0, 1.25), (1.25, 0.0), (1.25, 1.25), (1.0, 1.0)])

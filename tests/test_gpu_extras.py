@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 
+import cases
 import pangu_oracle as O
 import synth
 
@@ -46,3 +47,30 @@ def test_device_prefetcher(P):
         assert torch.equal(c.cpu(), batches[i][2].flip(-3))
     plain = list(P.data.DevicePrefetcher(batches, "cuda"))
     assert torch.equal(plain[3][0].cpu(), batches[3][0])
+
+
+def test_onnx_route_and_checkpoint_forward_golden(golden_dir, tmp_path):
+    """Weight import end to end on the GPU: initialisers in the ONNX layout through the 223-row key table
+    (weights.load_onnx_initializers, reference models/onnx2torch.py:23-52), then saved / re-loaded as the
+    {'model': state_dict} checkpoint of reference finetune_fully.py:115-116 (weights.load_checkpoint), then the forward
+    == the reference's forward on those weights (tests/golden/model_fwd.npz) within 1e-3."""
+    import json
+    import os
+    import numpy as np
+    import pangu_pytorch_amd as P
+    from pangu_pytorch_amd import weights as Wt
+    table = json.load(open(os.path.join(golden_dir, "keys_table.json")))
+    want = synth.fill_state_dict(cases.model_param_shapes())
+    onnx_weights = {table[k]: (v.t().contiguous() if v.dim() == 2 else v).numpy() for k, v in want.items()}
+    m = P.PanguModel(device="cuda").cuda().eval()
+    assert Wt.load_onnx_initializers(m, onnx_weights, table) == []
+    path = tmp_path / "onnx2torch_ckpt.pth"
+    torch.save({"model": m.state_dict(), "epoch": 0}, path)
+    m2 = P.PanguModel(device="cuda").cuda().eval()
+    Wt.load_checkpoint(m2, str(path), map_location="cuda")
+    g = np.load(os.path.join(golden_dir, "model_fwd.npz"))
+    inp, inp_s, stats, maps, const_h = cases.model_inputs("cuda")
+    with torch.no_grad():
+        out, out_s = m2(inp, inp_s, stats, maps, const_h)
+    assert cases.compare_summary(out, g, "model.out", 1e-3) < 1e-3
+    assert cases.compare_summary(out_s, g, "model.out_surface", 1e-3) < 1e-3

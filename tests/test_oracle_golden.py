@@ -97,3 +97,71 @@ def test_state_dict_contract(golden_dir):
     mine = cases.model_param_shapes()
     assert len(mine) == 223 and ks["n_params"] == 276659936
     assert {k: list(v) for k, v in mine.items()} == ks["state_dict"]
+
+
+def _params(prefixes):
+    return {k: synth.synth_param(k, sh) for k, sh in cases.model_param_shapes().items() if k.startswith(prefixes)}
+
+
+def test_fullres_layers_forward_backward(golden_dir):
+    """The oracle's patch_embed / down_sample / up_sample / patch_recover (the functions the GPU tests and smoke() lean on)
+    against the REFERENCE's PatchEmbedding_pretrain / DownSample / UpSample / PatchRecovery_pretrain at full resolution
+    (reference layers.py:12-93, :423-499, :501-545; tests/golden/layers_fullres.npz), forward and every parameter /
+    input gradient."""
+    g = _load(golden_dir, "layers_fullres.npz")
+    T = 5 * FP_TOL
+    # ---- patch embedding
+    p = {k: v.requires_grad_(True) for k, v in _params(("_input_layer.",)).items()}
+    inp, inp_s, stats, maps, const_h = cases.model_inputs()
+    x0 = O.patch_embed(p, inp, inp_s, stats, maps, const_h)
+    assert cases.compare_summary(x0, g, "embed.out", T) < T
+    (x0 * cases.cotangent("embed", x0.shape)).sum().backward()
+    for k in p:
+        assert cases.compare_summary(p[k].grad, g, "embed.d_" + k[len("_input_layer."):], T) < 4 * T, k
+    del x0, inp, inp_s, maps, const_h
+    # ---- down-sample
+    p = {k: v.requires_grad_(True) for k, v in _params(("downsample.",)).items()}
+    xin = synth.uniform((1, 8 * 181 * 360, 192), synth.name_seed("down_in")).requires_grad_(True)
+    y = O.down_sample(p, xin, 8, 181, 360)
+    assert cases.compare_summary(y, g, "down.out", T) < T
+    (y * cases.cotangent("down", y.shape)).sum().backward()
+    assert cases.compare_summary(xin.grad, g, "down.dx", T) < 4 * T
+    for k in p:
+        assert cases.compare_summary(p[k].grad, g, "down.d_" + k[len("downsample."):], T) < 4 * T, k
+    # ---- up-sample
+    p = {k: v.requires_grad_(True) for k, v in _params(("upsample.",)).items()}
+    xin = synth.uniform((1, 8 * 91 * 180, 384), synth.name_seed("up_in")).requires_grad_(True)
+    y = O.up_sample(p, xin, 8, 91, 180, 181)
+    assert cases.compare_summary(y, g, "up.out", T) < T
+    (y * cases.cotangent("up", y.shape)).sum().backward()
+    assert cases.compare_summary(xin.grad, g, "up.dx", T) < 4 * T
+    for k in p:
+        assert cases.compare_summary(p[k].grad, g, "up.d_" + k[len("upsample."):], T) < 4 * T, k
+    # ---- patch recovery
+    p = {k: v.requires_grad_(True) for k, v in _params(("_output_layer.",)).items()}
+    xin = synth.uniform((1, 8 * 181 * 360, 384), synth.name_seed("recover_in")).requires_grad_(True)
+    o, os_ = O.patch_recover(p, xin, 8, 181, 360)
+    assert cases.compare_summary(o, g, "recover.out", T) < T
+    assert cases.compare_summary(os_, g, "recover.out_surface", T) < T
+    ((o * cases.cotangent("recover", o.shape)).sum() + (os_ * cases.cotangent("recover_s", os_.shape)).sum()).backward()
+    assert cases.compare_summary(xin.grad, g, "recover.dx", T) < 4 * T
+    for k in p:
+        assert cases.compare_summary(p[k].grad, g, "recover.d_" + k[len("_output_layer."):], T) < 4 * T, k
+
+
+@pytest.mark.skipif(os.environ.get("PANGU_SKIP_SLOW") == "1", reason="whole-model CPU forward (~90 s on 8 cores)")
+def test_oracle_forward_and_loss_vs_reference(golden_dir):
+    """O.forward / O.train_loss against the reference's whole forward and its training loss on the same synthetic sample
+    (tests/golden/model_fwd.npz, model_bwd.npz['model.loss'])."""
+    g = _load(golden_dir, "model_fwd.npz")
+    p = {k: synth.synth_param(k, sh) for k, sh in cases.model_param_shapes().items()}
+    inp, inp_s, stats, maps, const_h = cases.model_inputs()
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    with torch.no_grad():
+        out, out_s = O.forward(p, inp, inp_s, stats, maps, const_h)
+    assert cases.compare_summary(out, g, "model.out", 1e-4) < 1e-4
+    assert cases.compare_summary(out_s, g, "model.out_surface", 1e-4) < 1e-4
+    gb = _load(golden_dir, "model_bwd.npz")
+    tgt, tgt_s = cases.model_targets()
+    loss = O.train_loss(out, out_s, tgt, tgt_s).item()
+    assert abs(loss - float(gb["model.loss"][0])) < 1e-5 * float(gb["model.loss"][0])

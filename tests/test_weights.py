@@ -66,3 +66,22 @@ def test_load_onnx_initializers_semantics():
     with pytest.raises(ValueError):
         Wt.load_onnx_initializers(m, {**ow, "onnx::MatMul_1": w_onnx.T.copy()}, table)
     assert Wt.load_onnx_initializers(m, ow, {"linear.weight": "onnx::MatMul_1"}) == ["norm.weight", "norm.bias"]
+
+
+def test_load_onnx_initializers_full_key_table(golden_dir):
+    """All 223 rows of the reference's torch_name -> onnx_name table (keys_all.csv as tests/golden/keys_table.json):
+    initialisers named and laid out the ONNX way (2-D MatMul weights (in, out), everything else as stored) land in the
+    right parameters of the whole model (reference models/onnx2torch.py:23-52)."""
+    import json
+    table = json.load(open(os.path.join(golden_dir, "keys_table.json")))
+    shapes = cases.model_param_shapes()
+    assert set(table) == set(shapes) and len(set(table.values())) == 223
+    m = P.PanguModel(depths=[2, 6, 6, 2])
+    want = synth.fill_state_dict(shapes)
+    onnx_weights = {table[k]: (v.t().contiguous() if v.dim() == 2 else v).numpy() for k, v in want.items()}
+    assert sum(1 for k, v in want.items() if v.dim() == 2) == 67        # the transposed ones: every nn.Linear weight
+    missing = Wt.load_onnx_initializers(m, onnx_weights, table, freeze=True)
+    assert missing == []
+    for k, p in m.named_parameters():
+        assert torch.equal(p, want[k]), k
+        assert not p.requires_grad
