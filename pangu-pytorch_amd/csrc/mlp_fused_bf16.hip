@@ -7,17 +7,21 @@
 // 1.6 GB of the 3.6 GB a C = 192 block moves in bf16), and the LayerNorm + residual run on the accumulators.
 //
 // Structure (MI355X: 160 KB LDS, 512 registers per lane at one wave per SIMD):
-//  * a workgroup = 4 waves owns 64*T consecutive tokens, wave w the 16*T tokens w*16T .. (T token tiles of 16);
-//    the wave's activations x[16T][C] are loaded ONCE, straight from global memory in MFMA-fragment shape, and stay in
-//    registers (C/32 * T fragments) for the whole tile -- they are the B operand of the first product;
-//  * both products are computed TRANSPOSED with v_mfma_f32_16x16x32_bf16, weights as the A operand:
+//  * a workgroup = 4 waves owns 128*T consecutive tokens, wave w the 32*T tokens w*32T .. (T token tiles of 32);
+//    the wave's activations x[32T][C] are loaded ONCE, straight from global memory in MFMA-fragment shape, and stay in
+//    registers (C/16 * T fragments) for the whole tile -- they are the B operand of the first product;
+//  * both products are computed TRANSPOSED with v_mfma_f32_32x32x16_bf16, weights as the A operand:
 //        H^T[hidden][token] = W1[hidden][:] . x^T          (K = C)
-//        Y^T[c][token]     += W2[c][hidden chunk] . GELU(H^T)[hidden chunk][token]     (K = 32 per chunk)
+//        Y^T[c][token]     += W2[c][hidden chunk] . GELU(H^T)[hidden chunk][token]     (K = 32 per chunk = 2 k-steps)
 //    so the accumulator of the first product (hidden on the register index, token on the lane) IS the B operand of the
-//    second one after GELU + bf16 packing (the bias is the accumulator's initial value): two 16-row hidden tiles give
-//    each lane the eight k values {4g..4g+3} u {16+4g..16+4g+3} of a 32-deep k-step; the W2 fragment is stored in that
-//    k order by the host-side packing, so nothing crosses lanes and nothing goes through LDS between the two products;
-//  * Y^T (C x 16T per wave, fp32) stays in 4*(C/16)*T accumulator registers over all hidden chunks;
+//    second one after GELU + bf16 packing (the bias is the accumulator's initial value): registers 8s..8s+7 are k-step s,
+//    element j of lane half h being hidden row 16s + 8(j>>2) + 4h + (j&3); the W2 fragment is stored in that k order by
+//    the host-side packing, so nothing crosses lanes and nothing goes through LDS between the two products.
+//    The 32x32x16 shape (32 matrix cycles per instruction) is what makes a one-wave-per-SIMD kernel feasible: measured
+//    on the 16x16x32 version of this kernel (PMC, gpurun_out/pmc_mlp2), every instruction of the single wave costs
+//    >= 4 issue cycles and only 8 of a 16-cycle MFMA's cycles are free for others -- with 3.6 other instructions per
+//    MFMA it was issue-bound at 0.39 MFMA-busy; the same work in half as many MFMAs leaves 24 free cycles each;
+//  * Y^T (C x 32T per wave, fp32) stays in 16*(C/32)*T accumulator registers over all hidden chunks;
 //  * the weights stream L2 -> LDS by LDS-DMA in chunks of 32 hidden units, W1 rows and W2 columns as two streams with
 //    a ring of 3 slots each (the host packs both contiguously, layout below), one raw s_barrier per chunk, counted
 //    vmcnt (two chunks ahead); every fragment read is a conflict-free ds_read_b128 feeding T MFMAs;
@@ -26,14 +30,14 @@
 //    the FIRST product of chunk i, and spreads the GELU + pack of chunk i-1 and the LDS-DMA requests of chunks i+2 / i
 //    between the MFMAs of both (step boundaries pinned with sched_barrier, MFMA : VALU interleave inside a step with
 //    sched_group_barrier);
-//  * epilogue per 16-token tile: shortcut rows staged into a per-wave LDS patch (coalesced 16-B loads), LayerNorm
-//    statistics in fp32 over the lane's 4*C/16 values + two cross-lane adds, normalise / gamma / beta / scale / residual
+//  * epilogue per 32-token tile: shortcut rows staged into a per-wave LDS patch (coalesced 16-B loads), LayerNorm
+//    statistics in fp32 over the lane's 16*C/32 values + one cross-lane add, normalise / gamma / beta / scale / residual
 //    in the MFMA layout against the patch, rows read back and stored as whole 16-B segments.
 //
 // Packed weight image (u16 elements) [2][4C/32][32*C]: plane 0 = W1 stream, plane 1 = W2 stream, chunk ch each:
 //   W1 chunk: row hr = 0..31 (hidden 32ch+hr), 16-B chunk position p = 0..C/8-1 holds the eight K values
-//             8q..8q+7 of that row with q = p ^ (hr & SW), SW = 15 (C = 384) / 7 (C = 192)   (bank swizzle)
-//   W2 chunk: plane g = 0..3, row c = 0..C-1, 8 elements j: W2[c][32ch + (j<4 ? 4g+j : 16+4g+j-4)]
+//             8q..8q+7 of that row with q = p ^ f(hr), f = hr & 15 (C = 384) / (hr >> 1) & 7 (C = 192)   (bank swizzle)
+//   W2 chunk: [s = 0,1][h = 0,1][row c = 0..C-1][8 elements j]: W2[c][32ch + 16s + 8(j>>2) + 4h + (j&3)]
 #include "common.h"
 #include <type_traits>
 
@@ -50,13 +54,13 @@ constexpr float LN_EPS = 1e-5f;
 #define PANGU_MLP_ABLATE 0      // timing only: 1 no in-loop weight requests, 2 no GELU, 4 / 8 no first / second product
 #endif
 #ifndef PANGU_MLP_PD1
-#define PANGU_MLP_PD1 2         // fragment-read distance (k-steps ahead of the MFMAs), first product
+#define PANGU_MLP_PD1 3         // fragment-read distance (k-steps ahead of the MFMAs), first product
 #endif
 #ifndef PANGU_MLP_PD2
 #define PANGU_MLP_PD2 4         // the same (row tiles ahead), second product
 #endif
 #ifndef PANGU_MLP_IGLP
-#define PANGU_MLP_IGLP 3        // VALU instructions placed behind each MFMA of a step (0 = leave it to the scheduler)
+#define PANGU_MLP_IGLP 4        // VALU instructions placed behind each MFMA of a step (0 = leave it to the scheduler)
 #endif
 constexpr int ABL = PANGU_MLP_ABLATE;
 constexpr int PD1 = PANGU_MLP_PD1, PD2 = PANGU_MLP_PD2, IGLP = PANGU_MLP_IGLP;
@@ -78,6 +82,20 @@ __device__ __forceinline__ float gelu1(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+#ifdef PANGU_MLP_STAMP
+// Diagnostic build only (tools/ablate_mlp.py): where a steady-state iteration spends its cycles.  Sums over all waves of
+// s_memtime differences: [0] sync (wait + barrier), [1] second product phase, [2] first product phase, [3] iterations,
+// [4] whole kernel per wave, [5] waves.
+__device__ unsigned long long g_stamp[8];
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#endif
+
 template <bool B>
 using Flag = std::integral_constant<bool, B>;
 template <int N>
@@ -88,44 +106,50 @@ __global__ __launch_bounds__(256, 1) void mlp_ln_residual_bf16_kernel(
     const u16* __restrict__ X, int ldx, const u16* __restrict__ Wimg, const float* __restrict__ b1,
     const float* __restrict__ b2, const float* __restrict__ gamma, const float* __restrict__ beta,
     u16* __restrict__ Out, int ldo, int M, float scale) {
-  constexpr int HID = 4 * C, NCH = HID / 32, KS = C / 32, RT = C / 16;
+  constexpr int HID = 4 * C, NCH = HID / 32, KS = C / 16, RT = C / 32;
   constexpr int WB = 64 * C;                  // bytes of one W1 (or W2) chunk
   constexpr int NS = 3;                       // ring slots per stream
   constexpr int LPS = WB / 4096;              // LDS-DMA instructions per wave, chunk and stream (1 KB each)
   constexpr int LPW = 2 * LPS;                // ... per wave and iteration
-  constexpr int SW = C == 384 ? 15 : 7;
   constexpr int PLD = 2 * C + 16;             // bytes per row of an epilogue patch
   constexpr int CPR = C / 8;                  // 16-B chunks per activation row
-  constexpr int E = 8 * T;                    // GELU elements per lane and chunk: [tt][ht][r]
-  static_assert(KS % LPS == 0 && RT % LPS == 0 && NCH > 4, "shape");
+  constexpr int E = 16 * T;                   // GELU elements per lane and chunk: [tt][register]
+  static_assert(KS % LPS == 0 && (2 * RT) % LPS == 0 && NCH > 4, "shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const ring1 = smem;                      // W1 stream, NS slots
   unsigned char* const ring2 = smem + NS * WB;            // W2 stream, NS slots
   float* const b1s = reinterpret_cast<float*>(smem + 2 * NS * WB);
+  float* const eps = b1s + HID;                           // b2 | gamma | beta (3 x C floats) for the epilogue
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lq = lane & 15, lg = lane >> 4;
-  const int m0 = blockIdx.x * (64 * T) + wave * (16 * T);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * (128 * T) + wave * (32 * T);
+  const int fsw = C == 384 ? (lr & 15) : ((lr >> 1) & 7);      // this lane's W1 chunk swizzle
 
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<u16*>(X), 0, (int)(((size_t)(M - 1) * ldx + C) * sizeof(u16)), 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<u16*>(Wimg), 0, 2 * NCH * WB, 0x00020000);
 
-  // ---- activations of this wave: fragment (ks, tt) = x[m0 + 16tt + lq][32ks + 8lg .. +7]  (rows >= M read as zeros)
+  // ---- activations of this wave: fragment (ks, tt) = x[m0 + 32tt + lr][16ks + 8lh .. +7]  (rows >= M read as zeros)
   bf16x8 xf[KS][T];
 #pragma unroll
   for (int tt = 0; tt < T; ++tt) {
-    const unsigned row = (unsigned)(m0 + 16 * tt + lq);
+    const unsigned row = (unsigned)(m0 + 32 * tt + lr);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
       xf[ks][tt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                                                  x_rsrc, (int)((row * (unsigned)ldx + 32 * ks + 8 * lg) * 2u), 0, 0));
+                                                  x_rsrc, (int)((row * (unsigned)ldx + 16 * ks + 8 * lh) * 2u), 0, 0));
   }
-  // ---- b1 -> LDS (fp32)
+  // ---- b1 and the epilogue's per-channel vectors -> LDS (fp32): as global loads in the epilogue (144 per lane, each
+  // waited for at its use) they cost a quarter of the kernel
   for (int i = tid; i < HID / 4; i += 256)
     reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(b1)[i];
+  for (int i = tid; i < 3 * C / 4; i += 256) {
+    const int which = i / (C / 4), j = i - which * (C / 4);
+    reinterpret_cast<f32x4*>(eps)[i] = reinterpret_cast<const f32x4*>(which == 0 ? b2 : which == 1 ? gamma : beta)[j];
+  }
 
   // piece i (0 .. LPS-1) of this wave for chunk ch of stream st (0 = W1, 1 = W2) -> ring slot `slot` of that stream
   auto issue_piece = [&](int st, int ch, int slot, int i) {
@@ -134,14 +158,21 @@ __global__ __launch_bounds__(256, 1) void mlp_ln_residual_bf16_kernel(
     __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, dst, 16, lane * 16, (st * NCH + ch) * WB + q * 1024, 0, 0);
   };
 
-  f32x4 yacc[RT][T];
+#ifdef PANGU_MLP_STAMP
+  unsigned long long st_sync = 0, st_b = 0, st_all = 0, st_n = 0, st_last = 0;
+  const unsigned long long st_begin = stamp();
+#endif
+  f32x16 yacc[RT][T];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-    for (int tt = 0; tt < T; ++tt) yacc[rt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 hacc[2][T];          // first product of the current chunk (bias included)
-  f32x4 hg[2][T];            // first product of the previous chunk, GELU applied element by element during this iteration
-  bf16x8 hf[T];              // packed GELU output of the chunk before that: B operand of the second product
+    for (int tt = 0; tt < T; ++tt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) yacc[rt][tt][i] = 0.f;
+  f32x16 hacc[T];            // first product of the current chunk (bias included)
+  float hg[T][16];           // first product of the previous chunk, GELU applied stage by stage during this iteration
+  bf16x8 hf[2][T];           // packed GELU output of the chunk before that: B operand (k-step s) of the second product
+  float gt[16 * T];          // GELU temporaries, one per element
 
   // One iteration: G2 = second product of chunk ch-2 (operand hf), GE = GELU of chunk ch-1 (hg), G1 = first product of
   // chunk ch (-> hacc); I1 / I2: request W1 chunk ch+2 / W2 chunk ch.  All flags are compile-time (peeled prologue /
@@ -152,34 +183,50 @@ __global__ __launch_bounds__(256, 1) void mlp_ln_residual_bf16_kernel(
     const int a1 = a + 1 >= NS ? a + 1 - NS : a + 1, a2 = a + 2 >= NS ? a + 2 - NS : a + 2;
     const unsigned char* w1 = ring1 + a * WB;              // W1 chunk ch
     const unsigned char* w2 = ring2 + a1 * WB;             // W2 chunk ch-2  ((ch-2) % 3 == (ch+1) % 3)
-    // GELU element e of hg in the order [tt][ht][r]: the first half is done beside the second product, the rest beside
-    // the first product
-    auto gelu_elems = [&](int e0, int e1) {
+    // GELU of hg, STAGE-major: op n = stage * E + element, stages t = x x; w = fma(t, c1, c0); z = x w; e = exp2(z);
+    // d = 1 + e; r = rcp(d); x r.  Consecutive ops belong to different elements and an element's next stage comes E ops
+    // (several MFMA steps) later: with one wave per SIMD a dependent VALU chain issued back to back stalls on every
+    // result (that was 25 % of the wave's cycles, SQ_WAIT_INST_ANY, when each element's seven ops ran in a row).
+    constexpr int NOPS = 7 * E, NSTEPS = 2 * RT + KS;
+    auto gelu_ops = [&](int n0, int n1) {
 #pragma unroll
-      for (int e = e0; e < e1; ++e) {
-        const int tt = e >> 3, ht = (e >> 2) & 1, r = e & 3;
-        if (!(ABL & 2)) hg[ht][tt][r] = gelu1(hg[ht][tt][r]);
+      for (int n = n0; n < n1; ++n) {
+        const int st = n / E, e = n % E;
+        if (ABL & 2) continue;
+        float& x = hg[e >> 4][e & 15];
+        float& t = gt[e];
+        if (st == 0) t = x * x;
+        else if (st == 1) t = fmaf(t, -0.06940179f * 1.4426950408889634f, -1.60031416f * 1.4426950408889634f);
+        else if (st == 2) t = x * t;
+        else if (st == 3) t = __builtin_amdgcn_exp2f(t);
+        else if (st == 4) t = 1.0f + t;
+        else if (st == 5) t = __builtin_amdgcn_rcpf(t);
+        else x = x * t;
       }
     };
-    // ---- second product of chunk ch-2: RT steps of T MFMAs, fragment reads PD2 steps ahead
+    auto gelu_step = [&](int g) { gelu_ops(NOPS * g / NSTEPS, NOPS * (g + 1) / NSTEPS); };
+    // ---- second product of chunk ch-2: 2 RT steps (row tile, k-step) of T MFMAs, fragment reads PD2 steps ahead
     if constexpr (G2) {
-      auto rd = [&](int rt) { return *reinterpret_cast<const bf16x8*>(w2 + lg * (16 * C) + (16 * rt + lq) * 16); };
-      bf16x8 fa[RT];
+      constexpr int NSTEP = 2 * RT;
+      auto rd = [&](int st) {     // step st = 2 rt + s
+        return *reinterpret_cast<const bf16x8*>(w2 + (((st & 1) * 2 + lh) * C + 32 * (st >> 1) + lr) * 16);
+      };
+      bf16x8 fa[NSTEP];
 #pragma unroll
-      for (int rt = 0; rt < PD2 && rt < RT; ++rt) fa[rt] = rd(rt);
+      for (int st = 0; st < PD2 && st < NSTEP; ++st) fa[st] = rd(st);
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        if (rt + PD2 < RT) fa[rt + PD2] = rd(rt + PD2);
+      for (int st = 0; st < NSTEP; ++st) {
+        if (st + PD2 < NSTEP) fa[st + PD2] = rd(st + PD2);
         __builtin_amdgcn_sched_barrier(0);
         if (!(ABL & 8)) {
 #pragma unroll
           for (int tt = 0; tt < T; ++tt)
-            yacc[rt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[rt], hf[tt], yacc[rt][tt], 0, 0, 0);
+            yacc[st >> 1][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st], hf[st & 1][tt], yacc[st >> 1][tt], 0, 0, 0);
         } else {
-          asm volatile("" ::"v"(fa[rt]), "v"(hf[0]));
+          asm volatile("" ::"v"(fa[st]), "v"(hf[0][0]));
         }
-        if constexpr (GE) gelu_elems((E / 2) * rt / RT, (E / 2) * (rt + 1) / RT);
-        if (I2 && rt % (RT / LPS) == 0) issue_piece(1, ch, a, rt / (RT / LPS));
+        if constexpr (GE) gelu_step(st);
+        if (I2 && st % (NSTEP / LPS) == 0) issue_piece(1, ch, a, st / (NSTEP / LPS));
         if (IGLP && GE) {
 #pragma unroll
           for (int i = 0; i < T; ++i) {
@@ -190,53 +237,49 @@ __global__ __launch_bounds__(256, 1) void mlp_ln_residual_bf16_kernel(
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
-      if constexpr (GE) gelu_elems(0, E / 2);
+      if constexpr (GE) gelu_ops(0, NOPS * (2 * RT) / NSTEPS);
       if (I2) {
 #pragma unroll
         for (int i = 0; i < LPS; ++i) issue_piece(1, ch, a, i);
       }
     }
-    // ---- first product of chunk ch: KS steps of 2T MFMAs, fragment reads PD1 steps ahead; accumulators start from the
-    // bias of this lane's hidden rows 4lg .. 4lg+3 of both 16-row tiles
+#ifdef PANGU_MLP_STAMP
+    const unsigned long long t_mid = stamp();
+    if (G2 && G1) st_b += t_mid - st_last;
+#endif
+    // ---- first product of chunk ch: KS steps of T MFMAs, fragment reads PD1 steps ahead; accumulators start from the
+    // bias of this lane's hidden rows (i&3) + 8(i>>2) + 4lh
     if constexpr (G1) {
-      const f32x4 bv0 = *reinterpret_cast<const f32x4*>(b1s + 32 * ch + 4 * lg);
-      const f32x4 bv1 = *reinterpret_cast<const f32x4*>(b1s + 32 * ch + 16 + 4 * lg);
 #pragma unroll
-      for (int tt = 0; tt < T; ++tt) {
-        hacc[0][tt] = bv0;
-        hacc[1][tt] = bv1;
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(b1s + 32 * ch + 8 * q + 4 * lh);
+#pragma unroll
+        for (int tt = 0; tt < T; ++tt) {
+          hacc[tt][4 * q] = bv[0]; hacc[tt][4 * q + 1] = bv[1]; hacc[tt][4 * q + 2] = bv[2]; hacc[tt][4 * q + 3] = bv[3];
+        }
       }
-      auto rd = [&](int ks, int ht) {
-        const int pc = (4 * ks + lg) ^ (lq & SW);
-        return *reinterpret_cast<const bf16x8*>(w1 + (16 * ht + lq) * (2 * C) + pc * 16);
+      auto rd = [&](int ks) {
+        return *reinterpret_cast<const bf16x8*>(w1 + lr * (2 * C) + (((2 * ks + lh) ^ fsw) << 4));
       };
-      bf16x8 fa[KS][2];
+      bf16x8 fa[KS];
 #pragma unroll
-      for (int ks = 0; ks < PD1 && ks < KS; ++ks) {
-        fa[ks][0] = rd(ks, 0);
-        fa[ks][1] = rd(ks, 1);
-      }
+      for (int ks = 0; ks < PD1 && ks < KS; ++ks) fa[ks] = rd(ks);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        if (ks + PD1 < KS) {
-          fa[ks + PD1][0] = rd(ks + PD1, 0);
-          fa[ks + PD1][1] = rd(ks + PD1, 1);
-        }
+        if (ks + PD1 < KS) fa[ks + PD1] = rd(ks + PD1);
         __builtin_amdgcn_sched_barrier(0);
         if (!(ABL & 4)) {
 #pragma unroll
-          for (int tt = 0; tt < T; ++tt) {
-            hacc[0][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][0], xf[ks][tt], hacc[0][tt], 0, 0, 0);
-            hacc[1][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][1], xf[ks][tt], hacc[1][tt], 0, 0, 0);
-          }
+          for (int tt = 0; tt < T; ++tt)
+            hacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], xf[ks][tt], hacc[tt], 0, 0, 0);
         } else {
-          asm volatile("" ::"v"(fa[ks][0]), "v"(fa[ks][1]));
+          asm volatile("" ::"v"(fa[ks]));
         }
-        if constexpr (GE) gelu_elems(E / 2 + (E / 2) * ks / KS, E / 2 + (E / 2) * (ks + 1) / KS);
+        if constexpr (GE) gelu_step(2 * RT + ks);
         if (I1 && ks % (KS / LPS) == 0) issue_piece(0, ch + 2, a2, ks / (KS / LPS));
         if (IGLP && GE) {
 #pragma unroll
-          for (int i = 0; i < 2 * T; ++i) {
+          for (int i = 0; i < T; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, IGLP, 0);
           }
@@ -244,20 +287,23 @@ __global__ __launch_bounds__(256, 1) void mlp_ln_residual_bf16_kernel(
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
-      if constexpr (GE) gelu_elems(E / 2, E);
+      if constexpr (GE) gelu_ops(NOPS * (2 * RT) / NSTEPS, NOPS);
     }
     // ---- rotate the pipeline registers: hf <- pack(GELU(chunk ch-1)), hg <- chunk ch
     if constexpr (GE) {
 #pragma unroll
       for (int tt = 0; tt < T; ++tt)
-        hf[tt] = __builtin_bit_cast(bf16x8, u32x4{pack_bf16x2(hg[0][tt][0], hg[0][tt][1]), pack_bf16x2(hg[0][tt][2], hg[0][tt][3]),
-                                                  pack_bf16x2(hg[1][tt][0], hg[1][tt][1]), pack_bf16x2(hg[1][tt][2], hg[1][tt][3])});
+#pragma unroll
+        for (int sk = 0; sk < 2; ++sk)
+          hf[sk][tt] = __builtin_bit_cast(
+              bf16x8, u32x4{pack_bf16x2(hg[tt][8 * sk], hg[tt][8 * sk + 1]), pack_bf16x2(hg[tt][8 * sk + 2], hg[tt][8 * sk + 3]),
+                            pack_bf16x2(hg[tt][8 * sk + 4], hg[tt][8 * sk + 5]), pack_bf16x2(hg[tt][8 * sk + 6], hg[tt][8 * sk + 7])});
     }
     if constexpr (G1) {
 #pragma unroll
-      for (int ht = 0; ht < 2; ++ht)
+      for (int tt = 0; tt < T; ++tt)
 #pragma unroll
-        for (int tt = 0; tt < T; ++tt) hg[ht][tt] = hacc[ht][tt];
+        for (int i = 0; i < 16; ++i) hg[tt][i] = hacc[tt][i];
     }
   };
   // top of iteration ch: the request group of iteration ch-2 has landed (this wave's pieces: vmcnt leaves the N newest
@@ -282,8 +328,19 @@ __global__ __launch_bounds__(256, 1) void mlp_ln_residual_bf16_kernel(
   iteration(1, 1, N_{}, Y{}, Y{}, Y{}, Y{});
   int a = 2;
   for (int ch = 2; ch < NCH - 2; ++ch) {
+#ifdef PANGU_MLP_STAMP
+    const unsigned long long t0 = stamp();
+#endif
     sync(Int<LPW>{});
+#ifdef PANGU_MLP_STAMP
+    st_last = stamp();
+    st_sync += st_last - t0;
+#endif
     iteration(ch, a, Y{}, Y{}, Y{}, Y{}, Y{});
+#ifdef PANGU_MLP_STAMP
+    st_all += stamp() - t0;
+    st_n += 1;
+#endif
     a = a + 1 == NS ? 0 : a + 1;
   }
   // ---- drain: chunks NCH-2, NCH-1 request no W1 any more; then two iterations without a first product
@@ -297,16 +354,16 @@ __global__ __launch_bounds__(256, 1) void mlp_ln_residual_bf16_kernel(
   iteration(NCH + 1, (NCH + 1) % NS, Y{}, N_{}, N_{}, N_{}, N_{});
   __syncthreads();                               // every wave is done with the rings: the patches may reuse them
 
-  // ---- epilogue: lane holds Y^T[c = 16rt + 4lg + r][token m0 + 16tt + lq]
-  unsigned char* patch = smem + wave * (16 * PLD);
+  // ---- epilogue: lane holds Y^T[c = 32rt + (i&3) + 8(i>>2) + 4lh][token m0 + 32tt + lr]
+  unsigned char* patch = smem + wave * (32 * PLD);
   const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       Out, 0, (int)(((size_t)(M - 1) * ldo + C) * sizeof(u16)), 0x00020000);
 #pragma unroll
   for (int tt = 0; tt < T; ++tt) {
-    const int tok0 = m0 + 16 * tt;
+    const int tok0 = m0 + 32 * tt;
     // shortcut rows -> patch
 #pragma unroll
-    for (int it = 0; it < 16 * CPR / 64; ++it) {
+    for (int it = 0; it < 32 * CPR / 64; ++it) {
       const int f = lane + 64 * it, row = f / CPR, chk = f - row * CPR;
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
           x_rsrc, (int)(((unsigned)(tok0 + row) * (unsigned)ldx + chk * 8) * 2u), 0, 0);
@@ -314,56 +371,70 @@ __global__ __launch_bounds__(256, 1) void mlp_ln_residual_bf16_kernel(
     }
     float s = 0.f;
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      yacc[rt][tt] += *reinterpret_cast<const f32x4*>(b2 + 16 * rt + 4 * lg);
-      s += (yacc[rt][tt][0] + yacc[rt][tt][1]) + (yacc[rt][tt][2] + yacc[rt][tt][3]);
-    }
-    s += __shfl_xor(s, 16, 64);
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(eps + 32 * rt + 8 * q + 4 * lh);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          yacc[rt][tt][4 * q + r] += bv[r];
+          s += yacc[rt][tt][4 * q + r];
+        }
+      }
     s += __shfl_xor(s, 32, 64);
     const float mean = s * (1.0f / C);
     float ss = 0.f;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float d = yacc[rt][tt][r] - mean;
+      for (int i = 0; i < 16; ++i) {
+        const float d = yacc[rt][tt][i] - mean;
         ss = fmaf(d, d, ss);
       }
-    ss += __shfl_xor(ss, 16, 64);
     ss += __shfl_xor(ss, 32, 64);
     const float rstd = rsqrtf(ss * (1.0f / C) + LN_EPS);
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 16 * rt + 4 * lg);
-      const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + 16 * rt + 4 * lg);
-      unsigned char* slotp = patch + lq * PLD + (16 * rt + 4 * lg) * 2;
-      const u32x2 xs = *reinterpret_cast<const u32x2*>(slotp);
-      f32x4 o;
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = fmaf((yacc[rt][tt][r] - mean) * rstd, gm[r], bt[r]) * scale;
-      o[0] += bflo(xs[0]); o[1] += bfhi(xs[0]); o[2] += bflo(xs[1]); o[3] += bfhi(xs[1]);
-      *reinterpret_cast<u32x2*>(slotp) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-    }
+      for (int q = 0; q < 4; ++q) {
+        const int c0 = 32 * rt + 8 * q + 4 * lh;
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(eps + C + c0);
+        const f32x4 bt = *reinterpret_cast<const f32x4*>(eps + 2 * C + c0);
+        unsigned char* slotp = patch + lr * PLD + c0 * 2;
+        const u32x2 xs = *reinterpret_cast<const u32x2*>(slotp);
+        f32x4 o;
 #pragma unroll
-    for (int it = 0; it < 16 * CPR / 64; ++it) {
+        for (int r = 0; r < 4; ++r) o[r] = fmaf((yacc[rt][tt][4 * q + r] - mean) * rstd, gm[r], bt[r]) * scale;
+        o[0] += bflo(xs[0]); o[1] += bfhi(xs[0]); o[2] += bflo(xs[1]); o[3] += bfhi(xs[1]);
+        *reinterpret_cast<u32x2*>(slotp) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+      }
+#pragma unroll
+    for (int it = 0; it < 32 * CPR / 64; ++it) {
       const int f = lane + 64 * it, row = f / CPR, chk = f - row * CPR;
       const u32x4 v = *reinterpret_cast<const u32x4*>(patch + row * PLD + chk * 16);
       const unsigned off = tok0 + row < M ? ((unsigned)(tok0 + row) * (unsigned)ldo + chk * 8) * 2u : 0xFFFFFFFFu;
       __builtin_amdgcn_raw_buffer_store_b128(v, o_rsrc, (int)off, 0, 0);
     }
   }
+#ifdef PANGU_MLP_STAMP
+  if (lane == 0) {
+    atomicAdd(&g_stamp[0], st_sync); atomicAdd(&g_stamp[1], st_b);
+    atomicAdd(&g_stamp[2], st_all - st_sync - st_b); atomicAdd(&g_stamp[3], st_n);
+    atomicAdd(&g_stamp[4], stamp() - st_begin); atomicAdd(&g_stamp[5], 1ull);
+  }
+#endif
 }
 
 template <int C, int T>
 int launch_mlp(hipStream_t s, const u16* x, int ldx, const u16* wimg, const float* b1, const float* b2,
                const float* gamma, const float* beta, u16* out, int ldo, int M, float scale) {
-  constexpr size_t ring = (size_t)6 * 64 * C + 4 * C * sizeof(float);
-  constexpr size_t epi = (size_t)4 * 16 * (2 * C + 16);
+  constexpr size_t ring = (size_t)6 * 64 * C + 7 * C * sizeof(float);
+  constexpr size_t epi = (size_t)4 * 32 * (2 * C + 16);
   constexpr size_t shm = ring > epi ? ring : epi;
   static_assert(shm <= 160 * 1024, "LDS");
   auto kern = mlp_ln_residual_bf16_kernel<C, T>;
   PANGU_ENSURE_DYN_LDS(kern, shm);
-  const int grid = (M + 64 * T - 1) / (64 * T);
+  const int grid = (M + 128 * T - 1) / (128 * T);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shm, s, x, ldx, wimg, b1, b2, gamma, beta, out, ldo, M, scale);
   return pangu_launch_status();
 }
@@ -378,10 +449,20 @@ extern "C" int pangu_mlp_ln_residual_fwd_bf16(pangu_stream_t stream, const void*
   if (!pangu_fits_u32(M, ldx, 2) || !pangu_fits_u32(M, ldo, 2)) return PANGU_E_RANGE;
   hipStream_t s = (hipStream_t)stream;
   if (C == 192)
-    return launch_mlp<192, 4>(s, (const u16*)x, ldx, (const u16*)w_packed, b1, b2, gamma, beta, (u16*)out, ldo, M,
+    return launch_mlp<192, 2>(s, (const u16*)x, ldx, (const u16*)w_packed, b1, b2, gamma, beta, (u16*)out, ldo, M,
                               branch_scale);
   if (C == 384)
-    return launch_mlp<384, 2>(s, (const u16*)x, ldx, (const u16*)w_packed, b1, b2, gamma, beta, (u16*)out, ldo, M,
+    return launch_mlp<384, 1>(s, (const u16*)x, ldx, (const u16*)w_packed, b1, b2, gamma, beta, (u16*)out, ldo, M,
                               branch_scale);
   return PANGU_E_SHAPE;
 }
+
+#ifdef PANGU_MLP_STAMP
+extern "C" int pangu_mlp_stamp_read(unsigned long long* out8) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 8);
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z));
+  return 0;
+}
+#endif

@@ -108,13 +108,15 @@ def pack_mlp_weights(w1, w2):
     if C not in (192, 384) or HID != 4 * C or tuple(w2.shape) != (C, HID):
         raise RuntimeError(f"pack_mlp_weights: w1 {tuple(w1.shape)} w2 {tuple(w2.shape)}")
     dev = w1.device
-    nch, sw = HID // 32, (15 if C == 384 else 7)
+    nch = HID // 32
     hr = torch.arange(32, device=dev)
     pos = torch.arange(C // 8, device=dev)
-    src = pos[None, :] ^ (hr[:, None] & sw)                                   # logical chunk stored at (row, position)
+    f = (hr & 15) if C == 384 else ((hr >> 1) & 7)
+    src = pos[None, :] ^ f[:, None]                                           # logical chunk stored at (row, position)
     w1b = w1.to(torch.bfloat16).reshape(nch, 32, C // 8, 8)
     w1img = w1b[:, hr[:, None], src, :]                                       # (nch, 32, C/8, 8)
-    perm = torch.tensor([4 * g + j if j < 4 else 16 + 4 * g + j - 4 for g in range(4) for j in range(8)], device=dev)
+    perm = torch.tensor([16 * s + 8 * (j >> 2) + 4 * h + (j & 3) for s in range(2) for h in range(2) for j in range(8)],
+                        device=dev)
     w2img = w2.to(torch.bfloat16).reshape(C, nch, 32)[:, :, perm].reshape(C, nch, 4, 8).permute(1, 2, 0, 3)
     return torch.stack([w1img.reshape(nch, 32 * C), w2img.reshape(nch, 32 * C)], 0).contiguous()
 

@@ -26,8 +26,8 @@ def _conflict_free(byte_addr_of_lane):
 
 @pytest.mark.parametrize("C", [192, 384])
 def test_mlp_image_matches_kernel_addressing(C):
-    HID, nch, KS, RT = 4 * C, 4 * C // 32, C // 32, C // 16
-    sw = 15 if C == 384 else 7
+    HID, nch, KS, RT = 4 * C, 4 * C // 32, C // 16, C // 32
+    fsw = (lambda r: r & 15) if C == 384 else (lambda r: (r >> 1) & 7)
     g = torch.Generator().manual_seed(C)
     w1 = torch.randn(HID, C, generator=g)
     w2 = torch.randn(C, HID, generator=g)
@@ -37,23 +37,21 @@ def test_mlp_image_matches_kernel_addressing(C):
     w1b, w2b = w1.to(torch.bfloat16).float().numpy(), w2.to(torch.bfloat16).float().numpy()
     for ch in (0, 1, nch - 1):
         for lane in range(64):
-            lq, lg = lane & 15, lane >> 4
-            for ks in range(KS):
-                for ht in range(2):
-                    pc = (4 * ks + lg) ^ (lq & sw)
-                    off = ((16 * ht + lq) * (2 * C) + pc * 16) // 2                      # element offset in the chunk
-                    np.testing.assert_array_equal(im[0, ch, off:off + 8],
-                                                  w1b[32 * ch + 16 * ht + lq, 32 * ks + 8 * lg:32 * ks + 8 * lg + 8])
-            for rt in range(RT):
-                off = (lg * 16 * C + (16 * rt + lq) * 16) // 2
-                hid = [32 * ch + (4 * lg + j if j < 4 else 16 + 4 * lg + j - 4) for j in range(8)]
-                np.testing.assert_array_equal(im[1, ch, off:off + 8], w2b[16 * rt + lq, hid])
+            lr, lh = lane & 31, lane >> 5
+            for ks in range(KS):       # first product: A fragment = W1[32ch + lr][16ks + 8lh .. +7]
+                off = (lr * 2 * C + (((2 * ks + lh) ^ fsw(lr)) << 4)) // 2
+                np.testing.assert_array_equal(im[0, ch, off:off + 8], w1b[32 * ch + lr, 16 * ks + 8 * lh:16 * ks + 8 * lh + 8])
+            for rt in range(RT):       # second product: k-step s, element j <-> hidden 16s + 8(j>>2) + 4lh + (j&3)
+                for sk in range(2):
+                    off = (((sk * 2 + lh) * C + 32 * rt + lr) * 16) // 2
+                    hid = [32 * ch + 16 * sk + 8 * (j >> 2) + 4 * lh + (j & 3) for j in range(8)]
+                    np.testing.assert_array_equal(im[1, ch, off:off + 8], w2b[32 * rt + lr, hid])
     # bank conflicts of the fragment reads
     for ks in range(KS):
-        for ht in range(2):
-            assert _conflict_free(lambda l: (16 * ht + (l & 15)) * 2 * C + ((4 * ks + (l >> 4)) ^ ((l & 15) & sw)) * 16)
+        assert _conflict_free(lambda l: (l & 31) * 2 * C + (((2 * ks + (l >> 5)) ^ fsw(l & 31)) << 4))
     for rt in range(RT):
-        assert _conflict_free(lambda l: (l >> 4) * 16 * C + (16 * rt + (l & 15)) * 16)
+        for sk in range(2):
+            assert _conflict_free(lambda l: ((sk * 2 + (l >> 5)) * C + 32 * rt + (l & 31)) * 16)
 
 
 def test_shadow_cache_revalidates_on_data_swap_and_is_not_copied():

@@ -45,3 +45,13 @@ for M, C in ((521280, 192), (131040, 384)):
     for tag in libs:
         t = sorted(times[tag])
         print(f"C={C} M={M} {tag:>8s}: median {t[len(t) // 2]:.3f} ms  min {t[0]:.3f} ms")
+        if hasattr(libs[tag], "pangu_mlp_stamp_read"):
+            buf = (ctypes.c_ulonglong * 8)()
+            libs[tag].pangu_mlp_stamp_read(buf)          # clear what the timing rounds accumulated
+            libs[tag].pangu_mlp_ln_residual_fwd_bf16(stream, x.data_ptr(), C, img.data_ptr(), b1.data_ptr(), b2.data_ptr(),
+                                                     g.data_ptr(), be.data_ptr(), out.data_ptr(), C, M, C, 1.0)
+            libs[tag].pangu_mlp_stamp_read(buf)
+            v = list(buf)
+            n = max(v[3], 1)
+            print(f"   stamps per steady iteration (cycles): sync {v[0] / n:.0f}  second product {v[1] / n:.0f}  first product {v[2] / n:.0f}"
+                  f"  | whole kernel per wave {v[4] / max(v[5], 1):.0f} cycles, {v[5]} waves, {v[3] / max(v[5], 1):.0f} steady iterations each")
