@@ -82,7 +82,8 @@ class EarthBlockFn(torch.autograd.Function):
             g["a2w"], g["a2b"] = ops.linear_wgrad(dy, o)
             do = ops.linear(dy, _wt(a2w))
             del dy
-            dqkv, dqb_pad, desb = ops.window_attention_bwd(qkv, a1b, esb[0], o, lse, do, Z, H, W, heads, shifted)
+            dqkv, dqb_pad, desb = ops.window_attention_bwd(qkv, a1b, esb[0], o, lse, do, Z, H, W, heads, shifted,
+                                                           desb_out=ops.grad_slot(esb))      # straight into the DP flat buffer
             del do
             g["esb"] = desb.unsqueeze(0)
             g["a1w"], g["a1b"] = ops.linear_wgrad(dqkv, x)

@@ -72,7 +72,8 @@ class EarthBlockFnBF16(torch.autograd.Function):
             g["a2w"], g["a2b"] = ob.linear_wgrad(dy, o)
             do = ob.linear(dy, sh.get_t(a2w))
             del dy
-            dqkv, dqb_pad, desb = ob.window_attention_bwd(qkv, sh.get(a1b), sh.get(esb), o, lse, do, Z, H, W, heads, shifted)
+            dqkv, dqb_pad, desb = ob.window_attention_bwd(qkv, sh.get(a1b), sh.get(esb), o, lse, do, Z, H, W, heads, shifted,
+                                                          desb_out=ops.grad_slot(esb))       # straight into the DP flat buffer
             del do
             g["esb"] = desb.unsqueeze(0)
             g["a1w"], g["a1b"] = ob.linear_wgrad(dqkv, x)

@@ -95,6 +95,30 @@ def _rows(t, name):
 
 _zero_arena = None        # [flat fp32 zeros, used elements]: see zero_arena
 
+# Gradient slots (dist.FlatGradSync): parameter storage address -> the fp32 view of the flat gradient buffer that will hold
+# that parameter's gradient.  Backward kernels that WRITE (not accumulate) a parameter gradient -- the Earth-specific bias
+# tables, 94 % of the 1.107 GB -- store straight into the slot, so the flat buffer is filled without a copy pass.
+_grad_slots = {}
+
+
+def register_grad_slots(slots):
+    """slots: {parameter: flat-buffer view}; replaces the registry (dist.FlatGradSync calls this; {} clears it)."""
+    global _grad_slots
+    _grad_slots = {p.data_ptr(): (p, v) for p, v in slots.items()}
+
+
+def grad_slot(param):
+    """The flat-buffer view for this parameter's gradient, or None: no registry entry, or the parameter already holds a
+    gradient (accumulation over several backward passes: autograd must ADD, so the kernel may not overwrite the slot)."""
+    hit = _grad_slots.get(param.data_ptr())
+    if hit is None:
+        return None
+    p, v = hit
+    if p.grad is not None or v.numel() != param.numel() or v.device != param.device:
+        return None
+    return v
+
+
 
 class zero_arena:
     """One zero fill for all the atomically accumulated gradient buffers of a backward step (weight / bias / LayerNorm /
@@ -247,14 +271,15 @@ def window_attention(qkv, qkv_bias, esb, Z, H, W, heads, shifted, want_lse=False
     return (out, lse) if want_lse else out
 
 
-def window_attention_bwd(qkv, qkv_bias, esb, out, lse, dout, Z, H, W, heads, shifted):
-    """-> (dqkv [N,3C], dqkv_bias [3C] (pad-slot part of linear1.bias' gradient), d_esb like esb)."""
+def window_attention_bwd(qkv, qkv_bias, esb, out, lse, dout, Z, H, W, heads, shifted, desb_out=None):
+    """-> (dqkv [N,3C], dqkv_bias [3C] (pad-slot part of linear1.bias' gradient), d_esb like esb; written into
+    `desb_out` (contiguous fp32, esb.numel() elements) when given)."""
     lib = _lib.load()
     N, C3 = qkv.shape
     C = C3 // 3
     dqkv = torch.empty_like(qkv)
     dqb = _zeros((C3,), qkv.device)
-    desb = torch.empty_like(esb)
+    desb = torch.empty_like(esb) if desb_out is None else desb_out.view(esb.shape)
     Np = (Z // 2) * ((H + 5) // 6) * (W // 12) * 144
     with _timed("attn_bwd", 14.0 * Np * 144 * C):
         _lib.check(lib.pangu_window_attn_bwd(_stream(), _chk(qkv, "qkv"), _chk(qkv_bias, "qkv_bias"), _chk(esb, "esb"),

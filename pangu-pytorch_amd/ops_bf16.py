@@ -212,13 +212,13 @@ def linear_wgrad(dc, a, want_bias=True):
     return dw, db
 
 
-def window_attention_bwd(qkv, qkv_bias, esb, out, lse, dout, Z, H, W, heads, shifted):
+def window_attention_bwd(qkv, qkv_bias, esb, out, lse, dout, Z, H, W, heads, shifted, desb_out=None):
     lib = _lib.load()
     N, C3 = qkv.shape
     C = C3 // 3
     dqkv = torch.empty_like(qkv)
     dqb = _zeros((C3,), qkv.device)
-    desb = torch.empty(esb.shape, dtype=torch.float32, device=qkv.device)
+    desb = torch.empty(esb.shape, dtype=torch.float32, device=qkv.device) if desb_out is None else desb_out.view(esb.shape)
     Np = (Z // 2) * ((H + 5) // 6) * (W // 12) * 144
     with _timed("attn_bwd_bf16", 14.0 * Np * 144 * C):
         _lib.check(lib.pangu_window_attn_bwd_bf16(_stream(), _p(qkv, "qkv"), _p(qkv_bias, "qkv_bias"), _p(esb, "esb"),
