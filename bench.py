@@ -24,7 +24,9 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
-FWD_GFLOP = 8421.2          # SURVEY.md §8(a) ledger: dense-contraction GFLOP per forward step
+FWD_GFLOP = 8421.2          # SURVEY.md §8(a) ledger: dense-contraction GFLOP per forward step on the reference's PADDED shapes
+FWD_GFLOP_EXEC = 8302.3     # executed here: the QKV / output projections skip the zero-pad rows (4 x 4.25 + 12 x 8.49 GFLOP less)
+XGMI_LINK_GBS = 153.0       # one xGMI link, one direction (7 links per GPU, point to point)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 PEAK_HBM_GBS = 8000.0
 
@@ -74,6 +76,41 @@ def cpu_baseline():
     }
 
 
+def cpu_baseline_full(threads):
+    """The CPU oracle's WHOLE forward (oracle/pangu_oracle.forward, the restatement of reference pangu_model.py:50-87) timed
+    once on this host with `threads` threads, on the bench's synthetic shapes."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cases
+    import pangu_oracle as O
+    import synth
+    torch.set_num_threads(threads)
+    p = {k: synth.synth_param(k, sh) for k, sh in cases.model_param_shapes().items()}
+    inp, inp_s, stats, maps, const_h = cases.model_inputs()
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        out, _ = O.forward(p, inp, inp_s, stats, maps, const_h)
+        t = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    return t
+
+
+def pmc_traffic(dtype, family):
+    """Per-launch HBM bytes / MFMA-busy of a kernel family from the committed rocprofv3 PMC run (tools/pmc_traffic.sh ->
+    profiles/pmc_traffic_<dtype>.json).  Counters cannot be read from inside this process; the JSON records the sha256 of the
+    kernel sources it was taken on: if a source changed since, the numbers are reported as stale (traffic null)."""
+    import hashlib
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", f"pmc_traffic_{dtype}.json")))
+        e = j[family]
+        h = hashlib.sha256()
+        for f in e["sources"]:
+            h.update(open(os.path.join(ROOT, "pangu-pytorch_amd", "csrc", f), "rb").read())
+        stale = h.hexdigest()[:16] != e["source_sha"]
+        return (None if stale else e["hbm_bytes_per_launch"]), (None if stale else e["mfma_busy_frac"]), stale, j.get("commit")
+    except (OSError, KeyError, ValueError):
+        return None, None, None, None
+
+
 def synthetic_inputs(dev, seed):
     """One synthetic ERA5-shaped sample, resident in HBM: upper-air (1,5,13,721,1440), surface (1,4,721,1440), O(1)
     values, non-trivial normalisation statistics, the three constant maps and const_h (reference pangu_model.py:60-66)."""
@@ -90,6 +127,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", choices=("auto", "sample", "full", "none"), default="auto",
+                    help="sample: oracle block pairs on a half-longitude slice, extrapolated (~15 s); full: also the oracle's whole "
+                         "forward once (45 s on a 256-core host, minutes on 8 cores); auto = full on hosts with >= 32 cores")
     ap.add_argument("--no-bf16", action="store_true", help="skip the secondary bf16 forward measurement")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary DDP training-step measurement")
     ap.add_argument("--train-steps", type=int, default=3)
@@ -139,8 +179,9 @@ def main():
         out = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    gemm_ms, gemm_flop, gemm_launches, other = ops.timing_stop("linear", also=("linear_ln",))
+    gemm_ms, gemm_flop, gemm_launches, other = ops.timing_stop("linear", also=("linear_ln", "attn"))
     fused_ms, fused_flop, fused_launches = other["linear_ln"]      # GEMMs with the fused LayerNorm+residual epilogue
+    attn_ms, attn_flop, attn_launches = other["attn"]              # fused window attention (QK^T + bias + mask + softmax + PV)
     assert torch.isfinite(out[0]).all()
 
     if dist is not None:
@@ -198,7 +239,8 @@ def main():
         bf16_res = {"metric": "bf16 forward steps/s (bf16 activations+weights, fp32 LN/softmax/accumulate), hipGraph replay",
                     "value": world * args.steps / tg, "ms_per_step": tg / args.steps * 1e3,
                     "eager_ms_per_step": tb / args.steps * 1e3, "rel_l2_drift_vs_f32": drift,
-                    "model_tflops": FWD_GFLOP / (tg / args.steps * 1e3),
+                    "model_tflops": FWD_GFLOP_EXEC / (tg / args.steps * 1e3),
+                    "frac_of_bf16_mfma_peak": FWD_GFLOP_EXEC / (tg / args.steps * 1e3) / 2500.0,
                     "rollout_7x24h_ms": tr * 1e3, "rollout_rel_l2_drift_vs_f32_per_step": roll_drift}
         model.set_compute_dtype(torch.float32)
         del out_b, gs
@@ -214,7 +256,7 @@ def main():
         elif ok:
             tg, tb, tr = t[:3].tolist()
             bf16_res.update(value=world * args.steps / tg, ms_per_step=tg / args.steps * 1e3,
-                            eager_ms_per_step=tb / args.steps * 1e3, model_tflops=FWD_GFLOP / (tg / args.steps * 1e3),
+                            eager_ms_per_step=tb / args.steps * 1e3, model_tflops=FWD_GFLOP_EXEC / (tg / args.steps * 1e3),
                             rollout_7x24h_ms=tr * 1e3)
 
     # ---- secondary metric: DDP finetune step (BASELINE configs[3] shape: 1 sample/GPU, fwd + bwd + bucketed RCCL
@@ -229,31 +271,53 @@ def main():
         opt = train.make_optimizer(model)      # Adam(lr=5e-6, weight_decay=3e-6), reference finetune_fully.py:121
         sync = FlatGradSync(model, force_collective=True) if dist is not None else None
         batch = (inp, inp_s, tgt, tgt_s)
+        exposed = []      # (event before finish(), event after): GPU time the compute stream spends waiting for the buckets
+
+        def grad_sync():
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            sync.finish()
+            b.record()
+            exposed.append((a, b))
         for tag, dt in (("ddp_train", torch.float32), ("ddp_train_bf16", torch.bfloat16)):
             try:
                 model.set_compute_dtype(dt)
                 torch.manual_seed(1234 + rank)            # DropPath draws (host RNG)
                 torch.cuda.reset_peak_memory_stats()
-                train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=sync.finish if sync else None)
-                barrier()
+                train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=grad_sync if sync else None)
+                lsync()
+                del exposed[:]
                 t1 = time.perf_counter()
                 for _ in range(args.train_steps):
-                    loss = train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=sync.finish if sync else None)
-                barrier()
+                    loss = train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=grad_sync if sync else None)
+                lsync()
                 t_train = time.perf_counter() - t1
-                if dist is not None:
-                    t = torch.tensor([t_train], dtype=torch.float64, device=dev)
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                    t_train = t.item()
+                what = ("fwd+bwd+bucketed grad all-reduce (RCCL, issued from the backward hooks)+Adam" if sync else
+                        "fwd+bwd+Adam; ONE rank: no collective and no flat gradient buffer exist (see ddp_model for the all-reduce)")
                 train_res[tag] = {
-                    "metric": "DDP finetune samples/s (fwd+bwd+bucketed grad all-reduce+Adam, 1 sample/GPU, DropPath on), "
+                    "metric": f"finetune samples/s ({what}; 1 sample/GPU, DropPath on), "
                               + ("fp32" if dt == torch.float32 else "bf16 compute / fp32 master weights+grads"),
                     "value": world * args.train_steps / t_train, "ms_per_step": t_train / args.train_steps * 1e3,
                     "steps": args.train_steps, "loss": float(loss),
                     "peak_mem_gb": torch.cuda.max_memory_allocated() / 2**30,
-                    "model_tflops": 3 * FWD_GFLOP / (t_train / args.train_steps * 1e3)}
+                    "model_tflops": 3 * FWD_GFLOP_EXEC / (t_train / args.train_steps * 1e3)}
+                if sync:
+                    train_res[tag]["exposed_allreduce_ms_per_step"] = sum(a.elapsed_time(b) for a, b in exposed) / max(len(exposed), 1)
+                    train_res[tag]["grad_copy_fallback_mib"] = sync.copied_bytes / 2**20
             except Exception as e:      # secondary metrics must never take the headline line down
                 train_res[tag] = {"error": repr(e)[:300]}
+            if dist is not None:        # collectives OUTSIDE the try: every rank gets here, failed or not
+                ok = "error" not in train_res[tag]
+                t = torch.tensor([train_res[tag]["ms_per_step"] if ok else 0.0, 0.0 if ok else 1.0], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                if ok and t[1].item() > 0:
+                    train_res[tag] = {"error": "another rank failed this section"}
+                    break
+                if ok:
+                    train_res[tag].update(ms_per_step=t[0].item(), value=world / (t[0].item() * 1e-3),
+                                          model_tflops=3 * FWD_GFLOP_EXEC / t[0].item())
+                else:
+                    break
         model.set_compute_dtype(torch.float32)
 
     if rank == 0:
@@ -261,12 +325,9 @@ def main():
         achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         # HBM bytes per launch of the same kernel family from the committed rocprofv3 PMC run (separate --pmc passes,
         # FETCH_SIZE doubled per MI355X_MICROARCH.md): counters cannot be read from inside this process
-        traffic, mfma_busy = None, None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_f32.json")))["gemm"]
-            traffic, mfma_busy = pmc["hbm_bytes_per_launch"], pmc["mfma_busy_frac"]
-        except (OSError, KeyError, ValueError):
-            pass
+        traffic, mfma_busy, stale, pmc_commit = pmc_traffic("f32", "gemm")
+        a_traffic, a_busy, a_stale, _ = pmc_traffic("f32", "attn")
+        a_achieved = attn_flop / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
         res = {
             "metric": "forward steps/sec (721x1440x13pl) per MI355X", "value": world * args.steps / elapsed,
             "unit": "forward steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -274,23 +335,66 @@ def main():
             "config": {"workload": "PanguModel fp32 forward, 1 sample/GPU, input (1,5,13,721,1440)+(1,4,721,1440), "
                                    "depths 2-6-6-2, dims 192/384, random-init weights (BASELINE configs[1])",
                        "parallelism": f"dp{world}"},
-            "model_tflops": FWD_GFLOP / ms,
+            "model_tflops": FWD_GFLOP_EXEC / ms,
+            "model_flop_note": f"executed dense-contraction GFLOP per step {FWD_GFLOP_EXEC} (the reference's padded-shape ledger: {FWD_GFLOP})",
             "roofline": {"bound": "mfma", "kernel": "gemm_tn_f32_dma_kernel (plain projection GEMMs)", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": traffic, "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, profiles/pmc_traffic_f32.json)",
+                         "traffic": traffic, "traffic_stale": stale, "traffic_commit": pmc_commit,
+                         "traffic_unit": "HBM bytes/launch (rocprofv3 PMC passes of tools/pmc_traffic.sh -> profiles/pmc_traffic_f32.json; "
+                                         "null + traffic_stale when the kernel source changed since)",
                          "algorithmic_flop_per_launch": gemm_flop / max(gemm_launches, 1),
                          "mfma_busy_frac_pmc": mfma_busy, "launches": gemm_launches, "avg_launch_ms": gemm_ms / max(gemm_launches, 1),
                          "share_of_step": gemm_ms / (ms * args.steps),
                          "fused_ln_gemm": {"kernel": "gemm_ln_residual_f32_dma_kernel (projection + LayerNorm + residual)",
                                            "launches": fused_launches, "avg_launch_ms": fused_ms / max(fused_launches, 1),
                                            "achieved": fused_flop / (fused_ms * 1e-3) / 1e12 if fused_ms > 0 else 0.0,
-                                           "share_of_step": fused_ms / (ms * args.steps)}},
+                                           "share_of_step": fused_ms / (ms * args.steps)},
+                         "attention": {"kernel": "window_attn_f32_kernel (QK^T + Earth bias + shift mask + softmax + PV, one launch per block)",
+                                       "bound": "mfma", "achieved": a_achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": a_achieved / PEAK_F32_MFMA_TFLOPS, "launches": attn_launches,
+                                       "avg_launch_ms": attn_ms / max(attn_launches, 1),
+                                       "algorithmic_flop_per_launch": attn_flop / max(attn_launches, 1),
+                                       "traffic": a_traffic, "traffic_stale": a_stale, "mfma_busy_frac_pmc": a_busy,
+                                       "share_of_step": attn_ms / (ms * args.steps)}},
         }
         if bf16_res is not None:
             res["bf16_forward"] = bf16_res
         res.update(train_res)
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline()
+        # ---- data-parallel model: measured 1-rank step + MODELLED gradient all-reduce
+        n_grad = sum(p.numel() for p in model.parameters())
+        gbytes = n_grad * 4.0
+        mdl = {"note": "MODELLED, not measured (one GPU per gpurun box): per step ONE averaged all-reduce of the flat fp32 gradient "
+                       "buffer (reference era5_data/utils_dist.py:125-134 semantics), bucketed in reverse block order so it runs under "
+                       "the remaining backward; xGMI is point to point, 7 links x 153 GB/s per direction per GPU",
+               "grad_bytes": gbytes, "link_GBps": XGMI_LINK_GBS, "allreduce_ms": {}}
+        for n in (2, 4, 8):
+            ring = 2.0 * (n - 1) / n * gbytes / (XGMI_LINK_GBS * 1e9) * 1e3          # one link busy per GPU
+            direct = 2.0 * gbytes / n / (XGMI_LINK_GBS * 1e9) * 1e3                    # reduce-scatter + all-gather, every peer link busy
+            mdl["allreduce_ms"][str(n)] = {"ring_one_link": ring, "direct_all_links": direct}
+        for tag in ("ddp_train", "ddp_train_bf16"):
+            if tag in train_res and "error" not in train_res[tag]:
+                t_step = train_res[tag]["ms_per_step"] if world == 1 else None
+                if t_step:
+                    d8 = mdl["allreduce_ms"]["8"]
+                    mdl[tag] = {"measured_1gpu_ms_per_step": t_step,
+                                "projected_8gpu_samples_per_s": {"allreduce_fully_overlapped": 8e3 / t_step,
+                                                                 "direct_fully_exposed": 8e3 / (t_step + d8["direct_all_links"]),
+                                                                 "ring_fully_exposed": 8e3 / (t_step + d8["ring_one_link"])}}
+                if "exposed_allreduce_ms_per_step" in train_res[tag]:
+                    mdl.setdefault(tag, {})["measured_exposed_allreduce_ms_this_run"] = train_res[tag]["exposed_allreduce_ms_per_step"]
+        res["ddp_model"] = mdl
+        mode = "none" if args.no_cpu_baseline else args.cpu_baseline
+        if mode == "auto":
+            mode = "full" if (os.cpu_count() or 1) >= 32 else "sample"
+        if world == 1 and mode != "none":
+            cb = cpu_baseline()
+            if mode == "full":
+                t_full = cpu_baseline_full(cb["cores"])
+                cb["extrapolated_from_block_pairs"] = {"value": cb["value"], "sample": cb["sample"]}
+                cb["value"] = 1.0 / t_full
+                cb["sample"] = (f"the oracle's WHOLE forward (oracle/pangu_oracle.forward = reference pangu_model.py:50-87 restated), one "
+                                f"step on the bench's shapes: {t_full:.1f} s with {cb['cores']} threads")
+            res["cpu_baseline"] = cb
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

@@ -294,18 +294,15 @@ __global__ __launch_bounds__(192, 2) void window_attn_qkv_bf16_kernel(const u16*
   unsigned char* const Ks = smem + QK_RING * QK_SLOT;                // [144][64 B]
   unsigned char* const Vt = Ks + PANGU_WTOK * 64;                    // [32][VT_LD]
 
+  // Block order: blocks b, b+8, .. share an XCD (its L2).  Every head of a window reads the SAME 144 input rows, so the
+  // heads of one window run back to back on one XCD (x leaves HBM once, not `heads` times: PMC FETCH_SIZE 0.67 -> ...
+  // GB per launch, profiles/), then the next longitude window of the same type (its `heads` bias tiles stay in that L2).
   const int b = blockIdx.x;
   const int xcd = b & 7, local = b >> 3;
-  int pair, l;
-  if (heads & 1) {
-    pair = (local / g.nLon) * 8 + xcd;
-    l = local % g.nLon;
-  } else {
-    const int sub = local & 1, wl = local >> 1;
-    const int unit = (wl / g.nLon) * 8 + xcd;
-    l = wl % g.nLon;
-    pair = 2 * unit + sub;
-  }
+  const int hd_ = local % heads, wl = local / heads;
+  const int l = wl % g.nLon;
+  const int t_ = (wl / g.nLon) * 8 + xcd;
+  const int pair = t_ * heads + hd_;
   if (pair >= n_pairs) return;
   const int t = pair / heads, hd = pair - t * heads;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -466,7 +463,7 @@ extern "C" int pangu_window_attn_qkv_fwd_bf16(pangu_stream_t stream, const void*
   if (!pangu_fits_u32(n_tok, ldx, 2)) return PANGU_E_RANGE;
   const WinGeom g = make_geom(Z, H, W);
   const int n_pairs = g.types * heads;
-  const int grid = (heads & 1) ? ((n_pairs + 7) / 8) * 8 * g.nLon : ((n_pairs / 2 + 7) / 8) * 8 * g.nLon * 2;
+  const int grid = ((g.types + 7) / 8) * 8 * g.nLon * heads;
   static const int ring = getenv("PANGU_ATTN_QKV_RING") ? atoi(getenv("PANGU_ATTN_QKV_RING")) : 2;      // A/B knob
   const size_t shm = (size_t)(ring == 3 ? 3 : 2) * QK_SLOT + PANGU_WTOK * 64 + 32 * VT_LD;
   hipStream_t s = (hipStream_t)stream;

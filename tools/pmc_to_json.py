@@ -1,38 +1,82 @@
 #!/usr/bin/env python3
-"""Per-launch HBM traffic and MFMA utilisation of a kernel family from separate rocprofv3 --pmc passes.
+"""Per-launch HBM traffic and MFMA utilisation of the forward's kernel families from separate rocprofv3 --pmc passes
+(driven by tools/pmc_traffic.sh, which also takes a kernel trace of the same command).
 
-  python tools/pmc_to_json.py <dir with the counter_collection CSVs> > profiles/pmc_traffic_f32.json
+  python tools/pmc_to_json.py <dir with trace/ fetch/ write/ mfma/> <f32|bf16>  > pmc_traffic_<dtype>.json
 FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE is doubled (gfx950 correction, MI355X_MICROARCH.md).
-mfma_busy = sum SQ_VALU_MFMA_BUSY_CYCLES / (sum GRBM_GUI_ACTIVE * 128)   (GUI_ACTIVE is summed over the 8 XCDs, the MFMA counter
-over the 1024 SIMDs)."""
-import collections, csv, glob, json, os, sys
+mfma_busy = sum SQ_VALU_MFMA_BUSY_CYCLES / (sum GRBM_GUI_ACTIVE * 128)   (GUI_ACTIVE is summed over the 8 XCDs, the MFMA
+counter over the 1024 SIMDs).  The JSON records the git commit and the sha256 of every kernel source a family comes from:
+bench.py recomputes those hashes and reports `traffic: null, traffic_stale: true` when a source changed since the
+counters were taken.  Exits non-zero if a family priced here does not appear in the kernel trace of the same command."""
+import collections
+import csv
+import glob
+import hashlib
+import json
+import os
+import subprocess
+import sys
 
-FAMILIES = {"gemm": ("gemm_tn_f32_dma_kernel", "gemm_tn_f32_kernel"), "gemm_ln": ("gemm_ln_residual_f32",),
-            "attn": ("window_attn_f32_kernel",)}
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "pangu-pytorch_amd", "csrc")
+# family -> (kernel-name substrings, source files)
+FAMILIES = {
+    "f32": {"gemm": (("gemm_tn_f32_dma_kernel", "gemm_tn_f32_kernel"), ("gemm_f32_dma.hip", "gemm_f32.hip")),
+            "gemm_ln": (("gemm_ln_residual_f32",), ("gemm_ln_f32_dma.hip", "gemm_ln_f32.hip")),
+            "attn": (("window_attn_f32_kernel",), ("attn_f32.hip",))},
+    "bf16": {"mlp_fused": (("mlp_ln_residual_bf16_kernel",), ("mlp_fused_bf16.hip",)),
+             "attn_qkv": (("window_attn_qkv_bf16_kernel",), ("attn_bf16.hip",)),
+             "gemm": (("gemm_tn_bf16", "gemm_ws_bf16"), ("gemm_bf16.hip", "gemm_ws_bf16.hip")),
+             "gemm_ln": (("gemm_ln_residual_bf16",), ("gemm_ln_bf16.hip",))},
+}
 
 
-def main(d):
+def source_sha(files):
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def main(d, dtype):
+    fams = FAMILIES[dtype]
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     disp = collections.defaultdict(lambda: collections.defaultdict(set))
     for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(path)):
-            for fam, names in FAMILIES.items():
+            for fam, (names, _) in fams.items():
                 if any(n in r["Kernel_Name"] for n in names):
                     agg[fam][r["Counter_Name"]] += float(r["Counter_Value"])
                     disp[fam][r["Counter_Name"]].add(r["Dispatch_Id"])
-    out = {}
-    for fam, c in agg.items():
+    traced = collections.Counter()
+    for path in glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True):
+        for r in csv.DictReader(open(path)):
+            traced[r["Name"]] += int(r["Calls"])
+    out, missing = {}, []
+    for fam, (names, files) in fams.items():
+        launched = sum(c for k, c in traced.items() if any(n in k for n in names))
+        c = agg.get(fam)
+        if not c or not launched:
+            missing.append(fam)
+            continue
         n = len(disp[fam]["FETCH_SIZE"]) or 1
         rd = c["FETCH_SIZE"] * 2 * 1024 / n
         wr = c["WRITE_SIZE"] * 1024 / max(len(disp[fam]["WRITE_SIZE"]), 1)
-        out[fam] = {"launches": n, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
-                    "hbm_bytes_per_launch": rd + wr,
+        out[fam] = {"kernels": list(names), "launches_in_trace": launched, "launches": n, "hbm_read_bytes_per_launch": rd,
+                    "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
                     "mfma_busy_frac": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] * 128) if c["GRBM_GUI_ACTIVE"] else None,
-                    "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB->bytes; separate rocprofv3 --pmc passes over "
-                            "`bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train --no-bf16`"}
-    out["source"] = "profiles/r01_fwd_f32_rocprof_summary.md (tools/pmc_to_json.py over the --pmc passes FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES+GRBM_GUI_ACTIVE)"
+                    "source_sha": source_sha(files), "sources": list(files)}
+    try:
+        commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except OSError:
+        commit = ""
+    out["commit"] = commit or os.environ.get("PANGU_COMMIT", "unknown (the GPU box has no .git; see the profile's file name / git log)")
+    out["command"] = f"python3 tools/profile_fwd.py {dtype} 3   (rocprofv3 passes: FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; FETCH_SIZE x2)"
     print(json.dumps(out, indent=1))
+    if missing:
+        sys.stderr.write(f"kernel families without counters or not launched by the traced command: {missing}\n")
+        sys.exit(1)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "f32")
