@@ -290,8 +290,11 @@ __global__ __launch_bounds__(192, 2) void window_attn_qkv_bf16_kernel(const u16*
                                                                       int heads, int n_pairs) {
   constexpr int KS = C / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // the K / V^T images REUSE the ring's memory (they are written after the K-loop, behind a barrier): 45 KB per workgroup
+  // with a ring of 3, so three workgroups per CU each keep two K-steps of LDS-DMA in flight -- the loop is bound by the
+  // DMA round trip (a step's 15 KB per workgroup), not by its 54 MFMAs
   unsigned char* const ring = smem;                                  // QK_RING slots
-  unsigned char* const Ks = smem + QK_RING * QK_SLOT;                // [144][64 B]
+  unsigned char* const Ks = smem;                                    // [144][64 B]
   unsigned char* const Vt = Ks + PANGU_WTOK * 64;                    // [32][VT_LD]
 
   // Block order: blocks b, b+8, .. share an XCD (its L2).  Every head of a window reads the SAME 144 input rows, so the
@@ -393,8 +396,11 @@ __global__ __launch_bounds__(192, 2) void window_attn_qkv_bf16_kernel(const u16*
     }
   }
 
-  // ---- q fragments (registers), K image and V^T image (LDS)
+  // ---- q fragments (registers), K image and V^T image (LDS, over the ring: every wave must be done reading it)
   BiasRow b0 = load_bias_row(bias_tile, tile0 * 16 + lq, lg);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
   bf16x8 qf[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -464,8 +470,8 @@ extern "C" int pangu_window_attn_qkv_fwd_bf16(pangu_stream_t stream, const void*
   const WinGeom g = make_geom(Z, H, W);
   const int n_pairs = g.types * heads;
   const int grid = ((g.types + 7) / 8) * 8 * g.nLon * heads;
-  static const int ring = getenv("PANGU_ATTN_QKV_RING") ? atoi(getenv("PANGU_ATTN_QKV_RING")) : 2;      // A/B knob
-  const size_t shm = (size_t)(ring == 3 ? 3 : 2) * QK_SLOT + PANGU_WTOK * 64 + 32 * VT_LD;
+  static const int ring = getenv("PANGU_ATTN_QKV_RING") ? atoi(getenv("PANGU_ATTN_QKV_RING")) : 2;      // A/B knob (2: four workgroups per CU -- 142 VGPRs; forcing 128 for five spills and loses 7 %; 3: three workgroups, two steps in flight, -5 %)
+  const size_t shm = (size_t)(ring == 3 ? 3 : 2) * QK_SLOT;                       // >= the K + V^T images (19968 B) that reuse it
   hipStream_t s = (hipStream_t)stream;
 #define PANGU_QKV_LAUNCH(SH, CC)                                                                                          \
   do {                                                                                                                    \
