@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ln_residual_bf16_kernel(
   unsigned char* const ring1 = smem;                      // W1 stream, NS slots
   unsigned char* const ring2 = smem + NS * WB;            // W2 stream, NS slots
   float* const b1s = reinterpret_cast<float*>(smem + 2 * NS * WB);
-  float* const eps = b1s + HID;                           // b2 | gamma | beta (3 x C floats) for the epilogue
+  float* const eps = b1s + HID;                           // (b2 |) gamma | beta (C floats each) for the epilogue
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -162,13 +162,18 @@ __global__ __launch_bounds__(256, 1) void mlp_ln_residual_bf16_kernel(
   unsigned long long st_sync = 0, st_b = 0, st_all = 0, st_n = 0, st_last = 0;
   const unsigned long long st_begin = stamp();
 #endif
+  // second-product accumulators start from b2 of the lane's channels 32rt + (i&3) + 8(i>>2) + 4lh (no bias pass in the epilogue)
   f32x16 yacc[RT][T];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-    for (int tt = 0; tt < T; ++tt)
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + 32 * rt + 8 * q + 4 * lh);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) yacc[rt][tt][i] = 0.f;
+      for (int tt = 0; tt < T; ++tt) {
+        yacc[rt][tt][4 * q] = bv[0]; yacc[rt][tt][4 * q + 1] = bv[1]; yacc[rt][tt][4 * q + 2] = bv[2]; yacc[rt][tt][4 * q + 3] = bv[3];
+      }
+    }
   f32x16 hacc[T];            // first product of the current chunk (bias included)
   float hg[T][16];           // first product of the previous chunk, GELU applied stage by stage during this iteration
   bf16x8 hf[2][T];           // packed GELU output of the chunk before that: B operand (k-step s) of the second product
@@ -204,7 +209,12 @@ __global__ __launch_bounds__(256, 1) void mlp_ln_residual_bf16_kernel(
         else x = x * t;
       }
     };
-    auto gelu_step = [&](int g) { gelu_ops(NOPS * g / NSTEPS, NOPS * (g + 1) / NSTEPS); };
+    // step 0 (right behind the barrier, while the first fragment reads are in flight: ~250 cycles with nothing else to
+    // issue) takes the first two stages of every element; the rest is spread evenly over the other steps
+    constexpr int FRONT = 2 * E;
+    auto gelu_step = [&](int g) {
+      if (g > 0) gelu_ops(FRONT + (NOPS - FRONT) * (g - 1) / (NSTEPS - 1), FRONT + (NOPS - FRONT) * g / (NSTEPS - 1));
+    };
     // ---- second product of chunk ch-2: 2 RT steps (row tile, k-step) of T MFMAs, fragment reads PD2 steps ahead
     if constexpr (G2) {
       constexpr int NSTEP = 2 * RT;
@@ -214,6 +224,10 @@ __global__ __launch_bounds__(256, 1) void mlp_ln_residual_bf16_kernel(
       bf16x8 fa[NSTEP];
 #pragma unroll
       for (int st = 0; st < PD2 && st < NSTEP; ++st) fa[st] = rd(st);
+      if constexpr (GE) {
+        __builtin_amdgcn_sched_barrier(0);
+        gelu_ops(0, FRONT);                                // under the first reads' flight
+      }
 #pragma unroll
       for (int st = 0; st < NSTEP; ++st) {
         if (st + PD2 < NSTEP) fa[st + PD2] = rd(st + PD2);
@@ -237,7 +251,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ln_residual_bf16_kernel(
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
-      if constexpr (GE) gelu_ops(0, NOPS * (2 * RT) / NSTEPS);
+      if constexpr (GE) gelu_ops(0, FRONT + (NOPS - FRONT) * (2 * RT - 1) / (NSTEPS - 1));
       if (I2) {
 #pragma unroll
         for (int i = 0; i < LPS; ++i) issue_piece(1, ch, a, i);
@@ -287,7 +301,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ln_residual_bf16_kernel(
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
-      if constexpr (GE) gelu_ops(NOPS * (2 * RT) / NSTEPS, NOPS);
+      if constexpr (GE) gelu_ops(FRONT + (NOPS - FRONT) * (2 * RT - 1) / (NSTEPS - 1), NOPS);
     }
     // ---- rotate the pipeline registers: hf <- pack(GELU(chunk ch-1)), hg <- chunk ch
     if constexpr (GE) {
@@ -323,6 +337,9 @@ __global__ __launch_bounds__(256, 1) void mlp_ln_residual_bf16_kernel(
 #pragma unroll
   for (int i = 0; i < LPS; ++i) issue_piece(0, 1, 1, i);
   sync(Int<LPS>{});                                       // W1 chunk 0 (and x, b1) landed; W1 chunk 1 in flight
+#ifdef PANGU_MLP_STAMP
+  const unsigned long long st_pro = stamp() - st_begin;
+#endif
   iteration(0, 0, N_{}, N_{}, Y{}, Y{}, Y{});
   sync(Int<LPW>{});
   iteration(1, 1, N_{}, Y{}, Y{}, Y{}, Y{});
@@ -353,6 +370,9 @@ __global__ __launch_bounds__(256, 1) void mlp_ln_residual_bf16_kernel(
   sync(Int<0>{});
   iteration(NCH + 1, (NCH + 1) % NS, Y{}, N_{}, N_{}, N_{}, N_{});
   __syncthreads();                               // every wave is done with the rings: the patches may reuse them
+#ifdef PANGU_MLP_STAMP
+  const unsigned long long st_epi0 = stamp();
+#endif
 
   // ---- epilogue: lane holds Y^T[c = 32rt + (i&3) + 8(i>>2) + 4lh][token m0 + 32tt + lr]
   unsigned char* patch = smem + wave * (32 * PLD);
@@ -361,36 +381,37 @@ __global__ __launch_bounds__(256, 1) void mlp_ln_residual_bf16_kernel(
 #pragma unroll
   for (int tt = 0; tt < T; ++tt) {
     const int tok0 = m0 + 32 * tt;
-    // shortcut rows -> patch
+    // The shortcut IS this wave's input tile, still in registers as the first product's B fragments: lane (token, h) holds
+    // channels 16ks + 8h .. +7, the accumulator layout wants 32rt + 8q + 4h .. +3 -- half of which the partner lane (h ^ 1,
+    // same token) holds: two v_permlane32_swap per fragment and (rt, q) reads registers {2(q&1), 2(q&1)+1} of fragment
+    // 2rt + (q>>1) in BOTH halves.  (Re-loading the tile instead made every CU read 100 KB at the same moment: the kernel
+    // runs its tiles in lockstep, so the epilogue was a chip-wide 25 MB burst, 38k of 175k cycles per tile.)
+    u32x4 sc[KS];
 #pragma unroll
-    for (int it = 0; it < 32 * CPR / 64; ++it) {
-      const int f = lane + 64 * it, row = f / CPR, chk = f - row * CPR;
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
-          x_rsrc, (int)(((unsigned)(tok0 + row) * (unsigned)ldx + chk * 8) * 2u), 0, 0);
-      *reinterpret_cast<u32x4*>(patch + row * PLD + chk * 16) = v;
+    for (int ks = 0; ks < KS; ++ks) {
+      u32x4 f = __builtin_bit_cast(u32x4, xf[ks][tt]);
+      const auto r02 = __builtin_amdgcn_permlane32_swap(f[0], f[2], false, false);
+      const auto r13 = __builtin_amdgcn_permlane32_swap(f[1], f[3], false, false);
+      sc[ks] = u32x4{r02[0], r13[0], r02[1], r13[1]};
     }
-    float s = 0.f;
+    // LayerNorm statistics: four independent partial sums (a single dependent add chain stalls the lone wave on every add)
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(eps + 32 * rt + 8 * q + 4 * lh);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          yacc[rt][tt][4 * q + r] += bv[r];
-          s += yacc[rt][tt][4 * q + r];
-        }
-      }
+      for (int i = 0; i < 16; ++i) s4[i & 3] += yacc[rt][tt][i];
+    float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     s += __shfl_xor(s, 32, 64);
     const float mean = s * (1.0f / C);
-    float ss = 0.f;
+    float q4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const float d = yacc[rt][tt][i] - mean;
-        ss = fmaf(d, d, ss);
+        q4[i & 3] = fmaf(d, d, q4[i & 3]);
       }
+    float ss = (q4[0] + q4[1]) + (q4[2] + q4[3]);
     ss += __shfl_xor(ss, 32, 64);
     const float rstd = rsqrtf(ss * (1.0f / C) + LN_EPS);
 #pragma unroll
@@ -401,7 +422,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ln_residual_bf16_kernel(
         const f32x4 gm = *reinterpret_cast<const f32x4*>(eps + C + c0);
         const f32x4 bt = *reinterpret_cast<const f32x4*>(eps + 2 * C + c0);
         unsigned char* slotp = patch + lr * PLD + c0 * 2;
-        const u32x2 xs = *reinterpret_cast<const u32x2*>(slotp);
+        const u32x2 xs = u32x2{sc[2 * rt + (q >> 1)][2 * (q & 1)], sc[2 * rt + (q >> 1)][2 * (q & 1) + 1]};
         f32x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = fmaf((yacc[rt][tt][4 * q + r] - mean) * rstd, gm[r], bt[r]) * scale;
@@ -420,7 +441,9 @@ __global__ __launch_bounds__(256, 1) void mlp_ln_residual_bf16_kernel(
   if (lane == 0) {
     atomicAdd(&g_stamp[0], st_sync); atomicAdd(&g_stamp[1], st_b);
     atomicAdd(&g_stamp[2], st_all - st_sync - st_b); atomicAdd(&g_stamp[3], st_n);
-    atomicAdd(&g_stamp[4], stamp() - st_begin); atomicAdd(&g_stamp[5], 1ull);
+    const unsigned long long t_end = stamp();
+    atomicAdd(&g_stamp[4], t_end - st_begin); atomicAdd(&g_stamp[5], 1ull);
+    atomicAdd(&g_stamp[6], st_pro); atomicAdd(&g_stamp[7], t_end - st_epi0);
   }
 #endif
 }

@@ -54,4 +54,5 @@ for M, C in ((521280, 192), (131040, 384)):
             v = list(buf)
             n = max(v[3], 1)
             print(f"   stamps per steady iteration (cycles): sync {v[0] / n:.0f}  second product {v[1] / n:.0f}  first product {v[2] / n:.0f}"
-                  f"  | whole kernel per wave {v[4] / max(v[5], 1):.0f} cycles, {v[5]} waves, {v[3] / max(v[5], 1):.0f} steady iterations each")
+                  f"  | whole kernel per wave {v[4] / max(v[5], 1):.0f} cycles ({v[5]} waves, {v[3] / max(v[5], 1):.0f} steady iterations each): "
+                  f"prologue {v[6] / max(v[5], 1):.0f}, epilogue {v[7] / max(v[5], 1):.0f}")
