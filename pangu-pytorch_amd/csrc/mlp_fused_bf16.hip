@@ -39,6 +39,7 @@
 //             8q..8q+7 of that row with q = p ^ f(hr), f = hr & 15 (C = 384) / (hr >> 1) & 7 (C = 192)   (bank swizzle)
 //   W2 chunk: [s = 0,1][h = 0,1][row c = 0..C-1][8 elements j]: W2[c][32ch + 16s + 8(j>>2) + 4h + (j&3)]
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -101,30 +102,35 @@ using Flag = std::integral_constant<bool, B>;
 template <int N>
 using Int = std::integral_constant<int, N>;
 
-template <int C, int T>
-__global__ __launch_bounds__(256, 1) void mlp_ln_residual_bf16_kernel(
+template <int C, int T, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void mlp_ln_residual_bf16_kernel(
     const u16* __restrict__ X, int ldx, const u16* __restrict__ Wimg, const float* __restrict__ b1,
     const float* __restrict__ b2, const float* __restrict__ gamma, const float* __restrict__ beta,
     u16* __restrict__ Out, int ldo, int M, float scale) {
   constexpr int HID = 4 * C, NCH = HID / 32, KS = C / 16, RT = C / 32;
   constexpr int WB = 64 * C;                  // bytes of one W1 (or W2) chunk
   constexpr int NS = 3;                       // ring slots per stream
-  constexpr int LPS = WB / 4096;              // LDS-DMA instructions per wave, chunk and stream (1 KB each)
-  constexpr int LPW = 2 * LPS;                // ... per wave and iteration
+  // LDS-DMA instructions (1 KB each) per wave: NW = 4: every wave requests LPS pieces of BOTH streams per iteration; NW = 8
+  // (two waves per SIMD): waves 0-3 request the W1 stream, waves 4-7 the W2 stream, LPS pieces each
+  constexpr int LPS = WB / 4096;
+  constexpr int LPW = NW == 4 ? 2 * LPS : LPS;          // ... per wave and iteration
   constexpr int PLD = 2 * C + 16;             // bytes per row of an epilogue patch
   constexpr int CPR = C / 8;                  // 16-B chunks per activation row
   constexpr int E = 16 * T;                   // GELU elements per lane and chunk: [tt][register]
   static_assert(KS % LPS == 0 && (2 * RT) % LPS == 0 && NCH > 4, "shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const ring1 = smem;                      // W1 stream, NS slots
-  unsigned char* const ring2 = smem + NS * WB;            // W2 stream, NS slots
-  float* const b1s = reinterpret_cast<float*>(smem + 2 * NS * WB);
+  // LDS: [b1 | b2, gamma, beta | W1 ring | W2 ring]; the epilogue's per-wave patches reuse the rings (and may extend past them)
+  float* const b1s = reinterpret_cast<float*>(smem);
   float* const eps = b1s + HID;                           // (b2 |) gamma | beta (C floats each) for the epilogue
+  constexpr int PRE = (HID + 3 * C) * 4;
+  unsigned char* const ring1 = smem + PRE;                // W1 stream, NS slots
+  unsigned char* const ring2 = ring1 + NS * WB;           // W2 stream, NS slots
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
-  const int m0 = blockIdx.x * (128 * T) + wave * (32 * T);
+  const int m0 = blockIdx.x * (32 * T * NW) + wave * (32 * T);
+  const int role = NW == 4 ? -1 : (wave >> 2);             // NW = 8: which stream this wave requests
   const int fsw = C == 384 ? (lr & 15) : ((lr >> 1) & 7);      // this lane's W1 chunk swizzle
 
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -144,16 +150,17 @@ __global__ __launch_bounds__(256, 1) void mlp_ln_residual_bf16_kernel(
   }
   // ---- b1 and the epilogue's per-channel vectors -> LDS (fp32): as global loads in the epilogue (144 per lane, each
   // waited for at its use) they cost a quarter of the kernel
-  for (int i = tid; i < HID / 4; i += 256)
+  for (int i = tid; i < HID / 4; i += 64 * NW)
     reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(b1)[i];
-  for (int i = tid; i < 3 * C / 4; i += 256) {
+  for (int i = tid; i < 3 * C / 4; i += 64 * NW) {
     const int which = i / (C / 4), j = i - which * (C / 4);
     reinterpret_cast<f32x4*>(eps)[i] = reinterpret_cast<const f32x4*>(which == 0 ? b2 : which == 1 ? gamma : beta)[j];
   }
 
   // piece i (0 .. LPS-1) of this wave for chunk ch of stream st (0 = W1, 1 = W2) -> ring slot `slot` of that stream
   auto issue_piece = [&](int st, int ch, int slot, int i) {
-    const int q = i * 4 + wave;
+    if (NW == 8 && st != role) return;
+    const int q = i * 4 + (wave & 3);
     auto dst = (__attribute__((address_space(3))) void*)((st ? ring2 : ring1) + slot * WB + q * 1024);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, dst, 16, lane * 16, (st * NCH + ch) * WB + q * 1024, 0, 0);
   };
@@ -361,11 +368,12 @@ __global__ __launch_bounds__(256, 1) void mlp_ln_residual_bf16_kernel(
     a = a + 1 == NS ? 0 : a + 1;
   }
   // ---- drain: chunks NCH-2, NCH-1 request no W1 any more; then two iterations without a first product
+  // (NW = 8: the two request streams sit on different waves; the drain simply waits for everything)
   sync(Int<LPW>{});
   iteration(NCH - 2, (NCH - 2) % NS, Y{}, Y{}, Y{}, N_{}, Y{});
-  sync(Int<LPS>{});
+  sync(Int<NW == 4 ? LPS : 0>{});
   iteration(NCH - 1, (NCH - 1) % NS, Y{}, Y{}, Y{}, N_{}, Y{});
-  sync(Int<LPS>{});
+  sync(Int<NW == 4 ? LPS : 0>{});
   iteration(NCH, NCH % NS, Y{}, Y{}, N_{}, N_{}, N_{});
   sync(Int<0>{});
   iteration(NCH + 1, (NCH + 1) % NS, Y{}, N_{}, N_{}, N_{}, N_{});
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ln_residual_bf16_kernel(
 #endif
 
   // ---- epilogue: lane holds Y^T[c = 32rt + (i&3) + 8(i>>2) + 4lh][token m0 + 32tt + lr]
-  unsigned char* patch = smem + wave * (32 * PLD);
+  unsigned char* patch = ring1 + wave * (32 * PLD);
   const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       Out, 0, (int)(((size_t)(M - 1) * ldo + C) * sizeof(u16)), 0x00020000);
 #pragma unroll
@@ -448,17 +456,17 @@ __global__ __launch_bounds__(256, 1) void mlp_ln_residual_bf16_kernel(
 #endif
 }
 
-template <int C, int T>
+template <int C, int T, int NW>
 int launch_mlp(hipStream_t s, const u16* x, int ldx, const u16* wimg, const float* b1, const float* b2,
                const float* gamma, const float* beta, u16* out, int ldo, int M, float scale) {
-  constexpr size_t ring = (size_t)6 * 64 * C + 7 * C * sizeof(float);
-  constexpr size_t epi = (size_t)4 * 32 * (2 * C + 16);
-  constexpr size_t shm = ring > epi ? ring : epi;
+  constexpr size_t ring = (size_t)6 * 64 * C;
+  constexpr size_t epi = (size_t)NW * 32 * (2 * C + 16);
+  constexpr size_t shm = 7 * C * sizeof(float) + (ring > epi ? ring : epi);
   static_assert(shm <= 160 * 1024, "LDS");
-  auto kern = mlp_ln_residual_bf16_kernel<C, T>;
+  auto kern = mlp_ln_residual_bf16_kernel<C, T, NW>;
   PANGU_ENSURE_DYN_LDS(kern, shm);
-  const int grid = (M + 128 * T - 1) / (128 * T);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shm, s, x, ldx, wimg, b1, b2, gamma, beta, out, ldo, M, scale);
+  const int grid = (M + 32 * T * NW - 1) / (32 * T * NW);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), shm, s, x, ldx, wimg, b1, b2, gamma, beta, out, ldo, M, scale);
   return pangu_launch_status();
 }
 
@@ -471,12 +479,18 @@ extern "C" int pangu_mlp_ln_residual_fwd_bf16(pangu_stream_t stream, const void*
   if (M <= 0 || ldx < C || ldo < C || (ldx & 7) || (ldo & 7)) return PANGU_E_SHAPE;
   if (!pangu_fits_u32(M, ldx, 2) || !pangu_fits_u32(M, ldo, 2)) return PANGU_E_RANGE;
   hipStream_t s = (hipStream_t)stream;
-  if (C == 192)
-    return launch_mlp<192, 2>(s, (const u16*)x, ldx, (const u16*)w_packed, b1, b2, gamma, beta, (u16*)out, ldo, M,
-                              branch_scale);
+  if (C == 192) {
+    // A/B knob: 4 waves x 64 tokens (one wave per SIMD, 512 registers) or 8 waves x 32 tokens (two per SIMD, 256 registers)
+    static const int nw = getenv("PANGU_MLP_NW192") ? atoi(getenv("PANGU_MLP_NW192")) : 4;
+    if (nw == 8)
+      return launch_mlp<192, 1, 8>(s, (const u16*)x, ldx, (const u16*)w_packed, b1, b2, gamma, beta, (u16*)out, ldo, M,
+                                   branch_scale);
+    return launch_mlp<192, 2, 4>(s, (const u16*)x, ldx, (const u16*)w_packed, b1, b2, gamma, beta, (u16*)out, ldo, M,
+                                 branch_scale);
+  }
   if (C == 384)
-    return launch_mlp<384, 1>(s, (const u16*)x, ldx, (const u16*)w_packed, b1, b2, gamma, beta, (u16*)out, ldo, M,
-                              branch_scale);
+    return launch_mlp<384, 1, 4>(s, (const u16*)x, ldx, (const u16*)w_packed, b1, b2, gamma, beta, (u16*)out, ldo, M,
+                                 branch_scale);
   return PANGU_E_SHAPE;
 }
 
