@@ -201,7 +201,7 @@ extern "C" int pangu_linear_wgrad(pangu_stream_t stream, const float* dC, int ld
   static const int dma_target = getenv("PANGU_WGRAD_DMA_WGS") ? atoi(getenv("PANGU_WGRAD_DMA_WGS")) : 768;    // measured sweep 768 / 1024 / 1536 / 2048: 768 best (1536 within 1 %)
   if (use_dma) {
     const int rc = pangu_linear_wgrad_f32_dma(s, dC, lddc, A, lda, dW, db, M, N, K, wide ? 3 : 2, dma_target);
-    if (rc != 1) return rc;
+    if (rc != -1000) return rc;          // -1000 = PANGU_WGRAD_NOT_COVERED (wgrad_f32_dma.hip): fall through
   }
   if (wide) {
     if (K % 192 == 0) return launch_wgrad<3, 3>(s, dC, lddc, A, lda, dW, db, M, N, K);

@@ -155,13 +155,15 @@ int launch_wgrad_dma(hipStream_t s, const float* dC, int lddc, const float* A, i
 
 }  // namespace
 
-// -> PANGU_OK when launched, 1 when the shape is not covered (the caller falls back to the register-staged kernel)
+// -> PANGU_OK when launched, PANGU_WGRAD_NOT_COVERED (a value no hipError_t or PANGU_E_* takes) when the shape is not
+// covered: the caller falls back to the register-staged kernel; every other non-zero code is a real launch error
+constexpr int PANGU_WGRAD_NOT_COVERED = -1000;
 int pangu_linear_wgrad_f32_dma(hipStream_t s, const float* dC, int lddc, const float* A, int lda, float* dW, float* db,
                                int M, int N, int K, int tnn, int target) {
   // the VGPR byte offset of the last slab's rows (up to M + 15, plus one row of columns) must not wrap 32 bits
-  if (((size_t)M + 32) * (size_t)lddc * 4u >= 0xFFFFFFFFull || ((size_t)M + 32) * (size_t)lda * 4u >= 0xFFFFFFFFull) return 1;
-  if (K % 192 != 0) return 1;
+  if (((size_t)M + 32) * (size_t)lddc * 4u >= 0xFFFFFFFFull || ((size_t)M + 32) * (size_t)lda * 4u >= 0xFFFFFFFFull) return PANGU_WGRAD_NOT_COVERED;
+  if (K % 192 != 0) return PANGU_WGRAD_NOT_COVERED;
   if (tnn == 3 && N % 192 == 0) return launch_wgrad_dma<3, 3>(s, dC, lddc, A, lda, dW, db, M, N, K, target);
   if (tnn == 2 && N % 128 == 0) return launch_wgrad_dma<2, 3>(s, dC, lddc, A, lda, dW, db, M, N, K, target);
-  return 1;
+  return PANGU_WGRAD_NOT_COVERED;
 }

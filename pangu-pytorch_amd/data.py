@@ -18,6 +18,7 @@ class DevicePrefetcher:
         self.stream = torch.cuda.Stream(device=self.device)
         self.depth = depth
         self._pinned = [None] * depth          # per slot: list of pinned host buffers
+        self._busy = [None] * depth            # per slot: event of the last host->device copy that read those buffers
         self._slot = 0
 
     def __len__(self):
@@ -27,6 +28,8 @@ class DevicePrefetcher:
         slot = self._slot
         self._slot = (slot + 1) % self.depth
         tensors = [t for t in batch if torch.is_tensor(t)]
+        if self._busy[slot] is not None:
+            self._busy[slot].synchronize()      # the async copy of the batch staged here `depth` batches ago must be done
         if self._pinned[slot] is None or any(p.shape != t.shape or p.dtype != t.dtype
                                              for p, t in zip(self._pinned[slot], tensors)):
             self._pinned[slot] = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in tensors]
@@ -45,6 +48,7 @@ class DevicePrefetcher:
                 out.append(d)
         ev = torch.cuda.Event()
         ev.record(self.stream)
+        self._busy[slot] = ev
         return out, ev
 
     def __iter__(self):

@@ -29,12 +29,16 @@ class DropPath(nn.Module):
     def __init__(self, drop_prob=0.0):
         super().__init__()
         self.drop_prob = float(drop_prob)
+        self.n_dropped = 0           # branches dropped so far (diagnostic)
 
     def sample_scale(self, training):
         if not training or self.drop_prob == 0.0:
             return 1.0
         keep = 1.0 - self.drop_prob
-        return (1.0 / keep) if torch.rand(()).item() < keep else 0.0
+        if torch.rand(()).item() < keep:
+            return 1.0 / keep
+        self.n_dropped += 1
+        return 0.0
 
     def extra_repr(self):
         return f"drop_prob={self.drop_prob:.3f}"

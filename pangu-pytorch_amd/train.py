@@ -46,5 +46,12 @@ def train_step(model, optimizer, batch, statistics, maps, const_h, stats_last=No
     loss.backward()
     if grad_sync is not None:
         grad_sync()
+    else:
+        # a DropPath-dropped branch is not computed here, so its parameters come back without a gradient; the reference
+        # computes the branch, multiplies by zero and hands Adam ZERO gradients (moments decay, weight decay applies)
+        for group in optimizer.param_groups:
+            for p in group["params"]:
+                if p.requires_grad and p.grad is None:
+                    p.grad = torch.zeros_like(p)
     optimizer.step()
     return loss.detach()

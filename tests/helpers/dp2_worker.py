@@ -30,6 +30,7 @@ def one_backward(model, rank, sync=None):
     out, out_s = model(inp, inp_s, stats, maps, const_h)
     train.weighted_l1_loss(out, out_s, tgt, tgt_s).backward()
     if sync is not None:
+        sync.launched_in_backward = sync._next       # buckets whose all-reduce was issued from the backward hooks
         sync.finish()
 
 
@@ -48,7 +49,10 @@ def main():
     names = {id(p): n for n, p in model.named_parameters()}
     assert all(p.grad.data_ptr() == sync._slot[p][1].data_ptr() for p in model.parameters())
     total = sync.flat.numel() * 4
-    info = {"copied_bytes": sync.copied_bytes, "flat_bytes": total,
+    dropped = sum(getattr(m, "n_dropped", 0) for m in model.modules())
+    pattern = [(n, m.n_dropped) for n, m in model.named_modules() if getattr(m, "n_dropped", 0)]
+    info = {"copied_bytes": sync.copied_bytes, "flat_bytes": total, "launched_in_backward": sync.launched_in_backward,
+            "buckets": len(sync.buckets), "dropped_branches": dropped, "pattern": pattern,
             "order": [names[id(b[2][0][0])] for b in sync.buckets][:3]}
     if rank == 0:
         torch.save({"flat": sync.flat.cpu(), "info": info}, os.path.join(out_dir, "dp2.pt"))
