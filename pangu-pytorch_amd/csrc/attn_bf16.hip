@@ -271,7 +271,7 @@ __global__ __launch_bounds__(192, 3) void window_attn_bf16_kernel(const u16* __r
 //   * the biases are the accumulators' initial values; then the three query tiles of the wave run through attn_tile
 //     exactly as in the kernel above.
 constexpr int QK_ROWS = PANGU_WTOK + 96;                 // rows of one ring slot: 144 x rows, then q/k/v weight rows
-constexpr int QK_SLOT = QK_ROWS * 64;
+constexpr int QK_SLOT = QK_ROWS * 64;                    // slot bytes at 32 channels per K-step (BK = 64: twice that)
 
 __device__ inline int kswz64(int row, int chunk) {      // 64-byte rows, 4 chunks: F = {0,2,3,1}[(row>>2)&3]
   const int f = (0x78 >> (((row >> 2) & 3) * 2)) & 3;
@@ -281,14 +281,22 @@ __device__ inline int kswz64(int row, int chunk) {      // 64-byte rows, 4 chunk
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <bool SHIFTED, int C, int QK_RING>
+// BK = input channels per K-step (32: 64-byte slot rows; 64: 128-byte rows, half as many steps / barriers / DMA round trips);
+// QK_RING = 1: one slot (request, wait, compute: other workgroups cover the round trip), 2 / 3: steps requested ahead.
+template <bool SHIFTED, int C, int QK_RING, int BK>
 __global__ __launch_bounds__(192, 2) void window_attn_qkv_bf16_kernel(const u16* __restrict__ x, int ldx,
                                                                       const u16* __restrict__ wqkv,
                                                                       const float* __restrict__ bqkv,
                                                                       const u16* __restrict__ esb, u16* __restrict__ out,
                                                                       float* __restrict__ lse, WinGeom g, int n_tok,
                                                                       int heads, int n_pairs) {
-  constexpr int KS = C / 32;
+  constexpr int KS = C / BK;
+  constexpr int CH = BK / 8;                 // 16-B chunks per slot row
+  constexpr int ROWB = BK * 2;               // bytes per slot row
+  constexpr int SLOT = QK_ROWS * ROWB;
+  constexpr int RPI = 1024 / ROWB;           // rows per LDS-DMA instruction (1 KB)
+  constexpr int NIW = QK_ROWS / RPI / 3;     // instructions per wave and step
+  constexpr int NIX = PANGU_WTOK / RPI;      // the first NIX instructions of a step carry x rows, the rest weight rows
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // the K / V^T images REUSE the ring's memory (they are written after the K-loop, behind a barrier): 45 KB per workgroup
   // with a ring of 3, so three workgroups per CU each keep two K-steps of LDS-DMA in flight -- the loop is bound by the
@@ -318,17 +326,17 @@ __global__ __launch_bounds__(192, 2) void window_attn_qkv_bf16_kernel(const u16*
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<u16*>(wqkv), 0, 3 * C * C * (int)sizeof(u16), 0x00020000);
 
-  // ---- LDS-DMA plan: instruction q covers ring rows 16q .. 16q+15 (1 KB); q = 0..8 the x rows, 9..14 the weight rows.
-  // Wave w issues q = w, w+3, .. (five per step).  This lane fills (row 16q + lane>>2, physical chunk lane&3) with the
-  // logical chunk (lane&3) ^ F(row).
-  unsigned voff[5];
+  // ---- LDS-DMA plan: instruction q covers slot rows RPI q .. RPI q + RPI - 1 (1 KB); q < NIX the x rows, then the weight rows.
+  // Wave w issues q = w, w+3, ..  This lane fills (row RPI q + lane / CH, physical chunk lane % CH) with the logical chunk
+  // (lane % CH) ^ F(row): 64-byte rows F = {0,2,3,1}[(row>>2)&3], 128-byte rows F = (row>>1)&7 (conflict-free b128 reads).
+  auto fsw = [](int row) { return BK == 32 ? ((0x78 >> (((row >> 2) & 3) * 2)) & 3) : ((row >> 1) & 7); };
+  unsigned voff[NIW];
 #pragma unroll
-  for (int i = 0; i < 5; ++i) {
+  for (int i = 0; i < NIW; ++i) {
     const int q = wave + 3 * i;
-    const int row = 16 * q + (lane >> 2);
-    const int f = (0x78 >> (((row >> 2) & 3) * 2)) & 3;
-    const int c = (lane & 3) ^ f;
-    if (q < 9) {
+    const int row = RPI * q + lane / CH;
+    const int c = (lane % CH) ^ fsw(row);
+    if (q < NIX) {
       const int tok = win_src_token(g, l, t, row, SHIFTED);
       voff[i] = tok >= 0 ? ((unsigned)tok * (unsigned)ldx + c * 8) * 2u : 0x7FFFFFF0u;       // pad row: out of range -> zeros
     } else {
@@ -337,16 +345,16 @@ __global__ __launch_bounds__(192, 2) void window_attn_qkv_bf16_kernel(const u16*
     }
   }
   auto issue = [&](int ks) {
-    unsigned char* base = ring + (ks % QK_RING) * QK_SLOT;
+    unsigned char* base = ring + (ks % QK_RING) * SLOT;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < NIW; ++i) {
       const int q = wave + 3 * i;
       auto dst = (__attribute__((address_space(3))) void*)(base + q * 1024);
-      if (q < 9) __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, dst, 16, (int)voff[i], ks * 64, 0, 0);
-      else __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, dst, 16, (int)voff[i], ks * 64, 0, 0);
+      if (q < NIX) __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, dst, 16, (int)voff[i], ks * ROWB, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, dst, 16, (int)voff[i], ks * ROWB, 0, 0);
     }
   };
-  issue(0);
+  if (QK_RING >= 2) issue(0);
   if (QK_RING >= 3) issue(1);
 
   // the first tile's bias row and the query-token indices are requested / computed under the K-loop
@@ -372,27 +380,48 @@ __global__ __launch_bounds__(192, 2) void window_attn_qkv_bf16_kernel(const u16*
   }
 
   for (int ks = 0; ks < KS; ++ks) {
-    if (QK_RING >= 3 && ks + 1 < KS) wait_vmcnt<5>(); else wait_vmcnt<0>();     // step ks landed (ring of 3: step ks+1 may fly)
-    // every fragment read of the previous step must have RETURNED before this wave releases the barrier: behind it the other
-    // waves re-request that ring slot, and an LDS-DMA write can overtake a ds_read that is still queued (seen on MI355X as
-    // ~1 wrong workgroup in 3000 when the compiler had sunk the last reads' wait below the barrier)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();                                // ... for every wave; the slot of step ks-1 is free
-    asm volatile("" ::: "memory");
-    if (ks + QK_RING - 1 < KS) issue(ks + QK_RING - 1);
-    const unsigned char* slot = ring + (ks % QK_RING) * QK_SLOT;
-    bf16x8 fx[3], fw[6];
+    if (QK_RING == 1) {
+      // one slot: every wave is done reading it (barrier), request step ks, wait for it, barrier, compute
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issue(ks);
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    } else {
+      if (QK_RING >= 3 && ks + 1 < KS) wait_vmcnt<NIW>(); else wait_vmcnt<0>();   // step ks landed (ring of 3: step ks+1 may fly)
+      // every fragment read of the previous step must have RETURNED before this wave releases the barrier: behind it the
+      // other waves re-request that ring slot, and an LDS-DMA write can overtake a ds_read that is still queued (seen on
+      // MI355X as ~1 wrong workgroup in 3000 when the compiler had sunk the last reads' wait below the barrier)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();                                // ... for every wave; the slot of step ks-1 is free
+      asm volatile("" ::: "memory");
+      if (ks + QK_RING - 1 < KS) issue(ks + QK_RING - 1);
+    }
+    const unsigned char* slot = ring + (ks % QK_RING) * SLOT;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) fx[i] = *reinterpret_cast<const bf16x8*>(slot + kswz64((tile0 + i) * 16 + lq, lg));
+    for (int kk = 0; kk < BK / 32; ++kk) {
+      bf16x8 fx[3], fw[6];
 #pragma unroll
-    for (int rt = 0; rt < 6; ++rt) fw[rt] = *reinterpret_cast<const bf16x8*>(slot + kswz64(PANGU_WTOK + rt * 16 + lq, lg));
+      for (int i = 0; i < 3; ++i) {
+        const int row = (tile0 + i) * 16 + lq;
+        fx[i] = *reinterpret_cast<const bf16x8*>(slot + row * ROWB + (((kk * 4 + lg) ^ fsw(row)) << 4));
+      }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+      for (int rt = 0; rt < 6; ++rt) {
+        const int row = PANGU_WTOK + rt * 16 + lq;
+        fw[rt] = *reinterpret_cast<const bf16x8*>(slot + row * ROWB + (((kk * 4 + lg) ^ fsw(row)) << 4));
+      }
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) acc[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[rt], fx[i], acc[rt][i], 0, 0, 0);
+      for (int i = 0; i < 3; ++i) {
 #pragma unroll
-      for (int rt = 4; rt < 6; ++rt) acc[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[i], fw[rt], acc[rt][i], 0, 0, 0);
+        for (int rt = 0; rt < 4; ++rt) acc[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[rt], fx[i], acc[rt][i], 0, 0, 0);
+#pragma unroll
+        for (int rt = 4; rt < 6; ++rt) acc[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[i], fw[rt], acc[rt][i], 0, 0, 0);
+      }
     }
   }
 
@@ -470,22 +499,26 @@ extern "C" int pangu_window_attn_qkv_fwd_bf16(pangu_stream_t stream, const void*
   const WinGeom g = make_geom(Z, H, W);
   const int n_pairs = g.types * heads;
   const int grid = ((g.types + 7) / 8) * 8 * g.nLon * heads;
-  static const int ring = getenv("PANGU_ATTN_QKV_RING") ? atoi(getenv("PANGU_ATTN_QKV_RING")) : 2;      // A/B knob (2: four workgroups per CU -- 142 VGPRs; forcing 128 for five spills and loses 7 %; 3: three workgroups, two steps in flight, -5 %)
-  const size_t shm = (size_t)(ring == 3 ? 3 : 2) * QK_SLOT;                       // >= the K + V^T images (19968 B) that reuse it
+  // A/B knob PANGU_ATTN_QKV_MODE = <ring><bk/32>: 21 (default) ring of 2 x 32 channels, four workgroups per CU; 31 ring of 3;
+  // 12 one slot of 64 channels (half the steps); 22 ring of 2 x 64 channels (two workgroups per CU)
+  static const int mode = getenv("PANGU_ATTN_QKV_MODE") ? atoi(getenv("PANGU_ATTN_QKV_MODE")) : 21;
+  const int ring = mode / 10, bk = (mode % 10) * 32;
+  if ((ring != 1 && ring != 2 && ring != 3) || (bk != 32 && bk != 64) || (ring == 3 && bk == 64) || (ring == 1 && bk == 32)) return PANGU_E_ARG;
+  const size_t shm = (size_t)ring * QK_SLOT * (bk / 32);                          // >= the K + V^T images (19968 B) that reuse it
   hipStream_t s = (hipStream_t)stream;
-#define PANGU_QKV_LAUNCH(SH, CC)                                                                                          \
+#define PANGU_QKV_LAUNCH1(SH, CC, RG, BKK)                                                                                \
   do {                                                                                                                    \
-    if (ring == 3) {                                                                                                      \
-      auto kern = window_attn_qkv_bf16_kernel<SH, CC, 3>;                                                                 \
-      PANGU_ENSURE_DYN_LDS(kern, shm);                                                                                    \
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(192), shm, s, (const u16*)x, ldx, (const u16*)w_qkv, b_qkv,               \
-                         (const u16*)esb, (u16*)out, lse, g, n_tok, heads, n_pairs);                                      \
-      break;                                                                                                              \
-    }                                                                                                                     \
-    auto kern = window_attn_qkv_bf16_kernel<SH, CC, 2>;                                                                    \
+    auto kern = window_attn_qkv_bf16_kernel<SH, CC, RG, BKK>;                                                             \
     PANGU_ENSURE_DYN_LDS(kern, shm);                                                                                      \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(192), shm, s, (const u16*)x, ldx, (const u16*)w_qkv, b_qkv,                 \
                        (const u16*)esb, (u16*)out, lse, g, n_tok, heads, n_pairs);                                        \
+  } while (0)
+#define PANGU_QKV_LAUNCH(SH, CC)                                                                                          \
+  do {                                                                                                                    \
+    if (mode == 31) PANGU_QKV_LAUNCH1(SH, CC, 3, 32);                                                                     \
+    else if (mode == 12) PANGU_QKV_LAUNCH1(SH, CC, 1, 64);                                                                \
+    else if (mode == 22) PANGU_QKV_LAUNCH1(SH, CC, 2, 64);                                                                \
+    else PANGU_QKV_LAUNCH1(SH, CC, 2, 32);                                                                                \
   } while (0)
   if (C == 192) {
     if (shifted) PANGU_QKV_LAUNCH(true, 192); else PANGU_QKV_LAUNCH(false, 192);
@@ -493,5 +526,6 @@ extern "C" int pangu_window_attn_qkv_fwd_bf16(pangu_stream_t stream, const void*
     if (shifted) PANGU_QKV_LAUNCH(true, 384); else PANGU_QKV_LAUNCH(false, 384);
   }
 #undef PANGU_QKV_LAUNCH
+#undef PANGU_QKV_LAUNCH1
   return pangu_launch_status();
 }

@@ -193,7 +193,7 @@ def test_window_attention_bf16(P, C, shifted):
 
 @pytest.mark.parametrize("C", [192, 384])
 @pytest.mark.parametrize("shifted", [False, True])
-@pytest.mark.parametrize("ring", ["2", "3"])
+@pytest.mark.parametrize("ring", ["2", "31", "12", "22"])
 def test_window_attention_qkv_fused_bf16(P, C, shifted, ring, monkeypatch):
     """QKV projection fused into the attention kernel (csrc/attn_bf16.hip window_attn_qkv_bf16_kernel) == Linear ->
     window attention (reference layers.py:365-415) on the same bf16-rounded operands: q, k, v are rounded to bf16 once,
@@ -210,7 +210,7 @@ def test_window_attention_qkv_fused_bf16(P, C, shifted, ring, monkeypatch):
     ref, ref_lse = O.window_attention_core(qkv.float()[None], b.to(BF).float(), esb.float(), Z, H, W, heads, shifted)
     # the oracle takes the pad rows' q/k/v from the (bf16-rounded) bias, the kernel computes them as 0 @ W + b -> same value
     got, lse = ob.window_attention_qkv(x.cuda(), w.cuda(), b.cuda(), esb[0].cuda(), Z, H, W, heads, shifted, want_lse=True) \
-        if ring == "2" else _attn_qkv_ring3(ob, x, w, b, esb, Z, H, W, heads, shifted)
+        if ring == "2" else _attn_qkv_ring3(ob, x, w, b, esb, Z, H, W, heads, shifted, ring)
     assert rel_err(got, ref[0]) < ROUND
     assert rel_err(lse, ref_lse[0]) < 2e-3                 # scores from bf16 q, k: same inputs, fp32 accumulation order differs
     # and the two-launch path on the GPU agrees
@@ -218,8 +218,8 @@ def test_window_attention_qkv_fused_bf16(P, C, shifted, ring, monkeypatch):
     assert rel_err(got, two) < ROUND
 
 
-def _attn_qkv_ring3(ob, x, w, b, esb, Z, H, W, heads, shifted):
-    """The ring-of-3 instantiation is chosen by an environment variable read once per process: run it in a child."""
+def _attn_qkv_ring3(ob, x, w, b, esb, Z, H, W, heads, shifted, ring):
+    """The other pipeline instantiations are chosen by an environment variable read once per process: run them in a child."""
     import subprocess
     import sys
     import tempfile
@@ -230,7 +230,7 @@ def _attn_qkv_ring3(ob, x, w, b, esb, Z, H, W, heads, shifted):
                 "o, l = ob.window_attention_qkv(x.cuda(), w.cuda(), b.cuda(), esb[0].cuda(), Z, H, W, heads, shifted, want_lse=True)\n"
                 "torch.save((o.cpu(), l.cpu()), %r)\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                           os.path.join(d, "in.pt"), os.path.join(d, "out.pt"))
-        subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, PANGU_ATTN_QKV_RING="3"))
+        subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, PANGU_ATTN_QKV_MODE=ring))
         o, l = torch.load(os.path.join(d, "out.pt"))
     return o.cuda(), l.cuda()
 
