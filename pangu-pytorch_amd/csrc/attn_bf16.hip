@@ -281,6 +281,20 @@ __device__ inline int kswz64(int row, int chunk) {      // 64-byte rows, 4 chunk
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+#ifdef PANGU_ATTN_STAMP
+// Diagnostic build only (tools/ablate_attn.py): s_memtime sums over all waves: [0] K-loop, [1] q/K/V staging + barrier,
+// [2] the three attention tiles, [3] whole kernel, [4] waves, [5] prologue up to the first K-step.
+constexpr int STAMP_WAVES = 80000;
+__device__ unsigned long long g_attn_stamp[STAMP_WAVES * 8];      // per wave: no atomics (they would dominate the timing)
+__device__ __forceinline__ unsigned long long attn_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#endif
+
 // BK = input channels per K-step (32: 64-byte slot rows; 64: 128-byte rows, half as many steps / barriers / DMA round trips);
 // QK_RING = 1: one slot (request, wait, compute: other workgroups cover the round trip), 2 / 3: steps requested ahead.
 template <bool SHIFTED, int C, int QK_RING, int BK>
@@ -290,6 +304,9 @@ __global__ __launch_bounds__(192, 2) void window_attn_qkv_bf16_kernel(const u16*
                                                                       const u16* __restrict__ esb, u16* __restrict__ out,
                                                                       float* __restrict__ lse, WinGeom g, int n_tok,
                                                                       int heads, int n_pairs) {
+#ifdef PANGU_ATTN_STAMP
+  const unsigned long long st0 = attn_stamp();
+#endif
   constexpr int KS = C / BK;
   constexpr int CH = BK / 8;                 // 16-B chunks per slot row
   constexpr int ROWB = BK * 2;               // bytes per slot row
@@ -379,6 +396,9 @@ __global__ __launch_bounds__(192, 2) void window_attn_qkv_bf16_kernel(const u16*
     for (int i = 0; i < 3; ++i) acc[rt][i] = f32x4{bv, bv, bv, bv};
   }
 
+#ifdef PANGU_ATTN_STAMP
+  const unsigned long long st1 = attn_stamp();
+#endif
   for (int ks = 0; ks < KS; ++ks) {
     if (QK_RING == 1) {
       // one slot: every wave is done reading it (barrier), request step ks, wait for it, barrier, compute
@@ -425,6 +445,9 @@ __global__ __launch_bounds__(192, 2) void window_attn_qkv_bf16_kernel(const u16*
     }
   }
 
+#ifdef PANGU_ATTN_STAMP
+  const unsigned long long st2 = attn_stamp();
+#endif
   // ---- q fragments (registers), K image and V^T image (LDS, over the ring: every wave must be done reading it)
   BiasRow b0 = load_bias_row(bias_tile, tile0 * 16 + lq, lg);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -460,12 +483,22 @@ __global__ __launch_bounds__(192, 2) void window_attn_qkv_bf16_kernel(const u16*
       }
   }
   __syncthreads();
+#ifdef PANGU_ATTN_STAMP
+  const unsigned long long st3 = attn_stamp();
+#endif
 
   const BiasRow b1 = load_bias_row(bias_tile, (tile0 + 1) * 16 + lq, lg);
   attn_tile<SHIFTED>(Ks, Vt, qf[0], b0, tile0 * 16 + lq, qtok[0], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
   b0 = load_bias_row(bias_tile, (tile0 + 2) * 16 + lq, lg);
   attn_tile<SHIFTED>(Ks, Vt, qf[1], b1, (tile0 + 1) * 16 + lq, qtok[1], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
   attn_tile<SHIFTED>(Ks, Vt, qf[2], b0, (tile0 + 2) * 16 + lq, qtok[2], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
+#ifdef PANGU_ATTN_STAMP
+  const unsigned long long st4 = attn_stamp();
+  if (lane == 0 && (int)(blockIdx.x * 3 + wave) < STAMP_WAVES) {
+    unsigned long long* d = g_attn_stamp + (size_t)(blockIdx.x * 3 + wave) * 8;
+    d[0] = st2 - st1; d[1] = st3 - st2; d[2] = st4 - st3; d[3] = st4 - st0; d[4] = 1ull; d[5] = st1 - st0;
+  }
+#endif
 }
 
 }  // namespace
@@ -529,3 +562,17 @@ extern "C" int pangu_window_attn_qkv_fwd_bf16(pangu_stream_t stream, const void*
 #undef PANGU_QKV_LAUNCH1
   return pangu_launch_status();
 }
+
+#ifdef PANGU_ATTN_STAMP
+extern "C" int pangu_attn_stamp_read(unsigned long long* out8) {
+  (void)hipDeviceSynchronize();
+  static unsigned long long host[STAMP_WAVES * 8];
+  (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_stamp), sizeof(host));
+  for (int k = 0; k < 8; ++k) out8[k] = 0;
+  for (int w = 0; w < STAMP_WAVES; ++w)
+    for (int k = 0; k < 8; ++k) out8[k] += host[(size_t)w * 8 + k];
+  for (size_t i = 0; i < (size_t)STAMP_WAVES * 8; ++i) host[i] = 0;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamp), host, sizeof(host));
+  return 0;
+}
+#endif
