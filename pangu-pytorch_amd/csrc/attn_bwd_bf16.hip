@@ -8,6 +8,7 @@
 // token-major images K^T, Q^T, dO^T ([32 d][160 tokens], 336-B rows) that the staging pass writes next to the
 // row-major ones.  66 MFMAs per wave and window: the kernel is bound by the exp/softmax VALU work and HBM.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -280,6 +281,293 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_bf16_kernel(
   for (int j = 0; j < 9; ++j) *reinterpret_cast<f32x4*>(drow + j * 16) = dbias[j];
 }
 
+
+// ===================================================================================================================
+// v2 (round 2): ONE score orientation.  Wave w owns KEY tile w in phase 1: S = Q K^T and dP = dO V^T with the key on
+// the lane, so P and dS (two adjacent query tiles' accumulator quads = one 8-token operand) feed dV^T += dO^T P and
+// dK^T += Q^T dS directly; dS (bf16) crosses LDS ONCE as a [key][query] image for phase 2, where wave w owns QUERY tile
+// w: dQ^T += K^T dS^T.  The operands whose k index runs over tokens (dO^T, Q^T, K^T, dS^T) are read from the ROW-major
+// images with ds_read_b64_tr_b16 (hardware transpose): no transposed copies, no 2-byte scatter writes in the staging
+// pass (v1: 24 ds_write_b16 per thread and window, 44 % bank-conflict cycles), half the exp / softmax VALU work and
+// 48 instead of 66 MFMAs per wave and window.  d_esb stays in registers over the longitude windows (key tile w x all
+// query tiles).  The next window's q/k/v/dO/O rows are requested before the compute phases and written to LDS after
+// them (register prefetch): the HBM latency of the staging pass runs under the MFMAs.  Bias tile transposed in LDS
+// ([key][query]: one 8-byte read per score tile).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int DS_LD = 288;                       // bytes per row of the [key][query] bf16 images (dS, bias^T)
+constexpr int DSIMG = PANGU_WTOK * DS_LD;
+constexpr int DB2_LDS = 4, DB2_REG = 9 - DB2_LDS;
+// LDS map (byte offsets from the start of the dynamic region).  Every access below is (one lane-constant base
+// register) + (compile-time immediate < 64 KB): the bases are made opaque to the compiler, which otherwise keeps one
+// precomputed address register per (image, tile) alive across the window loop -- 40 registers at the 168-VGPR cap
+constexpr int L_ROW = 0;                         // lse_s, del_s (float[144] each), tok_s (int[144]), pad_s (float[64])
+constexpr int L_IMG = 2048;                      // Kr, Vr, Qr, Gr: row-major [144][32] bf16, 16-B chunks swizzled
+constexpr int L_DS = L_IMG + 4 * ROWIMG;         // dS of the current window, [key][query] bf16
+constexpr int L_BT = L_DS + DSIMG;               // bias tile transposed, [key][query] bf16
+constexpr int L_DB = L_BT + DSIMG;               // d_esb quads that do not fit the register file (lane-private)
+constexpr int L_END = L_DB + DB2_LDS * NT * 16;
+constexpr int I_K = 0, I_V = ROWIMG, I_Q = 2 * ROWIMG, I_G = 3 * ROWIMG;
+
+template <typename T>
+__device__ inline __attribute__((address_space(3))) T* ldsp(unsigned off) {
+  return (__attribute__((address_space(3))) T*)(off);
+}
+__device__ inline s16x4 tr16(unsigned off) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(ldsp<s16x4>(off));
+}
+__device__ inline bf16x8 cat8(s16x4 a, s16x4 b) { return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+__device__ inline unsigned opaque(unsigned v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+template <bool SHIFTED>
+__global__ __launch_bounds__(NT) void window_attn_bwd2_bf16_kernel(
+    const u16* __restrict__ qkv, const u16* __restrict__ qkv_bias, const u16* __restrict__ esb,
+    const u16* __restrict__ out, const float* __restrict__ lse, const u16* __restrict__ dout, u16* __restrict__ dqkv,
+    float* __restrict__ dqkv_bias, float* __restrict__ d_esb, WinGeom g, int C, int heads) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned L0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+  int pair = blockIdx.x;
+  if (!(heads & 1)) {
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    pair = 2 * ((local >> 1) * 8 + xcd) + (local & 1);
+  }
+  if (pair >= g.types * heads) return;
+  const int t = pair / heads, hd = pair - t * heads;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 15, lg = lane >> 4;
+  const int C3 = 3 * C;
+  const float scale = 0.17677669529663687f;
+  constexpr float K_LOG2E = 1.4426950408889634f;
+  const float scale2 = scale * K_LOG2E;
+  constexpr float K_MASK2 = -100.0f * K_LOG2E;
+  const u16* bias_tile = esb + (size_t)pair * PANGU_WTOK * PANGU_WTOK;
+
+  bool zcut = false, hcut = false;
+  if (SHIFTED) {
+    const int zwin = t / g.nHw, hwin = t - zwin * g.nHw;
+    zcut = zwin == g.nZw - 1;
+    hcut = hwin == g.nHw - 1;
+  }
+  auto masked = [&](int nq, int nk) -> bool {
+    const bool zd = (nq >= 72) != (nk >= 72);
+    const bool hdiff = (((nq / 12) % 6) < 3) != (((nk / 12) % 6) < 3);
+    return (zcut && zd) || (hcut && hdiff);
+  };
+  // the mask is window-invariant and the same for the 4 queries 16i + 4lg + r of a lane (the cuts fall on multiples of
+  // 12 and at 72): one bit per query tile against this lane's key, built once
+  const int kn = wave * 16 + lq;
+  unsigned mbits = 0u;
+  if (SHIFTED) {
+    if (zcut || hcut)
+      for (int i = 0; i < 9; ++i)
+        if (masked(i * 16 + lg * 4, kn)) mbits |= 1u << i;
+  }
+
+  if (tid < 64) *ldsp<float>(L0 + L_ROW + 1728 + tid * 4) = 0.f;
+  // bias tile -> LDS, transposed: 16-B global reads along the key axis, 2-byte LDS writes (once per workgroup)
+  for (int i = tid; i < PANGU_WTOK * (PANGU_WTOK / 8); i += NT) {
+    const int qn = i / (PANGU_WTOK / 8), c = i - qn * (PANGU_WTOK / 8);
+    const u32x4 b = *reinterpret_cast<const u32x4*>(bias_tile + (size_t)qn * PANGU_WTOK + c * 8);
+    const unsigned o = L0 + L_BT + c * 8 * DS_LD + qn * 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      *ldsp<u16>(o + (2 * e) * DS_LD) = (u16)(b[e] & 0xFFFFu);
+      *ldsp<u16>(o + (2 * e + 1) * DS_LD) = (u16)(b[e] >> 16);
+    }
+  }
+
+  // ---- lane-constant LDS bases
+  const int tq = lq >> 2, tp = lq & 3;      // transposed reads: this lane supplies row tq of its group's block, 4 columns at 4 tp
+  // d 0..15 / 16..31 of a row image, rows tb + 4lg + tq (tb a multiple of 16: the swizzle term does not see it)
+  const unsigned b_trlo = opaque(L0 + L_IMG + kswz(4 * lg + tq, tp >> 1) + 8 * (tp & 1));
+  const unsigned b_trhi = opaque(L0 + L_IMG + kswz(4 * lg + tq, 2 + (tp >> 1)) + 8 * (tp & 1));
+  const unsigned b_trds = opaque(L0 + L_DS + (4 * lg + tq) * DS_LD + wave * 32 + 8 * tp);   // dS: key rows, this wave's queries
+  const unsigned b_kqds = opaque(L0 + L_DS + kn * DS_LD + 8 * lg);     // [key kn][query 16i + 4lg ..] (+ 32 i)
+  const unsigned b_kqbt = opaque(L0 + L_BT + kn * DS_LD + 8 * lg);
+  const unsigned b_row = opaque(L0 + L_IMG + kswz(lq, lg));            // row read of token 16x + lq, chunk lg (+ 1024 x)
+  const unsigned b_ls = opaque(L0 + L_ROW + lg * 16);                  // lse_s / del_s quads of query tile i (+ 64 i)
+  const unsigned b_db = opaque(L0 + L_DB + tid * 16);
+
+  f32x4 dbias[DB2_REG];
+#pragma unroll
+  for (int j = 0; j < DB2_REG; ++j) dbias[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < DB2_LDS; ++j) *ldsp<f32x4>(b_db + j * NT * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- register prefetch of the staging pass: one 16-B chunk (8 dims) of q, k, v, dO, O per thread
+  const int sn = tid >> 2, sch = tid & 3;
+  const unsigned b_st = opaque(L0 + L_IMG + kswz(sn, sch));
+  const unsigned b_sr = opaque(L0 + L_ROW + sn * 4);
+  u32x4 qv, kv, vv, gv, ov;
+  int ptok;
+  float plse;
+  const unsigned ho = hd * 32 + sch * 8;
+  auto request = [&](int l) {
+    // 32-bit element offsets against the uniform base pointers
+    ptok = win_src_token(g, l, t, sn, SHIFTED);
+    const u16* src = ptok >= 0 ? qkv : qkv_bias;
+    const unsigned so = (ptok >= 0 ? (unsigned)ptok * (unsigned)C3 : 0u) + ho;
+    qv = *reinterpret_cast<const u32x4*>(src + so);
+    kv = *reinterpret_cast<const u32x4*>(src + so + (unsigned)C);
+    vv = *reinterpret_cast<const u32x4*>(src + so + 2u * (unsigned)C);
+    gv = u32x4{0u, 0u, 0u, 0u}; ov = gv; plse = 0.f;
+    if (ptok >= 0) {
+      const unsigned go = (unsigned)ptok * (unsigned)C + ho;
+      gv = *reinterpret_cast<const u32x4*>(dout + go);
+      ov = *reinterpret_cast<const u32x4*>(out + go);
+      plse = lse[(unsigned)ptok * (unsigned)heads + (unsigned)hd];
+    }
+  };
+  request(0);
+
+  for (int l = 0; l < g.nLon; ++l) {
+    __syncthreads();                              // the previous window's LDS reads are done
+    {
+      *ldsp<u32x4>(b_st + I_Q) = qv;
+      *ldsp<u32x4>(b_st + I_K) = kv;
+      *ldsp<u32x4>(b_st + I_V) = vv;
+      *ldsp<u32x4>(b_st + I_G) = gv;
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d += bflo(gv[e]) * bflo(ov[e]) + bfhi(gv[e]) * bfhi(ov[e]);
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      if (sch == 0) {
+        // row constants as INITIAL ACCUMULATORS: S' = q.k - lse/scale (p = exp2(S' scale log2e + b log2e)), dP - delta.
+        // A pad query's row of P must vanish (its output is discarded): -huge makes exp2(..) = 0
+        *ldsp<float>(b_sr + 576) = -d;
+        *ldsp<float>(b_sr) = ptok >= 0 ? -plse * (1.0f / scale) : -1e30f;
+        *ldsp<int>(b_sr + 1152) = ptok;
+      }
+    }
+    if (l + 1 < g.nLon) request(l + 1);           // in flight during the two compute phases
+    __syncthreads();
+
+    // =========================== phase 1: key tile `wave`; S[query][key], key on the lane ===========================
+    {
+      const bf16x8 kf = *ldsp<bf16x8>(b_row + I_K + wave * 1024);
+      const bf16x8 vf = *ldsp<bf16x8>(b_row + I_V + wave * 1024);
+      f32x4 dv0 = {0.f, 0.f, 0.f, 0.f}, dv1 = dv0, dk0 = dv0, dk1 = dv0;
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        __builtin_amdgcn_sched_barrier(0);
+        // each tile's P / dS quads are packed to bf16 (2 + 2 registers) as soon as they exist; the pair is the 8-token
+        // k operand of the second products
+        u32x2 ppk[2] = {u32x2{0u, 0u}, u32x2{0u, 0u}}, dsk[2] = {u32x2{0u, 0u}, u32x2{0u, 0u}};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int i = 2 * u + h;
+          if (i < 9) {
+            const bf16x8 af = *ldsp<bf16x8>(b_row + I_Q + i * 1024);
+            const bf16x8 gf = *ldsp<bf16x8>(b_row + I_G + i * 1024);
+            const f32x4 s0 = *ldsp<f32x4>(b_ls + i * 64);
+            const f32x4 d0 = *ldsp<f32x4>(b_ls + 576 + i * 64);
+            const u32x2 bq = *ldsp<u32x2>(b_kqbt + 32 * i);
+            const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, kf, s0, 0, 0, 0);     // [query 4lg+r][key lq]
+            const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, vf, d0, 0, 0, 0);    // dP - delta
+            const float bb[4] = {bflo(bq[0]), bfhi(bq[0]), bflo(bq[1]), bfhi(bq[1])};
+            float cm = 0.f;
+            if (SHIFTED) { if ((mbits >> i) & 1u) cm = K_MASK2; }
+            f32x4 p, ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              p[r] = __builtin_amdgcn_exp2f(fmaf(s[r], scale2, fmaf(bb[r], K_LOG2E, cm)));
+              ds[r] = p[r] * dp[r];
+            }
+            if (i < DB2_REG) dbias[i < DB2_REG ? i : 0] += ds;
+            else *ldsp<f32x4>(b_db + (i - DB2_REG) * NT * 16) += ds;
+            ppk[h] = u32x2{pack2(p[0], p[1]), pack2(p[2], p[3])};
+            dsk[h] = u32x2{pack2(ds[0], ds[1]), pack2(ds[2], ds[3])};
+            *ldsp<u32x2>(b_kqds + 32 * i) = dsk[h];
+          }
+        }
+        // dV^T[d][key] += dO^T[d][queries] . P ;  dK^T[d][key] += Q^T[d][queries] . dS   (queries of tiles 2u, 2u+1)
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, u32x4{ppk[0][0], ppk[0][1], ppk[1][0], ppk[1][1]});
+        const bf16x8 dsf = __builtin_bit_cast(bf16x8, u32x4{dsk[0][0], dsk[0][1], dsk[1][0], dsk[1][1]});
+        const s16x4 z4 = {0, 0, 0, 0};
+        const bool two = u < 4;                   // tile 9 does not exist: its half of the operand is zero
+        const bf16x8 g_lo = cat8(tr16(b_trlo + I_G + u * 2048), two ? tr16(b_trlo + I_G + u * 2048 + 1024) : z4);
+        const bf16x8 g_hi = cat8(tr16(b_trhi + I_G + u * 2048), two ? tr16(b_trhi + I_G + u * 2048 + 1024) : z4);
+        const bf16x8 q_lo = cat8(tr16(b_trlo + I_Q + u * 2048), two ? tr16(b_trlo + I_Q + u * 2048 + 1024) : z4);
+        const bf16x8 q_hi = cat8(tr16(b_trhi + I_Q + u * 2048), two ? tr16(b_trhi + I_Q + u * 2048 + 1024) : z4);
+        dv0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g_lo, pf, dv0, 0, 0, 0);
+        dv1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g_hi, pf, dv1, 0, 0, 0);
+        dk0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q_lo, dsf, dk0, 0, 0, 0);
+        dk1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q_hi, dsf, dk1, 0, 0, 0);
+      }
+      // lane: dK^T / dV^T [d = 16dt + 4lg + r][key kn]
+      const int ktok = *ldsp<int>(L0 + L_ROW + 1152 + kn * 4);
+      dk0 *= scale; dk1 *= scale;
+      if (ktok >= 0) {
+        u16* dst = dqkv + ((unsigned)ktok * (unsigned)C3 + (unsigned)(hd * 32 + lg * 4));
+        *reinterpret_cast<u32x2*>(dst + C) = u32x2{pack2(dk0[0], dk0[1]), pack2(dk0[2], dk0[3])};
+        *reinterpret_cast<u32x2*>(dst + C + 16) = u32x2{pack2(dk1[0], dk1[1]), pack2(dk1[2], dk1[3])};
+        *reinterpret_cast<u32x2*>(dst + 2 * C) = u32x2{pack2(dv0[0], dv0[1]), pack2(dv0[2], dv0[3])};
+        *reinterpret_cast<u32x2*>(dst + 2 * C + 16) = u32x2{pack2(dv1[0], dv1[1]), pack2(dv1[2], dv1[3])};
+      }
+      // zero-pad keys all carry linear1.bias: their gradients are summed (lanes of a pad key, then LDS, then ONE
+      // global atomic per value at the end) instead of 64 same-address global atomics per pad key and window
+      if (__any(ktok < 0)) {
+        const float keep = ktok < 0 ? 1.f : 0.f;
+        float* pad_s = (float*)(smem + L_ROW + 1728);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float a0 = dk0[r] * keep, a1 = dk1[r] * keep, b0 = dv0[r] * keep, b1 = dv1[r] * keep;
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) {
+            a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64);
+            b0 += __shfl_xor(b0, o, 64); b1 += __shfl_xor(b1, o, 64);
+          }
+          if (lq == 0) {
+            atomicAdd(&pad_s[lg * 4 + r], a0);
+            atomicAdd(&pad_s[16 + lg * 4 + r], a1);
+            atomicAdd(&pad_s[32 + lg * 4 + r], b0);
+            atomicAdd(&pad_s[48 + lg * 4 + r], b1);
+          }
+        }
+      }
+    }
+    __syncthreads();                              // the dS image is complete
+
+    // =========================== phase 2: query tile `wave`: dQ^T[d][query] += K^T[d][keys] . dS^T[keys][query] ======
+    {
+      f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = dq0;
+      const s16x4 z4 = {0, 0, 0, 0};
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        const bool two = u < 4;
+        const bf16x8 k_lo = cat8(tr16(b_trlo + I_K + u * 2048), two ? tr16(b_trlo + I_K + u * 2048 + 1024) : z4);
+        const bf16x8 k_hi = cat8(tr16(b_trhi + I_K + u * 2048), two ? tr16(b_trhi + I_K + u * 2048 + 1024) : z4);
+        const bf16x8 dsf = cat8(tr16(b_trds + u * 32 * DS_LD), two ? tr16(b_trds + u * 32 * DS_LD + 16 * DS_LD) : z4);
+        dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k_lo, dsf, dq0, 0, 0, 0);
+        dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k_hi, dsf, dq1, 0, 0, 0);
+      }
+      const int qtok = *ldsp<int>(L0 + L_ROW + 1152 + kn * 4);
+      if (qtok >= 0) {        // lane: dQ^T[d = 16dt + 4lg + r][query 16 wave + lq]
+        u16* dst = dqkv + ((unsigned)qtok * (unsigned)C3 + (unsigned)(hd * 32 + lg * 4));
+        *reinterpret_cast<u32x2*>(dst) = u32x2{pack2(dq0[0] * scale, dq0[1] * scale), pack2(dq0[2] * scale, dq0[3] * scale)};
+        *reinterpret_cast<u32x2*>(dst + 16) = u32x2{pack2(dq1[0] * scale, dq1[1] * scale), pack2(dq1[2] * scale, dq1[3] * scale)};
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const float pv = tid < 64 ? *ldsp<float>(L0 + L_ROW + 1728 + tid * 4) : 0.f;
+    if (tid < 64 && pv != 0.f) atomicAdd(dqkv_bias + (tid < 32 ? C : 2 * C) + hd * 32 + (tid & 31), pv);
+  }
+  // ---- bias gradient: lane holds sum_l dS[query = 16i + 4lg + r][key = kn]
+  float* drow = d_esb + (size_t)pair * PANGU_WTOK * PANGU_WTOK + (size_t)(lg * 4) * PANGU_WTOK + kn;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const f32x4 v = i < DB2_REG ? dbias[i < DB2_REG ? i : 0] : *ldsp<f32x4>(b_db + (i < DB2_REG ? 0 : i - DB2_REG) * NT * 16);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) drow[(i * 16 + r) * PANGU_WTOK] = v[r];
+  }
+}
+
 }  // namespace
 
 extern "C" int pangu_window_attn_bwd_bf16(pangu_stream_t stream, const void* qkv, const void* qkv_bias, const void* esb,
@@ -294,6 +582,21 @@ extern "C" int pangu_window_attn_bwd_bf16(pangu_stream_t stream, const void* qkv
   const size_t shm = 4 * (size_t)ROWIMG + 3 * (size_t)TIMG + 3 * PANGU_WTOK * sizeof(float) + 64 * sizeof(float) +
                      (size_t)PANGU_WTOK * PANGU_WTOK * sizeof(u16);
   hipStream_t s = (hipStream_t)stream;
+  static const int version = [] { const char* e = getenv("PANGU_ATTN_BWD_V"); return e ? atoi(e) : 2; }();
+  if (version == 2) {
+    const size_t shm2 = L_END;
+    PANGU_ENSURE_DYN_LDS(window_attn_bwd2_bf16_kernel<true>, shm2);
+    PANGU_ENSURE_DYN_LDS(window_attn_bwd2_bf16_kernel<false>, shm2);
+    if (shifted)
+      hipLaunchKernelGGL(window_attn_bwd2_bf16_kernel<true>, dim3(n_pairs), dim3(NT), shm2, s, (const u16*)qkv,
+                         (const u16*)qkv_bias, (const u16*)esb, (const u16*)out, lse, (const u16*)dout, (u16*)dqkv,
+                         dqkv_bias, d_esb, g, C, heads);
+    else
+      hipLaunchKernelGGL(window_attn_bwd2_bf16_kernel<false>, dim3(n_pairs), dim3(NT), shm2, s, (const u16*)qkv,
+                         (const u16*)qkv_bias, (const u16*)esb, (const u16*)out, lse, (const u16*)dout, (u16*)dqkv,
+                         dqkv_bias, d_esb, g, C, heads);
+    return pangu_launch_status();
+  }
   PANGU_ENSURE_DYN_LDS(window_attn_bwd_bf16_kernel<true>, shm);
   PANGU_ENSURE_DYN_LDS(window_attn_bwd_bf16_kernel<false>, shm);
   if (shifted)
