@@ -310,7 +310,7 @@ constexpr int I_K = 0, I_V = ROWIMG, I_Q = 2 * ROWIMG, I_G = 3 * ROWIMG;
 
 template <typename T>
 __device__ inline __attribute__((address_space(3))) T* ldsp(unsigned off) {
-  return (__attribute__((address_space(3))) T*)(off);
+  return (__attribute__((address_space(3))) T*)(size_t)(off);
 }
 __device__ inline s16x4 tr16(unsigned off) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16(ldsp<s16x4>(off));
@@ -321,11 +321,32 @@ __device__ inline unsigned opaque(unsigned v) {
   return v;
 }
 
+#ifdef PANGU_ATTN_BWD_STAMP
+// Diagnostic build only (tools/ablate_attn_bwd.py): per-wave s_memtime sums: [0] staging (loop top .. second barrier),
+// [1] phase 1, [2] wait at the dS barrier, [3] phase 2, [4] whole kernel, [5] waves, [6] prologue
+constexpr int STAMP_WAVES = 9 * 1024;
+__device__ unsigned long long g_bwd_stamp[STAMP_WAVES * 8];
+__device__ __forceinline__ unsigned long long bwd_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define BWD_STAMP(v) const unsigned long long v = bwd_stamp()
+#else
+#define BWD_STAMP(v)
+#endif
+
 template <bool SHIFTED>
 __global__ __launch_bounds__(NT) void window_attn_bwd2_bf16_kernel(
     const u16* __restrict__ qkv, const u16* __restrict__ qkv_bias, const u16* __restrict__ esb,
     const u16* __restrict__ out, const float* __restrict__ lse, const u16* __restrict__ dout, u16* __restrict__ dqkv,
     float* __restrict__ dqkv_bias, float* __restrict__ d_esb, WinGeom g, int C, int heads) {
+  BWD_STAMP(st_begin);
+#ifdef PANGU_ATTN_BWD_STAMP
+  unsigned long long acc_st[4] = {0ull, 0ull, 0ull, 0ull};
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned L0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
@@ -397,7 +418,17 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_bf16_kernel(
 #pragma unroll
   for (int j = 0; j < DB2_LDS; ++j) *ldsp<f32x4>(b_db + j * NT * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- register prefetch of the staging pass: one 16-B chunk (8 dims) of q, k, v, dO, O per thread
+  // ---- register prefetch of the staging pass: one 16-B chunk (8 dims) of q, k, v, dO, O per thread.
+  // Every global access of the window loop is UNCONDITIONAL (pad rows: buffer loads / stores with an out-of-range offset
+  // return zero / are dropped), and a window's loads are issued and consumed in the same loop iteration: the compiler can
+  // then wait for them with a COUNTED vmcnt that leaves the iteration's six gradient stores in flight (a branch around
+  // any of them forces vmcnt(0): the staging pass then also waits for the store acknowledgements, ~2k cycles per window)
+  const int n_tok = g.Z * g.H * g.W;
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t dq_rsrc = __builtin_amdgcn_make_buffer_rsrc(dqkv, 0, n_tok * C3 * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(dout), 0, n_tok * C * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(out), 0, n_tok * C * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t l_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lse), 0, n_tok * heads * 4, 0x00020000);
   const int sn = tid >> 2, sch = tid & 3;
   const unsigned b_st = opaque(L0 + L_IMG + kswz(sn, sch));
   const unsigned b_sr = opaque(L0 + L_ROW + sn * 4);
@@ -406,45 +437,45 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_bf16_kernel(
   float plse;
   const unsigned ho = hd * 32 + sch * 8;
   auto request = [&](int l) {
-    // 32-bit element offsets against the uniform base pointers
     ptok = win_src_token(g, l, t, sn, SHIFTED);
     const u16* src = ptok >= 0 ? qkv : qkv_bias;
-    const unsigned so = (ptok >= 0 ? (unsigned)ptok * (unsigned)C3 : 0u) + ho;
+    const unsigned so = (ptok >= 0 ? (unsigned)ptok * (unsigned)C3 : 0u) + ho;     // 32-bit element offsets
     qv = *reinterpret_cast<const u32x4*>(src + so);
     kv = *reinterpret_cast<const u32x4*>(src + so + (unsigned)C);
     vv = *reinterpret_cast<const u32x4*>(src + so + 2u * (unsigned)C);
-    gv = u32x4{0u, 0u, 0u, 0u}; ov = gv; plse = 0.f;
-    if (ptok >= 0) {
-      const unsigned go = (unsigned)ptok * (unsigned)C + ho;
-      gv = *reinterpret_cast<const u32x4*>(dout + go);
-      ov = *reinterpret_cast<const u32x4*>(out + go);
-      plse = lse[(unsigned)ptok * (unsigned)heads + (unsigned)hd];
+    const unsigned go = ptok >= 0 ? ((unsigned)ptok * (unsigned)C + ho) * 2u : OOB;
+    gv = __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, (int)go, 0, 0);
+    ov = __builtin_amdgcn_raw_buffer_load_b128(o_rsrc, (int)go, 0, 0);
+    plse = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+        l_rsrc, (int)(ptok >= 0 ? ((unsigned)ptok * (unsigned)heads + (unsigned)hd) * 4u : OOB), 0, 0));
+  };
+  auto stage = [&]() {
+    *ldsp<u32x4>(b_st + I_Q) = qv;
+    *ldsp<u32x4>(b_st + I_K) = kv;
+    *ldsp<u32x4>(b_st + I_V) = vv;
+    *ldsp<u32x4>(b_st + I_G) = gv;
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d += bflo(gv[e]) * bflo(ov[e]) + bfhi(gv[e]) * bfhi(ov[e]);
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    if (sch == 0) {
+      // row constants as INITIAL ACCUMULATORS: S' = q.k - lse/scale (p = exp2(S' scale log2e + b log2e)), dP - delta.
+      // A pad query's row of P must vanish (its output is discarded): -huge makes exp2(..) = 0
+      *ldsp<float>(b_sr + 576) = -d;
+      *ldsp<float>(b_sr) = ptok >= 0 ? -plse * (1.0f / scale) : -1e30f;
+      *ldsp<int>(b_sr + 1152) = ptok;
     }
   };
   request(0);
+  BWD_STAMP(st_loop);
+  stage();
 
   for (int l = 0; l < g.nLon; ++l) {
-    __syncthreads();                              // the previous window's LDS reads are done
-    {
-      *ldsp<u32x4>(b_st + I_Q) = qv;
-      *ldsp<u32x4>(b_st + I_K) = kv;
-      *ldsp<u32x4>(b_st + I_V) = vv;
-      *ldsp<u32x4>(b_st + I_G) = gv;
-      float d = 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) d += bflo(gv[e]) * bflo(ov[e]) + bfhi(gv[e]) * bfhi(ov[e]);
-      d += __shfl_xor(d, 1, 64);
-      d += __shfl_xor(d, 2, 64);
-      if (sch == 0) {
-        // row constants as INITIAL ACCUMULATORS: S' = q.k - lse/scale (p = exp2(S' scale log2e + b log2e)), dP - delta.
-        // A pad query's row of P must vanish (its output is discarded): -huge makes exp2(..) = 0
-        *ldsp<float>(b_sr + 576) = -d;
-        *ldsp<float>(b_sr) = ptok >= 0 ? -plse * (1.0f / scale) : -1e30f;
-        *ldsp<int>(b_sr + 1152) = ptok;
-      }
-    }
-    if (l + 1 < g.nLon) request(l + 1);           // in flight during the two compute phases
-    __syncthreads();
+    BWD_STAMP(s0);
+    __syncthreads();                              // window l is staged
+    request(l + 1 < g.nLon ? l + 1 : l);          // in flight during the two compute phases (the last one is redundant)
+    BWD_STAMP(s1);
 
     // =========================== phase 1: key tile `wave`; S[query][key], key on the lane ===========================
     {
@@ -501,12 +532,12 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_bf16_kernel(
       // lane: dK^T / dV^T [d = 16dt + 4lg + r][key kn]
       const int ktok = *ldsp<int>(L0 + L_ROW + 1152 + kn * 4);
       dk0 *= scale; dk1 *= scale;
-      if (ktok >= 0) {
-        u16* dst = dqkv + ((unsigned)ktok * (unsigned)C3 + (unsigned)(hd * 32 + lg * 4));
-        *reinterpret_cast<u32x2*>(dst + C) = u32x2{pack2(dk0[0], dk0[1]), pack2(dk0[2], dk0[3])};
-        *reinterpret_cast<u32x2*>(dst + C + 16) = u32x2{pack2(dk1[0], dk1[1]), pack2(dk1[2], dk1[3])};
-        *reinterpret_cast<u32x2*>(dst + 2 * C) = u32x2{pack2(dv0[0], dv0[1]), pack2(dv0[2], dv0[3])};
-        *reinterpret_cast<u32x2*>(dst + 2 * C + 16) = u32x2{pack2(dv1[0], dv1[1]), pack2(dv1[2], dv1[3])};
+      {
+        const unsigned dst = ktok >= 0 ? ((unsigned)ktok * (unsigned)C3 + (unsigned)(hd * 32 + lg * 4)) * 2u : OOB;
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(dk0[0], dk0[1]), pack2(dk0[2], dk0[3])}, dq_rsrc, (int)dst, 2 * C, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(dk1[0], dk1[1]), pack2(dk1[2], dk1[3])}, dq_rsrc, (int)dst, 2 * C + 32, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(dv0[0], dv0[1]), pack2(dv0[2], dv0[3])}, dq_rsrc, (int)dst, 4 * C, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(dv1[0], dv1[1]), pack2(dv1[2], dv1[3])}, dq_rsrc, (int)dst, 4 * C + 32, 0);
       }
       // zero-pad keys all carry linear1.bias: their gradients are summed (lanes of a pad key, then LDS, then ONE
       // global atomic per value at the end) instead of 64 same-address global atomics per pad key and window
@@ -530,7 +561,9 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_bf16_kernel(
         }
       }
     }
+    BWD_STAMP(s2);
     __syncthreads();                              // the dS image is complete
+    BWD_STAMP(s3);
 
     // =========================== phase 2: query tile `wave`: dQ^T[d][query] += K^T[d][keys] . dS^T[keys][query] ======
     {
@@ -546,14 +579,31 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_bf16_kernel(
         dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k_hi, dsf, dq1, 0, 0, 0);
       }
       const int qtok = *ldsp<int>(L0 + L_ROW + 1152 + kn * 4);
-      if (qtok >= 0) {        // lane: dQ^T[d = 16dt + 4lg + r][query 16 wave + lq]
-        u16* dst = dqkv + ((unsigned)qtok * (unsigned)C3 + (unsigned)(hd * 32 + lg * 4));
-        *reinterpret_cast<u32x2*>(dst) = u32x2{pack2(dq0[0] * scale, dq0[1] * scale), pack2(dq0[2] * scale, dq0[3] * scale)};
-        *reinterpret_cast<u32x2*>(dst + 16) = u32x2{pack2(dq1[0] * scale, dq1[1] * scale), pack2(dq1[2] * scale, dq1[3] * scale)};
+      {                       // lane: dQ^T[d = 16dt + 4lg + r][query 16 wave + lq]
+        const unsigned dst = qtok >= 0 ? ((unsigned)qtok * (unsigned)C3 + (unsigned)(hd * 32 + lg * 4)) * 2u : OOB;
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(dq0[0] * scale, dq0[1] * scale), pack2(dq0[2] * scale, dq0[3] * scale)},
+                                              dq_rsrc, (int)dst, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(dq1[0] * scale, dq1[1] * scale), pack2(dq1[2] * scale, dq1[3] * scale)},
+                                              dq_rsrc, (int)dst, 32, 0);
       }
     }
+    BWD_STAMP(s4);
+    __syncthreads();                              // every wave is done with the images and dS of window l
+    stage();                                      // window l + 1 (its loads were requested before phase 1)
+#ifdef PANGU_ATTN_BWD_STAMP
+    {
+      const unsigned long long s5 = bwd_stamp();
+      acc_st[0] += (s1 - s0) + (s5 - s4); acc_st[1] += s2 - s1; acc_st[2] += s3 - s2; acc_st[3] += s4 - s3;
+    }
+#endif
   }
-  __syncthreads();
+#ifdef PANGU_ATTN_BWD_STAMP
+  if (lane == 0 && blockIdx.x < 1024) {
+    unsigned long long* d = g_bwd_stamp + (size_t)(blockIdx.x * 9 + wave) * 8;
+    d[0] = acc_st[0]; d[1] = acc_st[1]; d[2] = acc_st[2]; d[3] = acc_st[3];
+    d[4] = bwd_stamp() - st_begin; d[5] = 1ull; d[6] = st_loop - st_begin;
+  }
+#endif
   {
     const float pv = tid < 64 ? *ldsp<float>(L0 + L_ROW + 1728 + tid * 4) : 0.f;
     if (tid < 64 && pv != 0.f) atomicAdd(dqkv_bias + (tid < 32 ? C : 2 * C) + hd * 32 + (tid & 31), pv);
@@ -569,6 +619,20 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_bf16_kernel(
 }
 
 }  // namespace
+
+#ifdef PANGU_ATTN_BWD_STAMP
+extern "C" int pangu_attn_bwd_stamp_read(unsigned long long* out8) {
+  (void)hipDeviceSynchronize();
+  static unsigned long long host[STAMP_WAVES * 8];
+  (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bwd_stamp), sizeof(host));
+  for (int k = 0; k < 8; ++k) out8[k] = 0;
+  for (int w = 0; w < STAMP_WAVES; ++w)
+    for (int k = 0; k < 8; ++k) out8[k] += host[(size_t)w * 8 + k];
+  for (size_t i = 0; i < (size_t)STAMP_WAVES * 8; ++i) host[i] = 0;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_stamp), host, sizeof(host));
+  return 0;
+}
+#endif
 
 extern "C" int pangu_window_attn_bwd_bf16(pangu_stream_t stream, const void* qkv, const void* qkv_bias, const void* esb,
                                           const void* out, const float* lse, const void* dout, void* dqkv,
