@@ -16,6 +16,7 @@
 // per tile: one bit per tile, built once before the window loop (+38 % shifted).  Zero-pad slots (q/k/v = linear1.bias) send their k/v gradient
 // to dqkv_bias with atomics (2.7 % of slots); every real token row of dqkv is written exactly once.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -25,7 +26,25 @@ constexpr int NW = 12;                     // waves per workgroup: 9 tile owners
 constexpr int NT = NW * 64;
 constexpr int I_SPLIT = 5;                 // phase B: the owner of key tile k sums query tiles [0,5), a helper [5,9)
 
-template <bool SHIFTED>
+// streaming accesses (every 128-B head slice of qkv / dO / O is read by exactly one workgroup, every dqkv slice written
+// once): with the `nt` hint they do not displace the 83-KB bias tiles the 32 workgroups of an XCD re-read from L2 twice per
+// window -- without it half of those re-reads miss (2.0x the algorithmic HBM reads, round-1 PMC tables)
+template <bool NTH>
+__device__ inline f32x4 ldg4(const float* p) {
+  return NTH ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)) : *reinterpret_cast<const f32x4*>(p);
+}
+template <bool NTH>
+__device__ inline void stg4(float* p, f32x4 v) {
+  if (NTH) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+  else *reinterpret_cast<f32x4*>(p) = v;
+}
+template <bool NTH>
+__device__ inline void stg1(float* p, float v) {
+  if (NTH) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
+template <bool SHIFTED, bool NTH>
 __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
     const float* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ esb,
     const float* __restrict__ out, const float* __restrict__ lse, const float* __restrict__ dout,
@@ -111,13 +130,13 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
       const int n = f >> 3, c4 = (f & 7) * 4;
       const int tok = tok_s[n];
       const float* src = tok >= 0 ? qkv + (size_t)tok * C3 : qkv_bias;
-      f32x4 qv = *reinterpret_cast<const f32x4*>(src + hd * 32 + c4);
-      const f32x4 kv = *reinterpret_cast<const f32x4*>(src + C + hd * 32 + c4);
-      const f32x4 vv = *reinterpret_cast<const f32x4*>(src + 2 * C + hd * 32 + c4);
+      f32x4 qv = ldg4<NTH>(src + hd * 32 + c4);
+      const f32x4 kv = ldg4<NTH>(src + C + hd * 32 + c4);
+      const f32x4 vv = ldg4<NTH>(src + 2 * C + hd * 32 + c4);
       f32x4 gv = {0.f, 0.f, 0.f, 0.f}, ov = {0.f, 0.f, 0.f, 0.f};
       if (tok >= 0) {
-        gv = *reinterpret_cast<const f32x4*>(dout + (size_t)tok * C + hd * 32 + c4);
-        ov = *reinterpret_cast<const f32x4*>(out + (size_t)tok * C + hd * 32 + c4);
+        gv = ldg4<NTH>(dout + (size_t)tok * C + hd * 32 + c4);
+        ov = ldg4<NTH>(out + (size_t)tok * C + hd * 32 + c4);
       }
       qv *= scale;
       *reinterpret_cast<f32x4*>(&Qs[n * KV_LD + c4]) = qv;
@@ -192,8 +211,8 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
       // lane: dQ^T[d = 16dt + 4lg + r][query = qn]; q was pre-scaled, so dq = scale * dQs
       if (qtok >= 0) {
         float* dst = dqkv + (size_t)qtok * C3 + hd * 32 + lg * 4;
-        *reinterpret_cast<f32x4*>(dst) = dq0 * scale;
-        *reinterpret_cast<f32x4*>(dst + 16) = dq1 * scale;
+        stg4<NTH>(dst, dq0 * scale);
+        stg4<NTH>(dst + 16, dq1 * scale);
       }
     }
 
@@ -267,10 +286,10 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
         const int ktok = tok_s[wave * 16 + lg * 4 + r];
         if (ktok >= 0) {
           float* dst = dqkv + (size_t)ktok * C3 + hd * 32 + lq;
-          dst[C] = dk0[r];
-          dst[C + 16] = dk1[r];
-          dst[2 * C] = dv0[r];
-          dst[2 * C + 16] = dv1[r];
+          stg1<NTH>(dst + C, dk0[r]);
+          stg1<NTH>(dst + C + 16, dk1[r]);
+          stg1<NTH>(dst + 2 * C, dv0[r]);
+          stg1<NTH>(dst + 2 * C + 16, dv1[r]);
         } else {
           any_pad = true;
         }
@@ -316,11 +335,15 @@ extern "C" int pangu_window_attn_bwd(pangu_stream_t stream, const float* qkv, co
   const WinGeom g = make_geom(Z, H, W);
   const int n_pairs = g.types * heads;
   hipStream_t s = (hipStream_t)stream;
-  if (shifted)
-    hipLaunchKernelGGL(window_attn_bwd_f32_kernel<true>, dim3(n_pairs), dim3(NT), 0, s, qkv, qkv_bias, esb, out, lse,
-                       dout, dqkv, dqkv_bias, d_esb, g, C, heads);
-  else
-    hipLaunchKernelGGL(window_attn_bwd_f32_kernel<false>, dim3(n_pairs), dim3(NT), 0, s, qkv, qkv_bias, esb, out, lse,
-                       dout, dqkv, dqkv_bias, d_esb, g, C, heads);
+  static const bool nt_hint = [] { const char* e = getenv("PANGU_ATTN_BWD_NT"); return e ? atoi(e) != 0 : true; }();
+#define PANGU_LAUNCH_BWD(SH, NTH)                                                                                    \
+  hipLaunchKernelGGL((window_attn_bwd_f32_kernel<SH, NTH>), dim3(n_pairs), dim3(NT), 0, s, qkv, qkv_bias, esb, out, \
+                     lse, dout, dqkv, dqkv_bias, d_esb, g, C, heads)
+  if (shifted) {
+    if (nt_hint) PANGU_LAUNCH_BWD(true, true); else PANGU_LAUNCH_BWD(true, false);
+  } else {
+    if (nt_hint) PANGU_LAUNCH_BWD(false, true); else PANGU_LAUNCH_BWD(false, false);
+  }
+#undef PANGU_LAUNCH_BWD
   return pangu_launch_status();
 }
