@@ -324,7 +324,7 @@ __device__ inline unsigned opaque(unsigned v) {
 #ifdef PANGU_ATTN_BWD_STAMP
 // Diagnostic build only (tools/ablate_attn_bwd.py): per-wave s_memtime sums: [0] staging (loop top .. second barrier),
 // [1] phase 1, [2] wait at the dS barrier, [3] phase 2, [4] whole kernel, [5] waves, [6] prologue
-constexpr int STAMP_WAVES = 12 * 1024;
+constexpr int STAMP_WAVES = 9 * 1024;
 __device__ unsigned long long g_bwd_stamp[STAMP_WAVES * 8];
 __device__ __forceinline__ unsigned long long bwd_stamp() {
   unsigned long long t;
@@ -618,368 +618,6 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_bf16_kernel(
   }
 }
 
-// ===================================================================================================================
-// v3: v2's algorithm on TWELVE waves.  Nine waves on four SIMDs sit 3/2/2/2 and phase 1 is bound by the instruction issue
-// of the full SIMD (stamps: 260 cycles of SIMD time per 16x16 score tile, 27 tiles on SIMD 0 against 18 on the others);
-// here the owner of key tile w takes query tiles 0..5, helper wave 9 + h takes query tiles 6..8 of key tiles 3h..3h+2
-// (partial dK/dV handed to the owner through LDS), so every SIMD runs three waves with 18-21 tiles.  The helpers need no
-// prefetch registers (the staging pass belongs to the owners' 576 threads) and hold their nine d_esb quads in registers, the
-// owners hold six: no d_esb accumulators in LDS.
-constexpr int NW3 = 12, NT3 = NW3 * 64;
-constexpr int L_PART = L_BT + DSIMG;             // helpers' partial dV / dK: [key tile][4 quads][64 lanes] f32x4
-constexpr int L_END3 = L_PART + 9 * 4 * 1024;
-
-// one 16x16 score tile (query tile I against the key tile behind kf / vf): P and dS quads packed to bf16, d_esb
-// accumulated, dS written to the [key][query] image
-template <int I>
-__device__ inline void bwd3_tile(unsigned b_row, unsigned b_ls, unsigned a_bt, unsigned a_ds, const bf16x8& kf,
-                                 const bf16x8& vf, bool msk, float scale2, f32x4& db, u32x2& ppk, u32x2& dsk) {
-  constexpr float K_LOG2E = 1.4426950408889634f;
-  const bf16x8 af = *ldsp<bf16x8>(b_row + I_Q + I * 1024);
-  const bf16x8 gf = *ldsp<bf16x8>(b_row + I_G + I * 1024);
-  const f32x4 s0 = *ldsp<f32x4>(b_ls + I * 64);
-  const f32x4 d0 = *ldsp<f32x4>(b_ls + 576 + I * 64);
-  const u32x2 bq = *ldsp<u32x2>(a_bt + 32 * I);
-  const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, kf, s0, 0, 0, 0);     // [query 4lg+r][key lq]
-  const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, vf, d0, 0, 0, 0);    // dP - delta
-  const float bb[4] = {bflo(bq[0]), bfhi(bq[0]), bflo(bq[1]), bfhi(bq[1])};
-  const float cm = msk ? -100.0f * K_LOG2E : 0.f;
-  f32x4 p, ds;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    p[r] = __builtin_amdgcn_exp2f(fmaf(s[r], scale2, fmaf(bb[r], K_LOG2E, cm)));
-    ds[r] = p[r] * dp[r];
-  }
-  db += ds;
-  ppk = u32x2{pack2(p[0], p[1]), pack2(p[2], p[3])};
-  dsk = u32x2{pack2(ds[0], ds[1]), pack2(ds[2], ds[3])};
-  *ldsp<u32x2>(a_ds + 32 * I) = dsk;
-}
-
-// the second products of query tiles 2U, 2U+1 (TWO) or of tile 2U alone: dV^T += dO^T P, dK^T += Q^T dS
-template <int U, bool TWO>
-__device__ inline void bwd3_pair(unsigned b_trlo, unsigned b_trhi, const u32x2 (&ppk)[2], const u32x2 (&dsk)[2], f32x4& dv0,
-                                 f32x4& dv1, f32x4& dk0, f32x4& dk1) {
-  const bf16x8 pf = __builtin_bit_cast(bf16x8, u32x4{ppk[0][0], ppk[0][1], ppk[1][0], ppk[1][1]});
-  const bf16x8 dsf = __builtin_bit_cast(bf16x8, u32x4{dsk[0][0], dsk[0][1], dsk[1][0], dsk[1][1]});
-  const s16x4 z4 = {0, 0, 0, 0};
-  const bf16x8 g_lo = cat8(tr16(b_trlo + I_G + U * 2048), TWO ? tr16(b_trlo + I_G + U * 2048 + 1024) : z4);
-  const bf16x8 g_hi = cat8(tr16(b_trhi + I_G + U * 2048), TWO ? tr16(b_trhi + I_G + U * 2048 + 1024) : z4);
-  const bf16x8 q_lo = cat8(tr16(b_trlo + I_Q + U * 2048), TWO ? tr16(b_trlo + I_Q + U * 2048 + 1024) : z4);
-  const bf16x8 q_hi = cat8(tr16(b_trhi + I_Q + U * 2048), TWO ? tr16(b_trhi + I_Q + U * 2048 + 1024) : z4);
-  dv0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g_lo, pf, dv0, 0, 0, 0);
-  dv1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g_hi, pf, dv1, 0, 0, 0);
-  dk0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q_lo, dsf, dk0, 0, 0, 0);
-  dk1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q_hi, dsf, dk1, 0, 0, 0);
-}
-
-__device__ inline void bwd3_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-template <bool SHIFTED>
-__global__ __launch_bounds__(NT3) void window_attn_bwd3_bf16_kernel(
-    const u16* __restrict__ qkv, const u16* __restrict__ qkv_bias, const u16* __restrict__ esb,
-    const u16* __restrict__ out, const float* __restrict__ lse, const u16* __restrict__ dout, u16* __restrict__ dqkv,
-    float* __restrict__ dqkv_bias, float* __restrict__ d_esb, WinGeom g, int C, int heads) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const unsigned L0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-
-  int pair = blockIdx.x;
-  if (!(heads & 1)) {
-    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-    pair = 2 * ((local >> 1) * 8 + xcd) + (local & 1);
-  }
-  if (pair >= g.types * heads) return;
-  const int t = pair / heads, hd = pair - t * heads;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lq = lane & 15, lg = lane >> 4;
-  const int C3 = 3 * C;
-  const float scale = 0.17677669529663687f;
-  constexpr float K_LOG2E = 1.4426950408889634f;
-  const float scale2 = scale * K_LOG2E;
-  const u16* bias_tile = esb + (size_t)pair * PANGU_WTOK * PANGU_WTOK;
-  const bool owner = wave < 9;
-
-  bool zcut = false, hcut = false;
-  if (SHIFTED) {
-    const int zwin = t / g.nHw, hwin = t - zwin * g.nHw;
-    zcut = zwin == g.nZw - 1;
-    hcut = hwin == g.nHw - 1;
-  }
-  auto masked = [&](int nq, int nk) -> bool {
-    const bool zd = (nq >= 72) != (nk >= 72);
-    const bool hdiff = (((nq / 12) % 6) < 3) != (((nk / 12) % 6) < 3);
-    return (zcut && zd) || (hcut && hdiff);
-  };
-  // the mask is window-invariant and the same for the 4 queries 16i + 4lg + r of a lane (the cuts fall on multiples of
-  // 12 and at 72): one bit per (key tile task, query tile), built once.  Owner: bit i = query tile i against key
-  // 16 wave + lq; helper: bit 3 kk + (i - 6) = query tile i against key 16 (3h + kk) + lq
-  const int kt0 = owner ? wave : 3 * (wave - 9);
-  unsigned mbits = 0u;
-  if (SHIFTED) {
-    if (zcut || hcut) {
-      if (owner) {
-        for (int i = 0; i < 6; ++i)
-          if (masked(i * 16 + lg * 4, kt0 * 16 + lq)) mbits |= 1u << i;
-      } else {
-        for (int kk = 0; kk < 3; ++kk)
-          for (int i = 6; i < 9; ++i)
-            if (masked(i * 16 + lg * 4, (kt0 + kk) * 16 + lq)) mbits |= 1u << (3 * kk + i - 6);
-      }
-    }
-  }
-
-  if (tid < 64) *ldsp<float>(L0 + L_ROW + 1728 + tid * 4) = 0.f;
-  // bias tile -> LDS, transposed: 16-B global reads along the key axis, 2-byte LDS writes (once per workgroup)
-  for (int i = tid; i < PANGU_WTOK * (PANGU_WTOK / 8); i += NT3) {
-    const int qn = i / (PANGU_WTOK / 8), c = i - qn * (PANGU_WTOK / 8);
-    const u32x4 b = *reinterpret_cast<const u32x4*>(bias_tile + (size_t)qn * PANGU_WTOK + c * 8);
-    const unsigned o = L0 + L_BT + c * 8 * DS_LD + qn * 2;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      *ldsp<u16>(o + (2 * e) * DS_LD) = (u16)(b[e] & 0xFFFFu);
-      *ldsp<u16>(o + (2 * e + 1) * DS_LD) = (u16)(b[e] >> 16);
-    }
-  }
-
-  // ---- lane-constant LDS bases (opaque: see the LDS map)
-  const int tq = lq >> 2, tp = lq & 3;
-  const unsigned b_trlo = opaque(L0 + L_IMG + kswz(4 * lg + tq, tp >> 1) + 8 * (tp & 1));
-  const unsigned b_trhi = opaque(L0 + L_IMG + kswz(4 * lg + tq, 2 + (tp >> 1)) + 8 * (tp & 1));
-  const unsigned b_row = opaque(L0 + L_IMG + kswz(lq, lg));
-  const unsigned b_ls = opaque(L0 + L_ROW + lg * 16);
-  const unsigned b_kq = opaque(L0 + (kt0 * 16 + lq) * DS_LD + 8 * lg);        // + L_DS / L_BT (+ 16 DS_LD kk) + 32 i
-  const unsigned b_part = opaque(L0 + L_PART + kt0 * 4096 + lane * 16);       // + 4096 kk + 1024 quad
-
-  const int n_tok = g.Z * g.H * g.W;
-  constexpr unsigned OOB = 0x80000000u;
-  float* dbase = d_esb + (size_t)pair * PANGU_WTOK * PANGU_WTOK + (size_t)(lg * 4) * PANGU_WTOK + lq;
-
-  if (owner) {
-    // ============================================ owners: staging, query tiles 0..5 of key tile `wave`, phase 2 =========
-    f32x4 db[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) db[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const unsigned b_trds = opaque(L0 + L_DS + (4 * lg + tq) * DS_LD + wave * 32 + 8 * tp);
-    const __amdgpu_buffer_rsrc_t dq_rsrc = __builtin_amdgcn_make_buffer_rsrc(dqkv, 0, n_tok * C3 * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(dout), 0, n_tok * C * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(out), 0, n_tok * C * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t l_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lse), 0, n_tok * heads * 4, 0x00020000);
-    const int sn = tid >> 2, sch = tid & 3;
-    const unsigned b_st = opaque(L0 + L_IMG + kswz(sn, sch));
-    const unsigned b_sr = opaque(L0 + L_ROW + sn * 4);
-    const int kn = wave * 16 + lq;
-    u32x4 qv, kv, vv, gv, ov;
-    int ptok;
-    float plse;
-    const unsigned ho = hd * 32 + sch * 8;
-    // every global access of the window loop is unconditional and a window's loads are issued and consumed in the same
-    // iteration (see v2): counted vmcnt, the six gradient stores stay in flight
-    auto request = [&](int l) {
-      ptok = win_src_token(g, l, t, sn, SHIFTED);
-      const u16* src = ptok >= 0 ? qkv : qkv_bias;
-      const unsigned so = (ptok >= 0 ? (unsigned)ptok * (unsigned)C3 : 0u) + ho;
-      qv = *reinterpret_cast<const u32x4*>(src + so);
-      kv = *reinterpret_cast<const u32x4*>(src + so + (unsigned)C);
-      vv = *reinterpret_cast<const u32x4*>(src + so + 2u * (unsigned)C);
-      const unsigned go = ptok >= 0 ? ((unsigned)ptok * (unsigned)C + ho) * 2u : OOB;
-      gv = __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, (int)go, 0, 0);
-      ov = __builtin_amdgcn_raw_buffer_load_b128(o_rsrc, (int)go, 0, 0);
-      plse = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-          l_rsrc, (int)(ptok >= 0 ? ((unsigned)ptok * (unsigned)heads + (unsigned)hd) * 4u : OOB), 0, 0));
-    };
-    auto stage = [&]() {
-      *ldsp<u32x4>(b_st + I_Q) = qv;
-      *ldsp<u32x4>(b_st + I_K) = kv;
-      *ldsp<u32x4>(b_st + I_V) = vv;
-      *ldsp<u32x4>(b_st + I_G) = gv;
-      float d = 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) d += bflo(gv[e]) * bflo(ov[e]) + bfhi(gv[e]) * bfhi(ov[e]);
-      d += __shfl_xor(d, 1, 64);
-      d += __shfl_xor(d, 2, 64);
-      if (sch == 0) {
-        *ldsp<float>(b_sr + 576) = -d;
-        *ldsp<float>(b_sr) = ptok >= 0 ? -plse * (1.0f / scale) : -1e30f;
-        *ldsp<int>(b_sr + 1152) = ptok;
-      }
-    };
-    request(0);
-    stage();
-
-#ifdef PANGU_ATTN_BWD_STAMP
-    unsigned long long acc_st[6] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
-#endif
-    for (int l = 0; l < g.nLon; ++l) {
-      BWD_STAMP(s0);
-      bwd3_barrier();                              // window l is staged
-      BWD_STAMP(s1);
-      request(l + 1 < g.nLon ? l + 1 : l);
-      const bf16x8 kf = *ldsp<bf16x8>(b_row + I_K + wave * 1024);
-      const bf16x8 vf = *ldsp<bf16x8>(b_row + I_V + wave * 1024);
-      f32x4 dv0 = {0.f, 0.f, 0.f, 0.f}, dv1 = dv0, dk0 = dv0, dk1 = dv0;
-      {
-        u32x2 ppk[2], dsk[2];
-        __builtin_amdgcn_sched_barrier(0);
-        bwd3_tile<0>(b_row, b_ls, b_kq + L_BT, b_kq + L_DS, kf, vf, SHIFTED && ((mbits >> 0) & 1u), scale2, db[0], ppk[0], dsk[0]);
-        bwd3_tile<1>(b_row, b_ls, b_kq + L_BT, b_kq + L_DS, kf, vf, SHIFTED && ((mbits >> 1) & 1u), scale2, db[1], ppk[1], dsk[1]);
-        bwd3_pair<0, true>(b_trlo, b_trhi, ppk, dsk, dv0, dv1, dk0, dk1);
-        __builtin_amdgcn_sched_barrier(0);
-        bwd3_tile<2>(b_row, b_ls, b_kq + L_BT, b_kq + L_DS, kf, vf, SHIFTED && ((mbits >> 2) & 1u), scale2, db[2], ppk[0], dsk[0]);
-        bwd3_tile<3>(b_row, b_ls, b_kq + L_BT, b_kq + L_DS, kf, vf, SHIFTED && ((mbits >> 3) & 1u), scale2, db[3], ppk[1], dsk[1]);
-        bwd3_pair<1, true>(b_trlo, b_trhi, ppk, dsk, dv0, dv1, dk0, dk1);
-        __builtin_amdgcn_sched_barrier(0);
-        bwd3_tile<4>(b_row, b_ls, b_kq + L_BT, b_kq + L_DS, kf, vf, SHIFTED && ((mbits >> 4) & 1u), scale2, db[4], ppk[0], dsk[0]);
-        bwd3_tile<5>(b_row, b_ls, b_kq + L_BT, b_kq + L_DS, kf, vf, SHIFTED && ((mbits >> 5) & 1u), scale2, db[5], ppk[1], dsk[1]);
-        bwd3_pair<2, true>(b_trlo, b_trhi, ppk, dsk, dv0, dv1, dk0, dk1);
-      }
-      BWD_STAMP(s2);
-      bwd3_barrier();                              // the dS image and the helpers' partial sums are complete
-      BWD_STAMP(s3);
-
-      // ---- dK / dV of key tile `wave`: own sums over query tiles 0..5 + the helper's over 6..8
-      {
-        dv0 += *ldsp<f32x4>(b_part);
-        dv1 += *ldsp<f32x4>(b_part + 1024);
-        dk0 += *ldsp<f32x4>(b_part + 2048);
-        dk1 += *ldsp<f32x4>(b_part + 3072);
-        const int ktok = *ldsp<int>(L0 + L_ROW + 1152 + kn * 4);
-        dk0 *= scale; dk1 *= scale;
-        // lane: dK^T / dV^T [d = 16dt + 4lg + r][key kn]
-        const unsigned dst = ktok >= 0 ? ((unsigned)ktok * (unsigned)C3 + (unsigned)(hd * 32 + lg * 4)) * 2u : OOB;
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(dk0[0], dk0[1]), pack2(dk0[2], dk0[3])}, dq_rsrc, (int)dst, 2 * C, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(dk1[0], dk1[1]), pack2(dk1[2], dk1[3])}, dq_rsrc, (int)dst, 2 * C + 32, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(dv0[0], dv0[1]), pack2(dv0[2], dv0[3])}, dq_rsrc, (int)dst, 4 * C, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(dv1[0], dv1[1]), pack2(dv1[2], dv1[3])}, dq_rsrc, (int)dst, 4 * C + 32, 0);
-        // zero-pad keys all carry linear1.bias: their gradients are summed (lanes of a pad key, then LDS, then ONE global
-        // atomic per value at the end) instead of 64 same-address global atomics per pad key and window
-        if (__any(ktok < 0)) {
-          const float keep = ktok < 0 ? 1.f : 0.f;
-          float* pad_s = (float*)(smem + L_ROW + 1728);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float a0 = dk0[r] * keep, a1 = dk1[r] * keep, b0 = dv0[r] * keep, b1 = dv1[r] * keep;
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-              a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64);
-              b0 += __shfl_xor(b0, o, 64); b1 += __shfl_xor(b1, o, 64);
-            }
-            if (lq == 0) {
-              atomicAdd(&pad_s[lg * 4 + r], a0);
-              atomicAdd(&pad_s[16 + lg * 4 + r], a1);
-              atomicAdd(&pad_s[32 + lg * 4 + r], b0);
-              atomicAdd(&pad_s[48 + lg * 4 + r], b1);
-            }
-          }
-        }
-      }
-      // ---- phase 2: query tile `wave`: dQ^T[d][query] += K^T[d][keys] . dS^T[keys][query]
-      {
-        f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = dq0;
-        const s16x4 z4 = {0, 0, 0, 0};
-#pragma unroll
-        for (int u = 0; u < 5; ++u) {
-          const bool two = u < 4;
-          const bf16x8 k_lo = cat8(tr16(b_trlo + I_K + u * 2048), two ? tr16(b_trlo + I_K + u * 2048 + 1024) : z4);
-          const bf16x8 k_hi = cat8(tr16(b_trhi + I_K + u * 2048), two ? tr16(b_trhi + I_K + u * 2048 + 1024) : z4);
-          const bf16x8 dsf = cat8(tr16(b_trds + u * 32 * DS_LD), two ? tr16(b_trds + u * 32 * DS_LD + 16 * DS_LD) : z4);
-          dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k_lo, dsf, dq0, 0, 0, 0);
-          dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k_hi, dsf, dq1, 0, 0, 0);
-        }
-        const int qtok = *ldsp<int>(L0 + L_ROW + 1152 + kn * 4);
-        const unsigned dst = qtok >= 0 ? ((unsigned)qtok * (unsigned)C3 + (unsigned)(hd * 32 + lg * 4)) * 2u : OOB;
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(dq0[0] * scale, dq0[1] * scale), pack2(dq0[2] * scale, dq0[3] * scale)},
-                                              dq_rsrc, (int)dst, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(dq1[0] * scale, dq1[1] * scale), pack2(dq1[2] * scale, dq1[3] * scale)},
-                                              dq_rsrc, (int)dst, 32, 0);
-      }
-      BWD_STAMP(s4);
-      bwd3_barrier();                              // every wave is done with the images, dS and partial sums of window l
-      BWD_STAMP(s5);
-      stage();                                     // window l + 1
-#ifdef PANGU_ATTN_BWD_STAMP
-      {
-        const unsigned long long s6 = bwd_stamp();
-        acc_st[0] += s1 - s0; acc_st[1] += s2 - s1; acc_st[2] += s3 - s2; acc_st[3] += s4 - s3; acc_st[4] += s5 - s4;
-        acc_st[5] += s6 - s5;
-      }
-#endif
-    }
-#ifdef PANGU_ATTN_BWD_STAMP
-    if (lane == 0 && blockIdx.x < 768) {
-      unsigned long long* d = g_bwd_stamp + (size_t)(blockIdx.x * 12 + wave) * 8;
-      for (int k = 0; k < 6; ++k) d[k] = acc_st[k];
-      d[6] = 1ull; d[7] = 0ull;
-    }
-#endif
-    // bias gradient: lane holds sum_l dS[query = 16i + 4lg + r][key]
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dbase[(i * 16 + r) * PANGU_WTOK + kt0 * 16] = db[i][r];
-  } else {
-    // ============================================ helpers: query tiles 6..8 of key tiles 3h .. 3h+2 =====================
-    f32x4 db[9];
-#pragma unroll
-    for (int j = 0; j < 9; ++j) db[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#ifdef PANGU_ATTN_BWD_STAMP
-    unsigned long long acc_h = 0ull;
-#endif
-    for (int l = 0; l < g.nLon; ++l) {
-      bwd3_barrier();                              // window l is staged
-      BWD_STAMP(h0);
-#pragma unroll
-      for (int kk = 0; kk < 3; ++kk) {
-        __builtin_amdgcn_sched_barrier(0);
-        const bf16x8 kf = *ldsp<bf16x8>(b_row + I_K + kt0 * 1024 + kk * 1024);
-        const bf16x8 vf = *ldsp<bf16x8>(b_row + I_V + kt0 * 1024 + kk * 1024);
-        f32x4 dv0 = {0.f, 0.f, 0.f, 0.f}, dv1 = dv0, dk0 = dv0, dk1 = dv0;
-        u32x2 ppk[2], dsk[2];
-        const unsigned a_bt = b_kq + L_BT + kk * 16 * DS_LD, a_ds = b_kq + L_DS + kk * 16 * DS_LD;
-        bwd3_tile<6>(b_row, b_ls, a_bt, a_ds, kf, vf, SHIFTED && ((mbits >> (3 * kk + 0)) & 1u), scale2, db[3 * kk + 0], ppk[0], dsk[0]);
-        bwd3_tile<7>(b_row, b_ls, a_bt, a_ds, kf, vf, SHIFTED && ((mbits >> (3 * kk + 1)) & 1u), scale2, db[3 * kk + 1], ppk[1], dsk[1]);
-        bwd3_pair<3, true>(b_trlo, b_trhi, ppk, dsk, dv0, dv1, dk0, dk1);
-        __builtin_amdgcn_sched_barrier(0);
-        bwd3_tile<8>(b_row, b_ls, a_bt, a_ds, kf, vf, SHIFTED && ((mbits >> (3 * kk + 2)) & 1u), scale2, db[3 * kk + 2], ppk[0], dsk[0]);
-        ppk[1] = u32x2{0u, 0u}; dsk[1] = u32x2{0u, 0u};
-        bwd3_pair<4, false>(b_trlo, b_trhi, ppk, dsk, dv0, dv1, dk0, dk1);
-        *ldsp<f32x4>(b_part + kk * 4096) = dv0;
-        *ldsp<f32x4>(b_part + kk * 4096 + 1024) = dv1;
-        *ldsp<f32x4>(b_part + kk * 4096 + 2048) = dk0;
-        *ldsp<f32x4>(b_part + kk * 4096 + 3072) = dk1;
-      }
-#ifdef PANGU_ATTN_BWD_STAMP
-      acc_h += bwd_stamp() - h0;
-#endif
-      bwd3_barrier();                              // dS image and partial sums complete
-      bwd3_barrier();                              // window l done
-    }
-#ifdef PANGU_ATTN_BWD_STAMP
-    if (lane == 0 && blockIdx.x < 768) {
-      unsigned long long* d = g_bwd_stamp + (size_t)(blockIdx.x * 12 + wave) * 8;
-      for (int k = 0; k < 7; ++k) d[k] = 0ull;
-      d[7] = acc_h;
-    }
-#endif
-#pragma unroll
-    for (int kk = 0; kk < 3; ++kk)
-#pragma unroll
-      for (int i = 6; i < 9; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dbase[(i * 16 + r) * PANGU_WTOK + (kt0 + kk) * 16] = db[3 * kk + i - 6][r];
-  }
-  __syncthreads();
-  {
-    const float pv = tid < 64 ? *ldsp<float>(L0 + L_ROW + 1728 + tid * 4) : 0.f;
-    if (tid < 64 && pv != 0.f) atomicAdd(dqkv_bias + (tid < 32 ? C : 2 * C) + hd * 32 + (tid & 31), pv);
-  }
-}
-
 }  // namespace
 
 #ifdef PANGU_ATTN_BWD_STAMP
@@ -1008,20 +646,7 @@ extern "C" int pangu_window_attn_bwd_bf16(pangu_stream_t stream, const void* qkv
   const size_t shm = 4 * (size_t)ROWIMG + 3 * (size_t)TIMG + 3 * PANGU_WTOK * sizeof(float) + 64 * sizeof(float) +
                      (size_t)PANGU_WTOK * PANGU_WTOK * sizeof(u16);
   hipStream_t s = (hipStream_t)stream;
-  static const int version = [] { const char* e = getenv("PANGU_ATTN_BWD_V"); return e ? atoi(e) : 3; }();
-  if (version == 3) {
-    PANGU_ENSURE_DYN_LDS(window_attn_bwd3_bf16_kernel<true>, L_END3);
-    PANGU_ENSURE_DYN_LDS(window_attn_bwd3_bf16_kernel<false>, L_END3);
-    if (shifted)
-      hipLaunchKernelGGL(window_attn_bwd3_bf16_kernel<true>, dim3(n_pairs), dim3(NT3), L_END3, s, (const u16*)qkv,
-                         (const u16*)qkv_bias, (const u16*)esb, (const u16*)out, lse, (const u16*)dout, (u16*)dqkv,
-                         dqkv_bias, d_esb, g, C, heads);
-    else
-      hipLaunchKernelGGL(window_attn_bwd3_bf16_kernel<false>, dim3(n_pairs), dim3(NT3), L_END3, s, (const u16*)qkv,
-                         (const u16*)qkv_bias, (const u16*)esb, (const u16*)out, lse, (const u16*)dout, (u16*)dqkv,
-                         dqkv_bias, d_esb, g, C, heads);
-    return pangu_launch_status();
-  }
+  static const int version = [] { const char* e = getenv("PANGU_ATTN_BWD_V"); return e ? atoi(e) : 2; }();
   if (version == 2) {
     const size_t shm2 = L_END;
     PANGU_ENSURE_DYN_LDS(window_attn_bwd2_bf16_kernel<true>, shm2);

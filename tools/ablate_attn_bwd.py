@@ -42,11 +42,6 @@ for C, Z, H, W, heads, types in ((192, 8, 181, 360, 6, 124), (384, 8, 91, 180, 1
         torch.cuda.synchronize()
         lib.pangu_attn_bwd_stamp_read(buf)
         v = list(buf)
-        if os.environ.get("PANGU_ATTN_BWD_V", "3") == "3":
-            n = max(v[6], 1) * nlon
-            print(f"C={C} shifted={sh}: {a.elapsed_time(e):.3f} ms; owner wave per window (cycles): wait@top {v[0] / n:.0f}  request+phase 1 {v[1] / n:.0f}  "
-                  f"wait@dS {v[2] / n:.0f}  dK/dV+phase 2 {v[3] / n:.0f}  wait@bottom {v[4] / n:.0f}  stage {v[5] / n:.0f}   | helper phase 1 {v[7] / (n / 3):.0f}  ({v[6]} owner waves)")
-        else:
-            n = max(v[5], 1) * nlon
-            print(f"C={C} shifted={sh}: {a.elapsed_time(e):.3f} ms; per wave and window (cycles): staging {v[0] / n:.0f}  phase 1 {v[1] / n:.0f}  "
-                  f"dS barrier wait {v[2] / n:.0f}  phase 2 {v[3] / n:.0f}   | prologue {v[6] / max(v[5], 1):.0f}  whole kernel {v[4] / max(v[5], 1):.0f}  ({v[5]} waves)")
+        n = max(v[5], 1) * nlon
+        print(f"C={C} shifted={sh}: {a.elapsed_time(e):.3f} ms; per wave and window (cycles): staging {v[0] / n:.0f}  phase 1 {v[1] / n:.0f}  "
+              f"dS barrier wait {v[2] / n:.0f}  phase 2 {v[3] / n:.0f}   | prologue {v[6] / max(v[5], 1):.0f}  whole kernel {v[4] / max(v[5], 1):.0f}  ({v[5]} waves)")
