@@ -137,7 +137,11 @@ def wgrad(bf16):
         a = torch.randn(M, K, device="cuda").to(dt)
         f = (lambda: ob.linear_wgrad(dc, a)) if bf16 else (lambda: ops.linear_wgrad(dc, a))
         ms = timeit(f)
-        print(f"wgrad {'bf16' if bf16 else 'f32 '} {name:14s} M={M:6d} N={N:4d} K={K:4d}  {ms:7.3f} ms  {2.0 * M * N * K / ms / 1e9:6.1f} TF/s")
+        line = f"wgrad {'bf16' if bf16 else 'f32 '} {name:14s} M={M:6d} N={N:4d} K={K:4d}  {ms:7.3f} ms  {2.0 * M * N * K / ms / 1e9:6.1f} TF/s"
+        if "--lib-compare" in sys.argv:          # external yardstick only: dW = dC^T A (+ column sums) through torch / hipBLASLt
+            ms2 = timeit(lambda: (torch.mm(dc.t(), a), dc.sum(0)))
+            line += f"   | torch {ms2:7.3f} ms {2.0 * M * N * K / ms2 / 1e9:6.1f} TF/s"
+        print(line)
 
 
 def attn_bf16():
