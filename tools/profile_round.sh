@@ -1,0 +1,30 @@
+#!/bin/bash
+# Regenerates the round's committed measurements on the GPU box (run through gpurun; every rocprofv3 pass under `timeout`):
+#   bash tools/profile_round.sh r02
+# -> gpurun_out/<tag>_*: forward kernel stats + PMC traffic JSONs (tools/pmc_traffic.sh), training-step kernel stats per dtype,
+#    the training PMC table (FETCH_SIZE | WRITE_SIZE | MFMA busy, three separate passes), the kernel micro-benchmarks and the
+#    default bench line.  Copy what is to be judged into profiles/.
+set -u
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+export TMPDIR=/tmp
+TAG=${1:-r02}
+mkdir -p gpurun_out
+bash tools/pmc_traffic.sh $TAG > gpurun_out/${TAG}_pmc_traffic.log 2>&1
+for DT in f32 bf16; do
+  rm -rf /tmp/tr_$DT
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr_$DT -- python3 tools/profile_train.py $DT 3 1 > gpurun_out/${TAG}_train_${DT}.log 2>&1
+  cp "$(find /tmp/tr_$DT -name '*kernel_stats.csv' | head -1)" gpurun_out/${TAG}_train_${DT}_kernel_stats.csv
+done
+P=/tmp/trpmc; rm -rf $P; mkdir -p $P
+timeout 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/p1 -- python3 tools/profile_train.py both 2 1 > $P/p1.log 2>&1
+timeout 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/p2 -- python3 tools/profile_train.py both 2 1 > $P/p2.log 2>&1
+timeout 500 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $P/p3 -- python3 tools/profile_train.py both 2 1 > $P/p3.log 2>&1
+python3 tools/pmc_train_table.py $P > gpurun_out/${TAG}_train_pmc_table.md 2> gpurun_out/${TAG}_train_pmc_table.err
+{
+  for sec in mlp_fused attn_qkv_bf16 attn_bf16 gemm_bf16 wgrad_bf16 gemm_ln_bf16 attn attn_bwd gemm wgrad; do
+    echo "## $sec"
+    timeout 400 python3 tools/bench_kernels.py $sec --lib-compare 2>&1 | grep -v "amdgpu.ids"
+  done
+} > gpurun_out/${TAG}_kernel_microbench.txt
+timeout 900 python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+tail -c 600 gpurun_out/${TAG}_bench.json
