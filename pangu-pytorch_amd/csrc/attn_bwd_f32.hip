@@ -17,6 +17,7 @@
 // to dqkv_bias with atomics (2.7 % of slots); every real token row of dqkv is written exactly once.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -323,6 +324,316 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
   }
 }
 
+
+// ===================================================================================================================
+// v2 (round 2): ONE score orientation.  Phase 1: the owner of KEY tile w computes S = Qs K^T and dP = dO V^T with the key
+// on the lane for query tiles 0..5 (helper wave 9 + h: query tiles 6..8 of key tiles 3h..3h+2), so P and dS feed
+// dV += P^T dO and dK += dS^T Qs directly; d_esb (this orientation's accumulators: 6 quads per owner, 9 per helper) stays
+// in registers over the longitude windows, and dS is written ONCE to a [query][key] fp32 image in LDS.  Phase 2: the owner
+// of QUERY tile w computes dQ^T += K^T dS^T from that image.  40 instead of 56 MFMAs per 16x16 tile pair (the round-1
+// kernel recomputed S and dP in the transposed orientation for dQ): 3 240 instead of 4 536 v_mfma_f32_16x16x4_f32 per
+// window, 264-288 per wave on every SIMD, and the bias tile is read once per window instead of twice.
+// LDS (156 KB): K, Qs, dO images (61 KB) + dS image (81 KB); V needs no image (only the owner of a key tile reads it: its
+// fragment comes straight from global memory).  A helper hands its partial dK / dV sums over through LDS: the first key
+// tile's in a 12-KB region of its own (written at once: frees 16 registers), the other two in the memory of the Qs / dO
+// images, which are dead after phase 1 (one extra barrier).
+namespace v2 {
+
+constexpr int DS_LD = PANGU_WTOK;          // floats per row of the dS image (2-way conflicts on its 9 + 36 accesses per wave and window: noise)
+constexpr int A_SPLIT = 6;                 // owner: query tiles [0, 6); helper: [6, 9) of three key tiles
+
+template <bool SHIFTED, bool NTH>
+__global__ __launch_bounds__(NT) void window_attn_bwd2_f32_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ esb,
+    const float* __restrict__ out, const float* __restrict__ lse, const float* __restrict__ dout,
+    float* __restrict__ dqkv, float* __restrict__ dqkv_bias, float* __restrict__ d_esb, WinGeom g, int C, int heads) {
+  __shared__ __attribute__((aligned(16))) float Ks[PANGU_WTOK * KV_LD];
+  __shared__ __attribute__((aligned(16))) float QGs[2 * PANGU_WTOK * KV_LD];     // Qs (scaled), dO; after phase 1: partial sums of the helpers' key tiles 1, 2
+  __shared__ __attribute__((aligned(16))) float dSs[PANGU_WTOK * DS_LD];
+  __shared__ __attribute__((aligned(16))) f32x4 part0_s[3 * 4 * 64];             // partial sums of the helpers' key tile 0
+  __shared__ __attribute__((aligned(16))) float lse_s[PANGU_WTOK];
+  __shared__ __attribute__((aligned(16))) float del_s[PANGU_WTOK];
+  __shared__ int tok_s[PANGU_WTOK];
+  __shared__ float pad_s[64];            // [2][32]: dK, dV summed over the zero-pad keys of this (type, head)
+  float* Qs = QGs;
+  float* Gs = QGs + PANGU_WTOK * KV_LD;
+  f32x4* part12_s = reinterpret_cast<f32x4*>(QGs);                               // [helper][key tile 1, 2][4][64 lanes]
+
+  const int pair = blockIdx.x;
+  const int t = pair / heads, hd = pair - t * heads;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int lq = lane & 15, lg = lane >> 4;     // laundered once per window (below): the per-tile LDS / bias addresses derived from
+                                          // them must not be hoisted out of the window loop (one register per address at the 168 cap)
+  const int C3 = 3 * C;
+  const float scale = 0.17677669529663687f;
+  constexpr float K_LOG2E = 1.4426950408889634f;
+  const float* bias_tile = esb + (size_t)pair * PANGU_WTOK * PANGU_WTOK;
+
+  bool zcut = false, hcut = false;
+  if (SHIFTED) {
+    const int zwin = t / g.nHw, hwin = t - zwin * g.nHw;
+    zcut = zwin == g.nZw - 1;
+    hcut = hwin == g.nHw - 1;
+  }
+  auto masked = [&](int nq, int nk) -> bool {
+    const bool zd = (nq >= 72) != (nk >= 72);
+    const bool hdiff = (((nq / 12) % 6) < 3) != (((nk / 12) % 6) < 3);
+    return (zcut && zd) || (hcut && hdiff);
+  };
+
+  if (tid < 64) pad_s[tid] = 0.f;
+  const bool owner = wave < NQ;
+  const int kt0 = owner ? wave : 3 * (wave - NQ);
+  // mask bit i (owner) / 3 kk + (i - 6) (helper): query tile i against this lane's key of task kk; window-invariant and the
+  // same for the 4 queries 16i + 4lg + r of a lane (the cuts fall on multiples of 12 and at 72)
+  unsigned mbits = 0u;
+  if (SHIFTED) {
+    if (zcut || hcut) {
+      if (owner) {
+        for (int i = 0; i < A_SPLIT; ++i)
+          if (masked(i * 16 + lg * 4, kt0 * 16 + lq)) mbits |= 1u << i;
+      } else {
+        for (int kk = 0; kk < 3; ++kk)
+          for (int i = A_SPLIT; i < NQ; ++i)
+            if (masked(i * 16 + lg * 4, (kt0 + kk) * 16 + lq)) mbits |= 1u << (3 * kk + i - A_SPLIT);
+      }
+    }
+  }
+
+  const float* bias_l = bias_tile;
+  // ---- staging pass of window l (all 768 threads): Qs (scaled), K, dO images, delta = rowsum(dO o O), lse; the V
+  // fragments of this wave's NK key tiles come straight from global memory (in flight during the pass)
+  auto stage = [&](int l, auto& vfr, auto nk_tag) {
+    constexpr int NK = decltype(nk_tag)::value;
+    __syncthreads();                               // previous window's LDS reads (images, dS, partial sums) are done
+    // the bias tile is the same for every window: stop the compiler from hoisting its loads out of the window loop
+    long lz = 0;
+    asm volatile("" : "+s"(lz));
+    bias_l = bias_tile + lz;
+    asm volatile("" : "+v"(lq), "+v"(lg));
+    if (tid < PANGU_WTOK) tok_s[tid] = win_src_token(g, l, t, tid, SHIFTED);
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+      const int tok = tok_s[(kt0 + kk) * 16 + lq];
+      const float* src = (tok >= 0 ? qkv + (size_t)tok * C3 : qkv_bias) + 2 * C + hd * 32 + lg * 8;
+      vfr[kk][0] = ldg4<NTH>(src);
+      vfr[kk][1] = ldg4<NTH>(src + 4);
+    }
+    for (int f = tid; f < PANGU_WTOK * 8; f += NT) {
+      const int n = f >> 3, c4 = (f & 7) * 4;
+      const int tok = tok_s[n];
+      const float* src = tok >= 0 ? qkv + (size_t)tok * C3 : qkv_bias;
+      f32x4 qv = ldg4<NTH>(src + hd * 32 + c4);
+      const f32x4 kv = ldg4<NTH>(src + C + hd * 32 + c4);
+      f32x4 gv = {0.f, 0.f, 0.f, 0.f}, ov = {0.f, 0.f, 0.f, 0.f};
+      if (tok >= 0) {
+        gv = ldg4<NTH>(dout + (size_t)tok * C + hd * 32 + c4);
+        ov = ldg4<NTH>(out + (size_t)tok * C + hd * 32 + c4);
+      }
+      qv *= scale;
+      *reinterpret_cast<f32x4*>(&Qs[n * KV_LD + c4]) = qv;
+      *reinterpret_cast<f32x4*>(&Ks[n * KV_LD + c4]) = kv;
+      *reinterpret_cast<f32x4*>(&Gs[n * KV_LD + c4]) = gv;
+      float d = (gv[0] * ov[0] + gv[1] * ov[1]) + (gv[2] * ov[2] + gv[3] * ov[3]);
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      d += __shfl_xor(d, 4, 64);
+      if ((f & 7) == 0) {
+        // p = exp2(S*log2e - lse*log2e), and -delta as the INITIAL ACCUMULATOR of the dP product (dS = p * (dP - delta)).
+        // A pad query's row of P must vanish (its output is discarded): -huge makes exp2(..) = 0
+        del_s[n] = -d;
+        lse_s[n] = tok >= 0 ? -K_LOG2E * lse[(size_t)tok * heads + hd] : -1e30f;
+      }
+    }
+    __syncthreads();
+  };
+  // ---- one 16x16 score tile: query tile i against key tile kt (fragments k0, k1, v0, v1); lane: [query 16i + 4lg + r][key kn]
+  int& lq_w = lq;
+  int& lg_w = lg;
+  auto score_tile = [&](int kt, int i, const f32x4& k0, const f32x4& k1, const f32x4& v0, const f32x4& v1, bool msk,
+                        f32x4& db, f32x4& dv0, f32x4& dv1, f32x4& dk0, f32x4& dk1) {
+    // per-tile copies of the lane ids behind an opaque asm: the tile's address arithmetic stays inside the tile (the
+    // compiler otherwise computes the bias / LDS addresses of all unrolled tiles up front: 48+ registers)
+    int lq = lq_w, lg = lg_w;
+    asm volatile("" : "+v"(lq), "+v"(lg));
+    const int kn = kt * 16 + lq;
+    const int qrow = (i * 16 + lq) * KV_LD + lg * 8;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(&Qs[qrow]);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(&Qs[qrow + 4]);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(&Gs[qrow]);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(&Gs[qrow + 4]);
+    const f32x4 ls = *reinterpret_cast<const f32x4*>(&lse_s[i * 16 + lg * 4]);      // -lse*log2e
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = bias_l[(size_t)(i * 16 + lg * 4 + r) * PANGU_WTOK + kn];
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = *reinterpret_cast<const f32x4*>(&del_s[i * 16 + lg * 4]);      // -delta
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      s = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[ks], k0[ks], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[ks], v0[ks], dp, 0, 0, 0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      s = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ks], k1[ks], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[ks], v1[ks], dp, 0, 0, 0);
+    }
+    f32x4 p, ds;
+    const float cm = msk ? -100.0f * K_LOG2E : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      p[r] = __builtin_amdgcn_exp2f(fmaf(s[r] + bv[r], K_LOG2E, ls[r] + cm));
+      ds[r] = p[r] * dp[r];
+      dSs[(i * 16 + lg * 4 + r) * DS_LD + kn] = ds[r];
+    }
+    db += ds;
+    // dV[key][d] += P[query][key] dO[query][d];  dK[key][d] += dS[query][key] Qs[query][d]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qn = i * 16 + lg * 4 + r;
+      dv0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p[r], Gs[qn * KV_LD + lq], dv0, 0, 0, 0);
+      dv1 = __builtin_amdgcn_mfma_f32_16x16x4f32(p[r], Gs[qn * KV_LD + 16 + lq], dv1, 0, 0, 0);
+      dk0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[r], Qs[qn * KV_LD + lq], dk0, 0, 0, 0);
+      dk1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[r], Qs[qn * KV_LD + 16 + lq], dk1, 0, 0, 0);
+    }
+  };
+  float* dbase = d_esb + (size_t)pair * PANGU_WTOK * PANGU_WTOK + (size_t)(lg * 4) * PANGU_WTOK + lq;
+
+  if (owner) {
+    f32x4 db[A_SPLIT];
+#pragma unroll
+    for (int j = 0; j < A_SPLIT; ++j) db[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < g.nLon; ++l) {
+      f32x4 vfr[1][2];
+      stage(l, vfr, std::integral_constant<int, 1>{});
+      const int kn = wave * 16 + lq;                        // this lane's key column (phase 1) / query row (phase 2)
+      // =========================== phase 1: key tile `wave`, query tiles 0..5 ===========================
+      const f32x4 k0 = *reinterpret_cast<const f32x4*>(&Ks[kn * KV_LD + lg * 8]);
+      const f32x4 k1 = *reinterpret_cast<const f32x4*>(&Ks[kn * KV_LD + lg * 8 + 4]);
+      f32x4 dv0 = {0.f, 0.f, 0.f, 0.f}, dv1 = dv0, dk0 = dv0, dk1 = dv0;
+#pragma unroll
+      for (int i = 0; i < A_SPLIT; ++i) {
+        __builtin_amdgcn_sched_barrier(0);      // keep each tile's loads inside its iteration (VGPR cap 168)
+        score_tile(wave, i, k0, k1, vfr[0][0], vfr[0][1], SHIFTED && ((mbits >> i) & 1u), db[i], dv0, dv1, dk0, dk1);
+      }
+      __syncthreads();                             // A: the dS image is complete; the Qs / dO images are dead
+      __syncthreads();                             // B: the helpers' partial sums are in LDS (they write them between A and B)
+      {
+        const int h = wave / 3, kk = wave - 3 * h;
+        const f32x4* src = kk == 0 ? part0_s + h * 4 * 64 + lane : part12_s + ((h * 2 + kk - 1) * 4) * 64 + lane;
+        dv0 += src[0]; dv1 += src[64]; dk0 += src[128]; dk1 += src[192];
+        // lane: dK/dV[key = 16*wave + 4lg + r][d = 16dt + lq]
+        bool any_pad = false;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ktok = tok_s[wave * 16 + lg * 4 + r];
+          if (ktok >= 0) {
+            float* dst = dqkv + (size_t)ktok * C3 + hd * 32 + lq;
+            stg1<NTH>(dst + C, dk0[r]);
+            stg1<NTH>(dst + C + 16, dk1[r]);
+            stg1<NTH>(dst + 2 * C, dv0[r]);
+            stg1<NTH>(dst + 2 * C + 16, dv1[r]);
+          } else {
+            any_pad = true;
+          }
+        }
+        // zero-pad keys all carry linear1.bias: sum their gradients over the keys this lane holds, then over the four
+        // key groups, then in LDS; ONE global atomic per value at the end (instead of 64 per pad key and window)
+        if (__any(any_pad)) {
+          float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (tok_s[wave * 16 + lg * 4 + r] < 0) { a0 += dk0[r]; a1 += dk1[r]; b0 += dv0[r]; b1 += dv1[r]; }
+          a0 += __shfl_xor(a0, 16, 64); a1 += __shfl_xor(a1, 16, 64); b0 += __shfl_xor(b0, 16, 64); b1 += __shfl_xor(b1, 16, 64);
+          a0 += __shfl_xor(a0, 32, 64); a1 += __shfl_xor(a1, 32, 64); b0 += __shfl_xor(b0, 32, 64); b1 += __shfl_xor(b1, 32, 64);
+          if (lg == 0) {
+            atomicAdd(&pad_s[lq], a0);
+            atomicAdd(&pad_s[16 + lq], a1);
+            atomicAdd(&pad_s[32 + lq], b0);
+            atomicAdd(&pad_s[48 + lq], b1);
+          }
+        }
+      }
+          // =========================== phase 2: query tile `wave`: dQ^T[d][query] += K^T[d][key] dS^T[key][query] =========
+      {
+        f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = dq0;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+          __builtin_amdgcn_sched_barrier(0);      // keep each key tile's LDS reads next to their MFMAs (register cap)
+          // k index lg of step s <-> key 16j + 4lg + s on both operands
+          const f32x4 dsq = *reinterpret_cast<const f32x4*>(&dSs[kn * DS_LD + j * 16 + lg * 4]);
+#pragma unroll
+          for (int sidx = 0; sidx < 4; ++sidx) {
+            const int key = j * 16 + lg * 4 + sidx;
+            dq0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[key * KV_LD + lq], dsq[sidx], dq0, 0, 0, 0);
+            dq1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[key * KV_LD + 16 + lq], dsq[sidx], dq1, 0, 0, 0);
+          }
+        }
+        // lane: dQ^T[d = 16dt + 4lg + r][query = kn]; q was pre-scaled, so dq = scale * dQs
+        const int qtok = tok_s[kn];
+        if (qtok >= 0) {
+          float* dst = dqkv + (size_t)qtok * C3 + hd * 32 + lg * 4;
+          stg4<NTH>(dst, dq0 * scale);
+          stg4<NTH>(dst + 16, dq1 * scale);
+        }
+      }
+    }
+    // bias gradient: lane holds sum_l dS[query = 16i + 4lg + r][key = 16 wave + lq]
+#pragma unroll
+    for (int i = 0; i < A_SPLIT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dbase[(i * 16 + r) * PANGU_WTOK + wave * 16] = db[i][r];
+  } else {
+    // ============================================ helpers: query tiles 6..8 of key tiles 3h .. 3h+2 =====================
+    const int h = wave - NQ;
+    f32x4 db[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) db[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < g.nLon; ++l) {
+      f32x4 vfr[3][2];
+      stage(l, vfr, std::integral_constant<int, 3>{});
+      f32x4 pk[2][4];                              // partial sums of key tiles 1, 2 (key tile 0's go to LDS at once)
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        const int kt = kt0 + kk;
+        const f32x4 k0 = *reinterpret_cast<const f32x4*>(&Ks[(kt * 16 + lq) * KV_LD + lg * 8]);
+        const f32x4 k1 = *reinterpret_cast<const f32x4*>(&Ks[(kt * 16 + lq) * KV_LD + lg * 8 + 4]);
+        f32x4 dv0 = {0.f, 0.f, 0.f, 0.f}, dv1 = dv0, dk0 = dv0, dk1 = dv0;
+#pragma unroll
+        for (int ii = 0; ii < NQ - A_SPLIT; ++ii) {
+          __builtin_amdgcn_sched_barrier(0);
+          score_tile(kt, A_SPLIT + ii, k0, k1, vfr[kk][0], vfr[kk][1], SHIFTED && ((mbits >> (3 * kk + ii)) & 1u),
+                     db[3 * kk + ii], dv0, dv1, dk0, dk1);
+        }
+        if (kk == 0) {
+          f32x4* dst = part0_s + h * 4 * 64 + lane;
+          dst[0] = dv0; dst[64] = dv1; dst[128] = dk0; dst[192] = dk1;
+        } else {
+          pk[kk - 1][0] = dv0; pk[kk - 1][1] = dv1; pk[kk - 1][2] = dk0; pk[kk - 1][3] = dk1;
+        }
+      }
+      __syncthreads();                             // A: the Qs / dO images are dead
+#pragma unroll
+      for (int kk = 1; kk < 3; ++kk) {
+        f32x4* dst = part12_s + ((h * 2 + kk - 1) * 4) * 64 + lane;
+        dst[0] = pk[kk - 1][0]; dst[64] = pk[kk - 1][1]; dst[128] = pk[kk - 1][2]; dst[192] = pk[kk - 1][3];
+      }
+      __syncthreads();                             // B
+    }
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk)
+#pragma unroll
+      for (int ii = 0; ii < NQ - A_SPLIT; ++ii)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          dbase[((A_SPLIT + ii) * 16 + r) * PANGU_WTOK + (kt0 + kk) * 16] = db[3 * kk + ii][r];
+  }
+  __syncthreads();
+  if (tid < 64 && pad_s[tid] != 0.f) atomicAdd(dqkv_bias + (tid < 32 ? C : 2 * C) + hd * 32 + (tid & 31), pad_s[tid]);
+}
+
+}  // namespace v2
+
 }  // namespace
 
 extern "C" int pangu_window_attn_bwd(pangu_stream_t stream, const float* qkv, const float* qkv_bias, const float* esb,
@@ -336,14 +647,20 @@ extern "C" int pangu_window_attn_bwd(pangu_stream_t stream, const float* qkv, co
   const int n_pairs = g.types * heads;
   hipStream_t s = (hipStream_t)stream;
   static const bool nt_hint = [] { const char* e = getenv("PANGU_ATTN_BWD_NT"); return e ? atoi(e) != 0 : true; }();
-#define PANGU_LAUNCH_BWD(SH, NTH)                                                                                    \
-  hipLaunchKernelGGL((window_attn_bwd_f32_kernel<SH, NTH>), dim3(n_pairs), dim3(NT), 0, s, qkv, qkv_bias, esb, out, \
-                     lse, dout, dqkv, dqkv_bias, d_esb, g, C, heads)
-  if (shifted) {
-    if (nt_hint) PANGU_LAUNCH_BWD(true, true); else PANGU_LAUNCH_BWD(true, false);
-  } else {
-    if (nt_hint) PANGU_LAUNCH_BWD(false, true); else PANGU_LAUNCH_BWD(false, false);
-  }
+  static const int version = [] { const char* e = getenv("PANGU_ATTN_BWD_V"); return e ? atoi(e) : 2; }();
+#define PANGU_LAUNCH_BWD(KERN, SH, NTH)                                                                           \
+  hipLaunchKernelGGL((KERN<SH, NTH>), dim3(n_pairs), dim3(NT), 0, s, qkv, qkv_bias, esb, out, lse, dout, dqkv, \
+                     dqkv_bias, d_esb, g, C, heads)
+#define PANGU_LAUNCH_BWD_V(KERN)                                                                   \
+  do {                                                                                             \
+    if (shifted) {                                                                                 \
+      if (nt_hint) PANGU_LAUNCH_BWD(KERN, true, true); else PANGU_LAUNCH_BWD(KERN, true, false);   \
+    } else {                                                                                       \
+      if (nt_hint) PANGU_LAUNCH_BWD(KERN, false, true); else PANGU_LAUNCH_BWD(KERN, false, false); \
+    }                                                                                              \
+  } while (0)
+  if (version == 1) PANGU_LAUNCH_BWD_V(window_attn_bwd_f32_kernel); else PANGU_LAUNCH_BWD_V(v2::window_attn_bwd2_f32_kernel);
+#undef PANGU_LAUNCH_BWD_V
 #undef PANGU_LAUNCH_BWD
   return pangu_launch_status();
 }

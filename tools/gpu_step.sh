@@ -1,6 +1,7 @@
 #!/bin/bash
 cd /root/repo
 mkdir -p gpurun_out
-timeout 600 python tools/profile_train.py bf16 6 2>&1 | tail -1
-timeout 600 python tools/profile_train.py f32 4 2>&1 | tail -1
-timeout 600 python scratch/prof_host.py 2>&1 | head -22
+timeout 900 python -m pytest tests/test_gpu_backward.py -x -q -k "attention" 2>&1 | tail -5 > gpurun_out/bwdf_test.log
+PANGU_ATTN_BWD_V=1 timeout 300 python tools/bench_kernels.py attn_bwd 2>&1 | grep "f32" > gpurun_out/bwdf_v1.log
+PANGU_ATTN_BWD_V=2 timeout 300 python tools/bench_kernels.py attn_bwd 2>&1 | grep "f32" > gpurun_out/bwdf_v2.log
+cat gpurun_out/bwdf_test.log gpurun_out/bwdf_v1.log gpurun_out/bwdf_v2.log
