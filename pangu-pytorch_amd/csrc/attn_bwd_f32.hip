@@ -327,7 +327,7 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
 
 // ===================================================================================================================
 // v2 (round 2): ONE score orientation.  Phase 1: the owner of KEY tile w computes S = Qs K^T and dP = dO V^T with the key
-// on the lane for query tiles 0..5 (helper wave 9 + h: query tiles 6..8 of key tiles 3h..3h+2), so P and dS feed
+// on the lane for query tiles 0..6 (helper wave 9 + h: query tiles 7, 8 of key tiles 3h..3h+2), so P and dS feed
 // dV += P^T dO and dK += dS^T Qs directly; d_esb (this orientation's accumulators: 6 quads per owner, 9 per helper) stays
 // in registers over the longitude windows, and dS is written ONCE to a [query][key] fp32 image in LDS.  Phase 2: the owner
 // of QUERY tile w computes dQ^T += K^T dS^T from that image.  40 instead of 56 MFMAs per 16x16 tile pair (the round-1
@@ -340,7 +340,25 @@ __global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
 namespace v2 {
 
 constexpr int DS_LD = PANGU_WTOK;          // floats per row of the dS image (2-way conflicts on its 9 + 36 accesses per wave and window: noise)
-constexpr int A_SPLIT = 6;                 // owner: query tiles [0, 6); helper: [6, 9) of three key tiles
+constexpr int A_SPLIT = 7;                 // owner: query tiles [0, 7); helper: [7, 9) of three key tiles (phase 1: 224 / 192 MFMAs; then the owners' 72 of phase 2)
+
+#ifdef PANGU_ATTN_BWD_STAMP
+// Diagnostic build only (tools/ablate_attn_bwd.py f32): per-wave s_memtime sums of the OWNER waves: [0] staging pass,
+// [1] phase 1, [2] barriers A + B, [3] dK/dV hand-over + stores, [4] request + phase 2, [5] waves, [6] wait at the top
+// barrier, [7] LDS writes of the staging pass + its closing barrier
+constexpr int STAMP_WAVES = 12 * 1024;
+__device__ unsigned long long g_bwdf_stamp[STAMP_WAVES * 8];
+__device__ __forceinline__ unsigned long long bwdf_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define BWDF_STAMP(v) const unsigned long long v = bwdf_stamp()
+#else
+#define BWDF_STAMP(v)
+#endif
 
 template <bool SHIFTED, bool NTH>
 __global__ __launch_bounds__(NT) void window_attn_bwd2_f32_kernel(
@@ -384,7 +402,7 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_f32_kernel(
   if (tid < 64) pad_s[tid] = 0.f;
   const bool owner = wave < NQ;
   const int kt0 = owner ? wave : 3 * (wave - NQ);
-  // mask bit i (owner) / 3 kk + (i - 6) (helper): query tile i against this lane's key of task kk; window-invariant and the
+  // mask bit i (owner) / (9 - A_SPLIT) kk + (i - A_SPLIT) (helper): query tile i against this lane's key of task kk; window-invariant and the
   // same for the 4 queries 16i + 4lg + r of a lane (the cuts fall on multiples of 12 and at 72)
   unsigned mbits = 0u;
   if (SHIFTED) {
@@ -395,47 +413,72 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_f32_kernel(
       } else {
         for (int kk = 0; kk < 3; ++kk)
           for (int i = A_SPLIT; i < NQ; ++i)
-            if (masked(i * 16 + lg * 4, (kt0 + kk) * 16 + lq)) mbits |= 1u << (3 * kk + i - A_SPLIT);
+            if (masked(i * 16 + lg * 4, (kt0 + kk) * 16 + lq)) mbits |= 1u << ((NQ - A_SPLIT) * kk + i - A_SPLIT);
       }
     }
   }
 
   const float* bias_l = bias_tile;
+#ifdef PANGU_ATTN_BWD_STAMP
+  unsigned long long sub_st[2] = {0ull, 0ull};
+#endif
   // ---- staging pass of window l (all 768 threads): Qs (scaled), K, dO images, delta = rowsum(dO o O), lse; the V
   // fragments of this wave's NK key tiles come straight from global memory (in flight during the pass)
-  auto stage = [&](int l, auto& vfr, auto nk_tag) {
+  // ---- staging of window l in two halves.  request(): ALL its global loads (1 152 16-B chunk slots = 144 tokens x 8
+  // chunks: ONE per owner thread, THREE per helper thread -- the helpers have the registers; the lse values; the V
+  // fragments of this wave's NK key tiles, which need no LDS image) into registers -- issued BEFORE phase 2 of the previous
+  // window (owners; the helpers are idle by then), where the register file has room (dK / dV accumulators and K / V
+  // fragments are dead), so the ~4.5 us the gathers take run under phase 2 and the barrier waits.
+  // stage(): images, delta = rowsum(dO o O) and lse to LDS.
+  f32x4 pq[3], pk_[3], pg[3], po[3];
+  float plv[3];
+  auto slot_of = [&](int u) { return owner ? tid : NQ * 64 + (tid - NQ * 64) + u * 192; };
+  auto request = [&](int l, auto& vfr, auto nk_tag) {
+    constexpr int NK = decltype(nk_tag)::value;      // key tiles of this wave = chunk slots of this thread: 1 (owner) or 3 (helper)
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+      const int tok = win_src_token(g, l, t, (kt0 + kk) * 16 + lq, SHIFTED);
+      const float* src = (tok >= 0 ? qkv + (size_t)tok * C3 : qkv_bias) + 2 * C + hd * 32 + lg * 8;
+      vfr[kk][0] = ldg4<NTH>(src);
+      vfr[kk][1] = ldg4<NTH>(src + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < NK; ++u) {
+      const int f = slot_of(u);
+      const int n = f >> 3, c4 = (f & 7) * 4;
+      const int tok = win_src_token(g, l, t, n, SHIFTED);
+      const float* src = tok >= 0 ? qkv + (size_t)tok * C3 : qkv_bias;
+      pq[u] = ldg4<NTH>(src + hd * 32 + c4);
+      pk_[u] = ldg4<NTH>(src + C + hd * 32 + c4);
+      // pad rows: any valid address (the values are zeroed in stage())
+      const size_t go = (size_t)(tok >= 0 ? tok : 0) * C + hd * 32 + c4;
+      pg[u] = ldg4<NTH>(dout + go);
+      po[u] = ldg4<NTH>(out + go);
+      plv[u] = lse[(size_t)(tok >= 0 ? tok : 0) * heads + hd];
+    }
+  };
+  auto stage = [&](int l, auto nk_tag) {
     constexpr int NK = decltype(nk_tag)::value;
+    BWDF_STAMP(u0);
     __syncthreads();                               // previous window's LDS reads (images, dS, partial sums) are done
+    BWDF_STAMP(u1);
     // the bias tile is the same for every window: stop the compiler from hoisting its loads out of the window loop
     long lz = 0;
     asm volatile("" : "+s"(lz));
     bias_l = bias_tile + lz;
     asm volatile("" : "+v"(lq), "+v"(lg));
-    if (tid < PANGU_WTOK) tok_s[tid] = win_src_token(g, l, t, tid, SHIFTED);
-    __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < NK; ++kk) {
-      const int tok = tok_s[(kt0 + kk) * 16 + lq];
-      const float* src = (tok >= 0 ? qkv + (size_t)tok * C3 : qkv_bias) + 2 * C + hd * 32 + lg * 8;
-      vfr[kk][0] = ldg4<NTH>(src);
-      vfr[kk][1] = ldg4<NTH>(src + 4);
-    }
-    for (int f = tid; f < PANGU_WTOK * 8; f += NT) {
+    for (int u = 0; u < NK; ++u) {
+      const int f = slot_of(u);
       const int n = f >> 3, c4 = (f & 7) * 4;
-      const int tok = tok_s[n];
-      const float* src = tok >= 0 ? qkv + (size_t)tok * C3 : qkv_bias;
-      f32x4 qv = ldg4<NTH>(src + hd * 32 + c4);
-      const f32x4 kv = ldg4<NTH>(src + C + hd * 32 + c4);
-      f32x4 gv = {0.f, 0.f, 0.f, 0.f}, ov = {0.f, 0.f, 0.f, 0.f};
-      if (tok >= 0) {
-        gv = ldg4<NTH>(dout + (size_t)tok * C + hd * 32 + c4);
-        ov = ldg4<NTH>(out + (size_t)tok * C + hd * 32 + c4);
-      }
-      qv *= scale;
-      *reinterpret_cast<f32x4*>(&Qs[n * KV_LD + c4]) = qv;
-      *reinterpret_cast<f32x4*>(&Ks[n * KV_LD + c4]) = kv;
-      *reinterpret_cast<f32x4*>(&Gs[n * KV_LD + c4]) = gv;
-      float d = (gv[0] * ov[0] + gv[1] * ov[1]) + (gv[2] * ov[2] + gv[3] * ov[3]);
+      const int tok = win_src_token(g, l, t, n, SHIFTED);      // recomputed (the VALU is idle here) rather than kept across phase 2
+      const bool real = tok >= 0;
+      const f32x4 g4 = real ? pg[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 o4 = real ? po[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(&Qs[n * KV_LD + c4]) = pq[u] * scale;
+      *reinterpret_cast<f32x4*>(&Ks[n * KV_LD + c4]) = pk_[u];
+      *reinterpret_cast<f32x4*>(&Gs[n * KV_LD + c4]) = g4;
+      float d = (g4[0] * o4[0] + g4[1] * o4[1]) + (g4[2] * o4[2] + g4[3] * o4[3]);
       d += __shfl_xor(d, 1, 64);
       d += __shfl_xor(d, 2, 64);
       d += __shfl_xor(d, 4, 64);
@@ -443,16 +486,22 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_f32_kernel(
         // p = exp2(S*log2e - lse*log2e), and -delta as the INITIAL ACCUMULATOR of the dP product (dS = p * (dP - delta)).
         // A pad query's row of P must vanish (its output is discarded): -huge makes exp2(..) = 0
         del_s[n] = -d;
-        lse_s[n] = tok >= 0 ? -K_LOG2E * lse[(size_t)tok * heads + hd] : -1e30f;
+        lse_s[n] = real ? -K_LOG2E * plv[u] : -1e30f;
+        tok_s[n] = tok;
       }
     }
     __syncthreads();
+#ifdef PANGU_ATTN_BWD_STAMP
+    { const unsigned long long u2 = bwdf_stamp(); sub_st[0] += u1 - u0; sub_st[1] += u2 - u1; }
+#endif
   };
   // ---- one 16x16 score tile: query tile i against key tile kt (fragments k0, k1, v0, v1); lane: [query 16i + 4lg + r][key kn]
   int& lq_w = lq;
   int& lg_w = lg;
-  auto score_tile = [&](int kt, int i, const f32x4& k0, const f32x4& k1, const f32x4& v0, const f32x4& v1, bool msk,
-                        f32x4& db, f32x4& dv0, f32x4& dv1, f32x4& dk0, f32x4& dk1) {
+  // `bv` holds this tile's four bias values on entry and the NEXT tile's (key tile ktn, query tile in) on exit: their L2
+  // round trip runs under this tile's 32 MFMAs instead of in front of the exp
+  auto score_tile = [&](int kt, int i, int ktn, int in, const f32x4& k0, const f32x4& k1, const f32x4& v0, const f32x4& v1,
+                        bool msk, f32x4& bv, f32x4& db, f32x4& dv0, f32x4& dv1, f32x4& dk0, f32x4& dk1) {
     // per-tile copies of the lane ids behind an opaque asm: the tile's address arithmetic stays inside the tile (the
     // compiler otherwise computes the bias / LDS addresses of all unrolled tiles up front: 48+ registers)
     int lq = lq_w, lg = lg_w;
@@ -464,9 +513,6 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_f32_kernel(
     const f32x4 b0 = *reinterpret_cast<const f32x4*>(&Gs[qrow]);
     const f32x4 b1 = *reinterpret_cast<const f32x4*>(&Gs[qrow + 4]);
     const f32x4 ls = *reinterpret_cast<const f32x4*>(&lse_s[i * 16 + lg * 4]);      // -lse*log2e
-    float bv[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bv[r] = bias_l[(size_t)(i * 16 + lg * 4 + r) * PANGU_WTOK + kn];
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = *reinterpret_cast<const f32x4*>(&del_s[i * 16 + lg * 4]);      // -delta
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -478,7 +524,9 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_f32_kernel(
       s = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ks], k1[ks], s, 0, 0, 0);
       dp = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[ks], v1[ks], dp, 0, 0, 0);
     }
-    f32x4 p, ds;
+    f32x4 p, ds, bvn;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bvn[r] = bias_l[(size_t)(in * 16 + lg * 4 + r) * PANGU_WTOK + ktn * 16 + lq];
     const float cm = msk ? -100.0f * K_LOG2E : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -496,6 +544,7 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_f32_kernel(
       dk0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[r], Qs[qn * KV_LD + lq], dk0, 0, 0, 0);
       dk1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[r], Qs[qn * KV_LD + 16 + lq], dk1, 0, 0, 0);
     }
+    bv = bvn;
   };
   float* dbase = d_esb + (size_t)pair * PANGU_WTOK * PANGU_WTOK + (size_t)(lg * 4) * PANGU_WTOK + lq;
 
@@ -503,21 +552,36 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_f32_kernel(
     f32x4 db[A_SPLIT];
 #pragma unroll
     for (int j = 0; j < A_SPLIT; ++j) db[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bv;                                               // bias values of the next tile to run (window-invariant)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = bias_tile[(size_t)(lg * 4 + r) * PANGU_WTOK + wave * 16 + lq];
+#ifdef PANGU_ATTN_BWD_STAMP
+    unsigned long long acc_st[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
+#endif
+    const __amdgpu_buffer_rsrc_t dq_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(dqkv, 0, (int)((size_t)g.Z * g.H * g.W * C3 * sizeof(float)), 0x00020000);
+    f32x4 vfn[1][2];                                        // V fragment of the NEXT window (requested before phase 2)
+    request(0, vfn, std::integral_constant<int, 1>{});
     for (int l = 0; l < g.nLon; ++l) {
-      f32x4 vfr[1][2];
-      stage(l, vfr, std::integral_constant<int, 1>{});
+      BWDF_STAMP(t0);
+      stage(l, std::integral_constant<int, 1>{});
+      const f32x4 vfr[1][2] = {{vfn[0][0], vfn[0][1]}};
+      BWDF_STAMP(t1);
       const int kn = wave * 16 + lq;                        // this lane's key column (phase 1) / query row (phase 2)
-      // =========================== phase 1: key tile `wave`, query tiles 0..5 ===========================
+      // =========================== phase 1: key tile `wave`, query tiles 0..6 ===========================
       const f32x4 k0 = *reinterpret_cast<const f32x4*>(&Ks[kn * KV_LD + lg * 8]);
       const f32x4 k1 = *reinterpret_cast<const f32x4*>(&Ks[kn * KV_LD + lg * 8 + 4]);
       f32x4 dv0 = {0.f, 0.f, 0.f, 0.f}, dv1 = dv0, dk0 = dv0, dk1 = dv0;
 #pragma unroll
       for (int i = 0; i < A_SPLIT; ++i) {
         __builtin_amdgcn_sched_barrier(0);      // keep each tile's loads inside its iteration (VGPR cap 168)
-        score_tile(wave, i, k0, k1, vfr[0][0], vfr[0][1], SHIFTED && ((mbits >> i) & 1u), db[i], dv0, dv1, dk0, dk1);
+        score_tile(wave, i, wave, (i + 1) % A_SPLIT, k0, k1, vfr[0][0], vfr[0][1], SHIFTED && ((mbits >> i) & 1u), bv, db[i],
+                   dv0, dv1, dk0, dk1);
       }
+      BWDF_STAMP(t2);
       __syncthreads();                             // A: the dS image is complete; the Qs / dO images are dead
       __syncthreads();                             // B: the helpers' partial sums are in LDS (they write them between A and B)
+      BWDF_STAMP(t3);
       {
         const int h = wave / 3, kk = wave - 3 * h;
         const f32x4* src = kk == 0 ? part0_s + h * 4 * 64 + lane : part12_s + ((h * 2 + kk - 1) * 4) * 64 + lane;
@@ -554,7 +618,9 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_f32_kernel(
           }
         }
       }
-          // =========================== phase 2: query tile `wave`: dQ^T[d][query] += K^T[d][key] dS^T[key][query] =========
+          BWDF_STAMP(t4);
+      request(l + 1 < g.nLon ? l + 1 : l, vfn, std::integral_constant<int, 1>{});     // the last one is redundant
+      // =========================== phase 2: query tile `wave`: dQ^T[d][query] += K^T[d][key] dS^T[key][query] =========
       {
         f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = dq0;
 #pragma unroll
@@ -570,28 +636,47 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_f32_kernel(
           }
         }
         // lane: dQ^T[d = 16dt + 4lg + r][query = kn]; q was pre-scaled, so dq = scale * dQs
+        // unconditional (a pad query's store carries an out-of-range offset and is dropped): a branch around the stores
+        // would turn the wait for the prefetched loads at the next stage() into vmcnt(0), i.e. into a wait for these
+        // stores' acknowledgements as well
         const int qtok = tok_s[kn];
-        if (qtok >= 0) {
-          float* dst = dqkv + (size_t)qtok * C3 + hd * 32 + lg * 4;
-          stg4<NTH>(dst, dq0 * scale);
-          stg4<NTH>(dst + 16, dq1 * scale);
-        }
+        const unsigned off = qtok >= 0 ? ((unsigned)qtok * (unsigned)C3 + (unsigned)(hd * 32 + lg * 4)) * 4u : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dq0 * scale), dq_rsrc, (int)off, 0, NTH ? 2 : 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dq1 * scale), dq_rsrc, (int)off, 64, NTH ? 2 : 0);
       }
+#ifdef PANGU_ATTN_BWD_STAMP
+      {
+        const unsigned long long t5 = bwdf_stamp();
+        acc_st[0] += t1 - t0; acc_st[1] += t2 - t1; acc_st[2] += t3 - t2; acc_st[3] += t4 - t3; acc_st[4] += t5 - t4;
+      }
+#endif
     }
+#ifdef PANGU_ATTN_BWD_STAMP
+    if (lane == 0 && blockIdx.x < 1024) {
+      unsigned long long* d = g_bwdf_stamp + (size_t)(blockIdx.x * 12 + wave) * 8;
+      for (int k = 0; k < 5; ++k) d[k] = acc_st[k];
+      d[5] = 1ull; d[6] = sub_st[0]; d[7] = sub_st[1];
+    }
+#endif
     // bias gradient: lane holds sum_l dS[query = 16i + 4lg + r][key = 16 wave + lq]
 #pragma unroll
     for (int i = 0; i < A_SPLIT; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) dbase[(i * 16 + r) * PANGU_WTOK + wave * 16] = db[i][r];
   } else {
-    // ============================================ helpers: query tiles 6..8 of key tiles 3h .. 3h+2 =====================
+    // ============================================ helpers: query tiles 7, 8 of key tiles 3h .. 3h+2 =====================
     const int h = wave - NQ;
-    f32x4 db[9];
+    constexpr int HT = NQ - A_SPLIT;               // query tiles per key tile
+    f32x4 db[3 * HT];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) db[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 3 * HT; ++j) db[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = bias_tile[(size_t)(A_SPLIT * 16 + lg * 4 + r) * PANGU_WTOK + kt0 * 16 + lq];
+    f32x4 vfr[3][2];
+    request(0, vfr, std::integral_constant<int, 3>{});
     for (int l = 0; l < g.nLon; ++l) {
-      f32x4 vfr[3][2];
-      stage(l, vfr, std::integral_constant<int, 3>{});
+      stage(l, std::integral_constant<int, 3>{});
       f32x4 pk[2][4];                              // partial sums of key tiles 1, 2 (key tile 0's go to LDS at once)
 #pragma unroll
       for (int kk = 0; kk < 3; ++kk) {
@@ -602,8 +687,10 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_f32_kernel(
 #pragma unroll
         for (int ii = 0; ii < NQ - A_SPLIT; ++ii) {
           __builtin_amdgcn_sched_barrier(0);
-          score_tile(kt, A_SPLIT + ii, k0, k1, vfr[kk][0], vfr[kk][1], SHIFTED && ((mbits >> (3 * kk + ii)) & 1u),
-                     db[3 * kk + ii], dv0, dv1, dk0, dk1);
+          // next tile in this wave's order: (kk, ii + 1), then (kk + 1, 0), then the next window's (0, 0)
+          const int kkn = ii + 1 < NQ - A_SPLIT ? kk : (kk + 1) % 3, iin = ii + 1 < NQ - A_SPLIT ? ii + 1 : 0;
+          score_tile(kt, A_SPLIT + ii, kt0 + kkn, A_SPLIT + iin, k0, k1, vfr[kk][0], vfr[kk][1],
+                     SHIFTED && ((mbits >> (HT * kk + ii)) & 1u), bv, db[HT * kk + ii], dv0, dv1, dk0, dk1);
         }
         if (kk == 0) {
           f32x4* dst = part0_s + h * 4 * 64 + lane;
@@ -619,14 +706,21 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_f32_kernel(
         dst[0] = pk[kk - 1][0]; dst[64] = pk[kk - 1][1]; dst[128] = pk[kk - 1][2]; dst[192] = pk[kk - 1][3];
       }
       __syncthreads();                             // B
+      request(l + 1 < g.nLon ? l + 1 : l, vfr, std::integral_constant<int, 3>{});     // the helpers are idle from here on
     }
+#ifdef PANGU_ATTN_BWD_STAMP
+    if (lane == 0 && blockIdx.x < 1024) {
+      unsigned long long* d = g_bwdf_stamp + (size_t)(blockIdx.x * 12 + wave) * 8;
+      for (int k = 0; k < 8; ++k) d[k] = 0ull;
+    }
+#endif
 #pragma unroll
     for (int kk = 0; kk < 3; ++kk)
 #pragma unroll
       for (int ii = 0; ii < NQ - A_SPLIT; ++ii)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          dbase[((A_SPLIT + ii) * 16 + r) * PANGU_WTOK + (kt0 + kk) * 16] = db[3 * kk + ii][r];
+          dbase[((A_SPLIT + ii) * 16 + r) * PANGU_WTOK + (kt0 + kk) * 16] = db[(NQ - A_SPLIT) * kk + ii][r];
   }
   __syncthreads();
   if (tid < 64 && pad_s[tid] != 0.f) atomicAdd(dqkv_bias + (tid < 32 ? C : 2 * C) + hd * 32 + (tid & 31), pad_s[tid]);
@@ -635,6 +729,20 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_f32_kernel(
 }  // namespace v2
 
 }  // namespace
+
+#ifdef PANGU_ATTN_BWD_STAMP
+extern "C" int pangu_attn_bwdf_stamp_read(unsigned long long* out8) {
+  (void)hipDeviceSynchronize();
+  static unsigned long long host[v2::STAMP_WAVES * 8];
+  (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(v2::g_bwdf_stamp), sizeof(host));
+  for (int k = 0; k < 8; ++k) out8[k] = 0;
+  for (int w = 0; w < v2::STAMP_WAVES; ++w)
+    for (int k = 0; k < 8; ++k) out8[k] += host[(size_t)w * 8 + k];
+  for (size_t i = 0; i < (size_t)v2::STAMP_WAVES * 8; ++i) host[i] = 0;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(v2::g_bwdf_stamp), host, sizeof(host));
+  return 0;
+}
+#endif
 
 extern "C" int pangu_window_attn_bwd(pangu_stream_t stream, const float* qkv, const float* qkv_bias, const float* esb,
                                      const float* out, const float* lse, const float* dout, float* dqkv,

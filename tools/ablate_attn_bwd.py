@@ -13,6 +13,38 @@ import pangu_pytorch_amd  # noqa: E402,F401
 from pangu_pytorch_amd import ops_bf16 as ob  # noqa: E402
 
 P, I = ctypes.c_void_p, ctypes.c_int
+F32 = len(sys.argv) > 1 and sys.argv[1] == "f32"
+if F32:
+    from pangu_pytorch_amd import ops  # noqa: E402
+    lib = ctypes.CDLL(os.path.join(ROOT, "scratch", "libattn_bwd_stamp.so"))
+    lib.pangu_window_attn_bwd.argtypes = [P] * 10 + [I] * 6
+    stream = torch.cuda.current_stream().cuda_stream
+    for C, Z, H, W, heads, types in ((192, 8, 181, 360, 6, 124), (384, 8, 91, 180, 12, 64)):
+        N, nlon = Z * H * W, W // 12
+        qkv = torch.randn(N, 3 * C, device="cuda")
+        b1 = torch.randn(3 * C, device="cuda")
+        esb = torch.randn(types, heads, 144, 144, device="cuda") * 0.1
+        dout = torch.randn(N, C, device="cuda")
+        dqkv, dqb, desb = torch.empty_like(qkv), torch.zeros(3 * C, device="cuda"), torch.empty(types, heads, 144, 144, device="cuda")
+        for sh in (0, 1):
+            out, lse = ops.window_attention(qkv, b1, esb, Z, H, W, heads, bool(sh), want_lse=True)
+            args = (stream, qkv.data_ptr(), b1.data_ptr(), esb.data_ptr(), out.data_ptr(), lse.data_ptr(), dout.data_ptr(),
+                    dqkv.data_ptr(), dqb.data_ptr(), desb.data_ptr(), Z, H, W, C, heads, sh)
+            buf = (ctypes.c_ulonglong * 8)()
+            for _ in range(2):
+                assert lib.pangu_window_attn_bwd(*args) == 0
+            lib.pangu_attn_bwdf_stamp_read(buf)
+            a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            lib.pangu_window_attn_bwd(*args)
+            e.record()
+            torch.cuda.synchronize()
+            lib.pangu_attn_bwdf_stamp_read(buf)
+            v = list(buf)
+            n = max(v[5], 1) * nlon
+            print(f"f32 C={C} shifted={sh}: {a.elapsed_time(e):.3f} ms; owner wave per window (cycles): staging pass {v[0] / n:.0f} (wait at the top barrier {v[6] / n:.0f}, "
+                  f"LDS writes + barrier {v[7] / n:.0f})  phase 1 {v[1] / n:.0f}  barriers A+B {v[2] / n:.0f}  dK/dV hand-over {v[3] / n:.0f}  phase 2 {v[4] / n:.0f}")
+    sys.exit(0)
 lib = ctypes.CDLL(os.path.join(ROOT, "scratch", "libattn_bwd_stamp.so"))
 lib.pangu_window_attn_bwd_bf16.argtypes = [P] * 10 + [I] * 6
 bf = torch.bfloat16
