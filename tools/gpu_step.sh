@@ -1,7 +1,6 @@
 #!/bin/bash
 cd /root/repo
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_backward.py -x -q -k "attention" 2>&1 | tail -5 > gpurun_out/bwdf_test.log
-PANGU_ATTN_BWD_V=2 timeout 300 python tools/bench_kernels.py attn_bwd 2>&1 | grep "f32" > gpurun_out/bwdf_v2.log
-timeout 300 python tools/ablate_attn_bwd.py f32 2>&1 | tail -4 > gpurun_out/bwdf_stamp.log
-cat gpurun_out/bwdf_test.log gpurun_out/bwdf_v2.log gpurun_out/bwdf_stamp.log
+timeout 2000 python -m pytest tests/test_gpu_backward.py tests/test_gpu_bf16.py tests/test_gpu_dp2.py -x -q 2>&1 | tail -5 > gpurun_out/t_bwd.log
+timeout 600 python tools/profile_train.py both 4 2 2>&1 | tail -2 > gpurun_out/train_wall.log
+cat gpurun_out/t_bwd.log gpurun_out/train_wall.log
