@@ -44,7 +44,10 @@ __device__ inline bf16x8 tr_frag(const unsigned char* img, int row0, int col0, i
 // WB_M = tokens per K-step: 32 (20 KB per ring slot, 157 VGPRs: three workgroups per CU).  Measured and dropped: 64-token
 // steps at two workgroups per CU (no better than the register-staged kernel), four workgroups per CU (128-VGPR cap:
 // spills in the K loop, 3x slower)
-template <int WB_M, int MIN_WGS>
+// TWO_STAGE: the workgroup's 128 x 192 partial tile goes to its token slab's slice of a workspace with PLAIN stores (free
+// next to the MFMAs: the stamps of the atomic form show 15-50 % of the kernel in its fp32 atomic tail -- 75 MB of adds per
+// launch at the chip's 1.3 TB/s atomic rate) and wgrad_reduce_kernel sums the slices into dW.
+template <int WB_M, int MIN_WGS, bool TWO_STAGE>
 __global__ __launch_bounds__(256, MIN_WGS) void wgrad_bf16_dma_kernel(
     const u16* __restrict__ dC, int lddc, const u16* __restrict__ A, int lda, float* __restrict__ dW,
     float* __restrict__ db, int M, int N, int K, int n_tiles, int k_tiles, int rows_per_split) {
@@ -159,7 +162,10 @@ __global__ __launch_bounds__(256, MIN_WGS) void wgrad_bf16_dma_kernel(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + wn * 64 + i * 16 + lg * 4 + r;
-        if (n < N) atomicAdd(&dW[(size_t)n * K + kc], acc[i][j][r]);
+        if (n < N) {
+          if (TWO_STAGE) dW[((size_t)split * N + n) * K + kc] = acc[i][j][r];      // dW = the workspace here
+          else atomicAdd(&dW[(size_t)n * K + kc], acc[i][j][r]);
+        }
       }
     }
   if (want_db && lc == 0) {                             // every column of dC^T @ ones holds the column sum
@@ -173,9 +179,36 @@ __global__ __launch_bounds__(256, MIN_WGS) void wgrad_bf16_dma_kernel(
   }
 }
 
+// dW[e] += sum over the token slabs s in this block's chunk of ws[s][e]: 16 independent 16-B loads per thread, then one
+// round of atomics per chunk (n_valid / 16 adders per element instead of n_valid)
+constexpr int RED_CHUNK = 32;
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const f32x4* __restrict__ ws, float* __restrict__ dW, int nk4,
+                                                           int n_valid) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= nk4) return;
+  const int s0 = blockIdx.y * RED_CHUNK, s1 = min(n_valid, s0 + RED_CHUNK);
+  const f32x4* p = ws + (size_t)s0 * nk4 + e;
+  f32x4 acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int sidx = s0;
+  for (; sidx + 8 <= s1; sidx += 8) {          // eight independent 16-B loads in flight per thread
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] += __builtin_nontemporal_load(p + (size_t)u * nk4);
+    p += (size_t)8 * nk4;
+  }
+  for (; sidx < s1; ++sidx) {
+    acc[0] += __builtin_nontemporal_load(p);
+    p += nk4;
+  }
+  const f32x4 a = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  float* d = dW + (size_t)e * 4;
+  atomicAdd(d, a[0]); atomicAdd(d + 1, a[1]); atomicAdd(d + 2, a[2]); atomicAdd(d + 3, a[3]);
+}
+
 template <int WB_M, int MIN_WGS>
 int launch(hipStream_t s, const u16* dC, int lddc, const u16* A, int lda, float* dW, float* db, int M, int N, int K,
-           int target) {
+           int target, float* ws, size_t ws_bytes) {
   const int n_tiles = (N + WB_N - 1) / WB_N, k_tiles = K / BKC;
   const int tiles = n_tiles * k_tiles;
   int split = (target / tiles) & ~7;                                // multiple of 8: equal share per XCD
@@ -183,11 +216,21 @@ int launch(hipStream_t s, const u16* dC, int lddc, const u16* A, int lda, float*
   int rows = ((M + split - 1) / split + 63) / 64 * 64;
   if (rows < 256) rows = 256;
   split = ((M + rows - 1) / rows + 7) & ~7;                         // grid padded to whole XCD rounds (empty slabs exit)
+  const int n_valid = (M + rows - 1) / rows;                        // slabs that hold tokens (the others write nothing)
   const size_t shm = 2 * (size_t)WB_M * (D_ROW + A_ROW);
-  auto kern = wgrad_bf16_dma_kernel<WB_M, MIN_WGS>;
-  PANGU_ENSURE_DYN_LDS(kern, shm);
-  hipLaunchKernelGGL(kern, dim3(tiles * split), dim3(256), shm, s, dC, lddc, A, lda, dW, db, M, N, K, n_tiles, k_tiles,
-                     rows);
+  const bool two_stage = ws != nullptr && (size_t)n_valid * N * K * sizeof(float) <= ws_bytes && n_valid > 1;
+  if (two_stage) {
+    auto kern = wgrad_bf16_dma_kernel<WB_M, MIN_WGS, true>;
+    PANGU_ENSURE_DYN_LDS(kern, shm);
+    hipLaunchKernelGGL(kern, dim3(tiles * split), dim3(256), shm, s, dC, lddc, A, lda, ws, db, M, N, K, n_tiles, k_tiles, rows);
+    const int nk4 = N * K / 4;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nk4 + 255) / 256, (n_valid + RED_CHUNK - 1) / RED_CHUNK), dim3(256), 0, s,
+                       reinterpret_cast<const f32x4*>(ws), dW, nk4, n_valid);
+  } else {
+    auto kern = wgrad_bf16_dma_kernel<WB_M, MIN_WGS, false>;
+    PANGU_ENSURE_DYN_LDS(kern, shm);
+    hipLaunchKernelGGL(kern, dim3(tiles * split), dim3(256), shm, s, dC, lddc, A, lda, dW, db, M, N, K, n_tiles, k_tiles, rows);
+  }
   return pangu_launch_status();
 }
 
@@ -195,9 +238,9 @@ int launch(hipStream_t s, const u16* dC, int lddc, const u16* A, int lda, float*
 
 // -> PANGU_OK when launched, 1 when the shape is not covered (the caller falls back to the register-staged kernel)
 int pangu_linear_wgrad_bf16_dma(hipStream_t s, const unsigned short* dC, int lddc, const unsigned short* A, int lda,
-                                float* dW, float* db, int M, int N, int K, int target) {
+                                float* dW, float* db, int M, int N, int K, int target, float* ws, size_t ws_bytes) {
   if (K % BKC != 0) return 1;
   // the VGPR byte offset of the last slab's rows (up to M + 63, plus one row of columns) must not wrap 32 bits
   if (((size_t)M + 128) * (size_t)lddc * 2u >= 0xFFFFFFFFull || ((size_t)M + 128) * (size_t)lda * 2u >= 0xFFFFFFFFull) return 1;
-  return launch<32, 3>(s, dC, lddc, A, lda, dW, db, M, N, K, target);
+  return launch<32, 3>(s, dC, lddc, A, lda, dW, db, M, N, K, target, ws, ws_bytes);
 }

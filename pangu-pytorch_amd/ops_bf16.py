@@ -195,9 +195,23 @@ def patch_embed_gather(inp, inp_surface, s_mean, s_std, u_mean, u_std, maps, con
 
 
 # ---------------------------------------------------------------- backward
+_WGRAD_WS_BYTES = 96 << 20
+_wgrad_ws = {}      # device -> fp32 scratch buffer of the two-stage weight-gradient reduction (allocated once)
+
+
+def _wgrad_workspace(device):
+    ws = _wgrad_ws.get(device)
+    if ws is None:
+        ws = torch.empty(_WGRAD_WS_BYTES // 4, dtype=torch.float32, device=device)
+        _wgrad_ws[device] = ws
+    return ws
+
+
 def linear_wgrad(dc, a, want_bias=True):
-    """dW[N,K] (fp32) = dc[M,N]^T @ a[M,K], db[N] = colsum(dc); bf16 operands (row-strided views allowed)."""
+    """dW[N,K] (fp32) = dc[M,N]^T @ a[M,K], db[N] = colsum(dc); bf16 operands (row-strided views allowed).  The partial tiles of
+    the token slabs travel through a per-device scratch buffer (96 MB, allocated on first use) instead of fp32 atomics."""
     lib = _lib.load()
+    ws = _wgrad_workspace(dc.device)
     dp, lddc = _rows(dc, "wgrad.dc")
     ap, lda = _rows(a, "wgrad.a")
     M, N = dc.shape
@@ -207,8 +221,9 @@ def linear_wgrad(dc, a, want_bias=True):
     db = buf[N * K:] if want_bias else None
     for m0, m1 in (_row_chunks(M, 2 * lddc, 2 * lda) or [(0, M)]):      # the kernel ADDS into dw / db
         with _timed("wgrad_bf16", 2.0 * (m1 - m0) * N * K):
-            _lib.check(lib.pangu_linear_wgrad_bf16(_stream(), dp + m0 * lddc * 2, lddc, ap + m0 * lda * 2, lda, dw.data_ptr(),
-                                                   db.data_ptr() if want_bias else None, m1 - m0, N, K), "linear_wgrad_bf16")
+            _lib.check(lib.pangu_linear_wgrad_bf16_ws(_stream(), dp + m0 * lddc * 2, lddc, ap + m0 * lda * 2, lda, dw.data_ptr(),
+                                                      db.data_ptr() if want_bias else None, m1 - m0, N, K, ws.data_ptr(),
+                                                      _WGRAD_WS_BYTES), "linear_wgrad_bf16")
     return dw, db
 
 
