@@ -79,6 +79,10 @@ int pangu_linear_fwd_f32x3(pangu_stream_t stream, const float* A, int lda, const
  * ACCUMULATES with fp32 atomics into caller-initialised buffers (zero them, or pass live .grad buffers). */
 int pangu_linear_wgrad(pangu_stream_t stream, const float* dC, int lddc, const float* A, int lda, float* dW,
                        float* db, int M, int N, int K);
+/* The same product with a caller-owned scratch buffer (see pangu_linear_wgrad_bf16_ws): partial tiles of the token slabs
+ * through the buffer + one reduce launch instead of fp32 atomics; NULL / too small = the entry above. */
+int pangu_linear_wgrad_ws(pangu_stream_t stream, const float* dC, int lddc, const float* A, int lda, float* dW,
+                          float* db, int M, int N, int K, float* workspace, long long workspace_bytes);
 
 /* ---- Earth-specific window attention -------------------------------------------------------------- */
 

@@ -25,6 +25,7 @@ SIGNATURES = {
     "pangu_linear_fwd": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "pangu_linear_fwd_f32x3": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "pangu_linear_wgrad": [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I],
+    "pangu_linear_wgrad_ws": [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _P, _c.c_longlong],
     "pangu_window_attn_bwd": [_P] * 10 + [_I] * 6,
     "pangu_ln_residual_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _F],
     "pangu_downsample_ln_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I],

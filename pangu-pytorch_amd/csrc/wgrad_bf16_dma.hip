@@ -206,6 +206,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const f32x4* __restri
   atomicAdd(d, a[0]); atomicAdd(d + 1, a[1]); atomicAdd(d + 2, a[2]); atomicAdd(d + 3, a[3]);
 }
 
+}  // namespace
+
+// dW[nk] += sum of the n_valid slab slices of the workspace (shared with the fp32 weight-gradient kernel, wgrad_f32_dma.hip)
+void pangu_wgrad_reduce(hipStream_t s, const float* ws, float* dW, int nk, int n_valid) {
+  const int nk4 = nk / 4;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nk4 + 255) / 256, (n_valid + RED_CHUNK - 1) / RED_CHUNK), dim3(256), 0, s,
+                     reinterpret_cast<const f32x4*>(ws), dW, nk4, n_valid);
+}
+
+namespace {
+
 template <int WB_M, int MIN_WGS>
 int launch(hipStream_t s, const u16* dC, int lddc, const u16* A, int lda, float* dW, float* db, int M, int N, int K,
            int target, float* ws, size_t ws_bytes) {
@@ -223,9 +234,7 @@ int launch(hipStream_t s, const u16* dC, int lddc, const u16* A, int lda, float*
     auto kern = wgrad_bf16_dma_kernel<WB_M, MIN_WGS, true>;
     PANGU_ENSURE_DYN_LDS(kern, shm);
     hipLaunchKernelGGL(kern, dim3(tiles * split), dim3(256), shm, s, dC, lddc, A, lda, ws, db, M, N, K, n_tiles, k_tiles, rows);
-    const int nk4 = N * K / 4;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nk4 + 255) / 256, (n_valid + RED_CHUNK - 1) / RED_CHUNK), dim3(256), 0, s,
-                       reinterpret_cast<const f32x4*>(ws), dW, nk4, n_valid);
+    pangu_wgrad_reduce(s, ws, dW, N * K, n_valid);
   } else {
     auto kern = wgrad_bf16_dma_kernel<WB_M, MIN_WGS, false>;
     PANGU_ENSURE_DYN_LDS(kern, shm);

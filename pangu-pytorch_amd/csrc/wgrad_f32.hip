@@ -184,10 +184,15 @@ int launch_wgrad(hipStream_t s, const float* dC, int lddc, const float* A, int l
 
 // wgrad_f32_dma.hip: LDS-DMA variant for N % (64*TNN) == 0, K % 192 == 0; returns 1 when the shape is not covered
 int pangu_linear_wgrad_f32_dma(hipStream_t s, const float* dC, int lddc, const float* A, int lda, float* dW, float* db,
-                               int M, int N, int K, int tnn, int target);
+                               int M, int N, int K, int tnn, int target, float* ws, size_t ws_bytes);
 
 extern "C" int pangu_linear_wgrad(pangu_stream_t stream, const float* dC, int lddc, const float* A, int lda, float* dW,
                                   float* db, int M, int N, int K) {
+  return pangu_linear_wgrad_ws(stream, dC, lddc, A, lda, dW, db, M, N, K, nullptr, 0);
+}
+
+extern "C" int pangu_linear_wgrad_ws(pangu_stream_t stream, const float* dC, int lddc, const float* A, int lda, float* dW,
+                                     float* db, int M, int N, int K, float* workspace, long long workspace_bytes) {
   if (!dC || !A || !dW) return PANGU_E_NULL;
   if (M <= 0 || N <= 0 || K <= 0 || (N & 3) || (K & 3) || lddc < N || lda < K || (lddc & 3) || (lda & 3))
     return PANGU_E_SHAPE;
@@ -200,7 +205,9 @@ extern "C" int pangu_linear_wgrad(pangu_stream_t stream, const float* dC, int ld
   static const int use_dma = getenv("PANGU_WGRAD_DMA") ? atoi(getenv("PANGU_WGRAD_DMA")) : 1;      // A/B knob
   static const int dma_target = getenv("PANGU_WGRAD_DMA_WGS") ? atoi(getenv("PANGU_WGRAD_DMA_WGS")) : 768;    // measured sweep 768 / 1024 / 1536 / 2048: 768 best (1536 within 1 %)
   if (use_dma) {
-    const int rc = pangu_linear_wgrad_f32_dma(s, dC, lddc, A, lda, dW, db, M, N, K, wide ? 3 : 2, dma_target);
+    const bool ws_ok = workspace != nullptr && workspace_bytes > 0 && (reinterpret_cast<size_t>(workspace) & 15) == 0;
+    const int rc = pangu_linear_wgrad_f32_dma(s, dC, lddc, A, lda, dW, db, M, N, K, wide ? 3 : 2, dma_target,
+                                              ws_ok ? workspace : nullptr, ws_ok ? (size_t)workspace_bytes : 0);
     if (rc != -1000) return rc;          // -1000 = PANGU_WGRAD_NOT_COVERED (wgrad_f32_dma.hip): fall through
   }
   if (wide) {

@@ -12,11 +12,15 @@
 // read as zeros.  Everything else stays on wgrad_f32.hip.
 #include "common.h"
 
+void pangu_wgrad_reduce(hipStream_t s, const float* ws, float* dW, int nk, int n_valid);      // wgrad_bf16_dma.hip
+
 namespace {
 
 constexpr int WG_BM = 16;    // tokens per K-step
 
-template <int TNN, int TK>
+// TWO_STAGE: the partial tile goes to its token slab's slice of a workspace with plain stores and pangu_wgrad_reduce sums the
+// slices into dW (see wgrad_bf16_dma.hip: plain stores are free next to the MFMAs, the atomic tail is not)
+template <int TNN, int TK, bool TWO_STAGE>
 __global__ __launch_bounds__(256, (TNN * TK <= 6) ? 4 : 3) void wgrad_f32_dma_kernel(
     const float* __restrict__ dC, int lddc, const float* __restrict__ A, int lda, float* __restrict__ dW,
     float* __restrict__ db, int M, int N, int K, int n_tiles, int k_tiles, int rows_per_split) {
@@ -132,7 +136,8 @@ __global__ __launch_bounds__(256, (TNN * TK <= 6) ? 4 : 3) void wgrad_f32_dma_ke
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wn * 32 * TNN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        atomicAdd(&dW[(size_t)n * K + kc], acc[i][j][r]);
+        if (TWO_STAGE) dW[((size_t)split * N + n) * K + kc] = acc[i][j][r];      // dW = the workspace here
+        else atomicAdd(&dW[(size_t)n * K + kc], acc[i][j][r]);
       }
   }
   if (want_db && (WG_BN == 128 || tid < WG_BN)) atomicAdd(&db[n0 + db_col], dbacc);
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256, (TNN * TK <= 6) ? 4 : 3) void wgrad_f32_dma_ke
 
 template <int TNN, int TK>
 int launch_wgrad_dma(hipStream_t s, const float* dC, int lddc, const float* A, int lda, float* dW, float* db, int M, int N,
-                     int K, int target) {
+                     int K, int target, float* ws, size_t ws_bytes) {
   constexpr int WG_BN = 64 * TNN, BKC = 64 * TK;
   const int n_tiles = N / WG_BN, k_tiles = K / BKC;
   const int tiles = n_tiles * k_tiles;
@@ -148,8 +153,15 @@ int launch_wgrad_dma(hipStream_t s, const float* dC, int lddc, const float* A, i
   int rows = ((M + split - 1) / split + WG_BM - 1) / WG_BM * WG_BM;
   if (rows < 8 * WG_BM) rows = 8 * WG_BM;
   split = ((M + rows - 1) / rows + 7) & ~7;                         // grid padded to whole XCD rounds (empty slabs exit)
-  hipLaunchKernelGGL((wgrad_f32_dma_kernel<TNN, TK>), dim3(tiles * split), dim3(256), 0, s, dC, lddc, A, lda, dW, db, M, N,
-                     K, n_tiles, k_tiles, rows);
+  const int n_valid = (M + rows - 1) / rows;                        // slabs that hold tokens (the others write nothing)
+  if (ws != nullptr && n_valid > 1 && (size_t)n_valid * N * K * sizeof(float) <= ws_bytes) {
+    hipLaunchKernelGGL((wgrad_f32_dma_kernel<TNN, TK, true>), dim3(tiles * split), dim3(256), 0, s, dC, lddc, A, lda, ws, db, M,
+                       N, K, n_tiles, k_tiles, rows);
+    pangu_wgrad_reduce(s, ws, dW, N * K, n_valid);
+  } else {
+    hipLaunchKernelGGL((wgrad_f32_dma_kernel<TNN, TK, false>), dim3(tiles * split), dim3(256), 0, s, dC, lddc, A, lda, dW, db, M,
+                       N, K, n_tiles, k_tiles, rows);
+  }
   return pangu_launch_status();
 }
 
@@ -159,11 +171,11 @@ int launch_wgrad_dma(hipStream_t s, const float* dC, int lddc, const float* A, i
 // covered: the caller falls back to the register-staged kernel; every other non-zero code is a real launch error
 constexpr int PANGU_WGRAD_NOT_COVERED = -1000;
 int pangu_linear_wgrad_f32_dma(hipStream_t s, const float* dC, int lddc, const float* A, int lda, float* dW, float* db,
-                               int M, int N, int K, int tnn, int target) {
+                               int M, int N, int K, int tnn, int target, float* ws, size_t ws_bytes) {
   // the VGPR byte offset of the last slab's rows (up to M + 15, plus one row of columns) must not wrap 32 bits
   if (((size_t)M + 32) * (size_t)lddc * 4u >= 0xFFFFFFFFull || ((size_t)M + 32) * (size_t)lda * 4u >= 0xFFFFFFFFull) return PANGU_WGRAD_NOT_COVERED;
   if (K % 192 != 0) return PANGU_WGRAD_NOT_COVERED;
-  if (tnn == 3 && N % 192 == 0) return launch_wgrad_dma<3, 3>(s, dC, lddc, A, lda, dW, db, M, N, K, target);
-  if (tnn == 2 && N % 128 == 0) return launch_wgrad_dma<2, 3>(s, dC, lddc, A, lda, dW, db, M, N, K, target);
+  if (tnn == 3 && N % 192 == 0) return launch_wgrad_dma<3, 3>(s, dC, lddc, A, lda, dW, db, M, N, K, target, ws, ws_bytes);
+  if (tnn == 2 && N % 128 == 0) return launch_wgrad_dma<2, 3>(s, dC, lddc, A, lda, dW, db, M, N, K, target, ws, ws_bytes);
   return PANGU_WGRAD_NOT_COVERED;
 }

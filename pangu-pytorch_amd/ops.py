@@ -237,9 +237,23 @@ def linear_ln_residual(a, weight, bias, shortcut, gamma, beta, out=None, branch_
     return out
 
 
+_WGRAD_WS_BYTES = 96 << 20
+_wgrad_ws = {}      # device -> fp32 scratch buffer of the two-stage weight-gradient reduction (allocated once, shared with ops_bf16)
+
+
+def wgrad_workspace(device):
+    ws = _wgrad_ws.get(device)
+    if ws is None:
+        ws = torch.empty(_WGRAD_WS_BYTES // 4, dtype=torch.float32, device=device)
+        _wgrad_ws[device] = ws
+    return ws
+
+
 def linear_wgrad(dc, a, want_bias=True):
-    """dW[N,K] = dc[M,N]^T @ a[M,K], db[N] = colsum(dc) (fp32 atomics into zero-initialised buffers)."""
+    """dW[N,K] = dc[M,N]^T @ a[M,K], db[N] = colsum(dc), ADDED into zero-initialised buffers; the token slabs' partial tiles
+    travel through a per-device scratch buffer (96 MB, allocated on first use) and one reduce launch instead of fp32 atomics."""
     lib = _lib.load()
+    ws = wgrad_workspace(dc.device)
     dp, lddc = _rows(dc, "wgrad.dc")
     ap, lda = _rows(a, "wgrad.a")
     M, N = dc.shape
@@ -250,8 +264,9 @@ def linear_wgrad(dc, a, want_bias=True):
     esz = dc.element_size()
     for m0, m1 in (_row_chunks(M, esz * lddc, esz * lda) or [(0, M)]):      # the kernel ADDS into dw / db
         with _timed("wgrad", 2.0 * (m1 - m0) * N * K):
-            _lib.check(lib.pangu_linear_wgrad(_stream(), dp + m0 * lddc * esz, lddc, ap + m0 * lda * esz, lda, dw.data_ptr(),
-                                              db.data_ptr() if want_bias else None, m1 - m0, N, K), "linear_wgrad")
+            _lib.check(lib.pangu_linear_wgrad_ws(_stream(), dp + m0 * lddc * esz, lddc, ap + m0 * lda * esz, lda, dw.data_ptr(),
+                                                 db.data_ptr() if want_bias else None, m1 - m0, N, K, ws.data_ptr(),
+                                                 _WGRAD_WS_BYTES), "linear_wgrad")
     return dw, db
 
 

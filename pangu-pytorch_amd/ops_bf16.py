@@ -2,6 +2,7 @@
 import torch
 
 from . import _lib
+from . import ops
 from .ops import _row_chunks, _stream, _timed, _zeros
 
 ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_ADD = 0, 1, 2, 3
@@ -195,16 +196,8 @@ def patch_embed_gather(inp, inp_surface, s_mean, s_std, u_mean, u_std, maps, con
 
 
 # ---------------------------------------------------------------- backward
-_WGRAD_WS_BYTES = 96 << 20
-_wgrad_ws = {}      # device -> fp32 scratch buffer of the two-stage weight-gradient reduction (allocated once)
-
-
-def _wgrad_workspace(device):
-    ws = _wgrad_ws.get(device)
-    if ws is None:
-        ws = torch.empty(_WGRAD_WS_BYTES // 4, dtype=torch.float32, device=device)
-        _wgrad_ws[device] = ws
-    return ws
+_WGRAD_WS_BYTES = ops._WGRAD_WS_BYTES
+_wgrad_workspace = ops.wgrad_workspace      # one scratch buffer per device for both dtypes
 
 
 def linear_wgrad(dc, a, want_bias=True):
