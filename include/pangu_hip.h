@@ -96,6 +96,13 @@ int pangu_linear_wgrad_ws(pangu_stream_t stream, const float* dC, int lddc, cons
  * Replaces reference layers.py:192-247 + :368-415. */
 int pangu_window_attn_fwd(pangu_stream_t stream, const float* qkv, const float* qkv_bias, const float* esb,
                           float* out, float* lse, int Z, int H, int W, int C, int heads, int shifted);
+/* Inference mode on the paper's COMPACT Earth-specific bias: esb_compact is [types][heads][3312] fp32 (the (3312, types, heads)
+ * table of reference layers.py:306-357 with the index axis last); the kernel gathers each score's bias through the
+ * position index in closed form (layers.py:319-357, :384-391) -- 13 KB per (type, head) instead of 83 KB, 10 MB instead
+ * of 62 MB per block.  Bit-identical to pangu_window_attn_fwd on the expanded table of the same values. */
+int pangu_window_attn_fwd_compact(pangu_stream_t stream, const float* qkv, const float* qkv_bias,
+                                  const float* esb_compact, float* out, float* lse, int Z, int H, int W, int C,
+                                  int heads, int shifted);
 
 /* Backward of pangu_window_attn_fwd.  One workgroup per (window type, head) walks the nLon longitude windows
  * and keeps the bias gradient d_esb[t][head] = sum_l dS in registers (no atomics, written once).

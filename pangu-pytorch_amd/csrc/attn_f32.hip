@@ -30,11 +30,33 @@ struct BiasRowF {          // one query row of the bias tile, this lane's 36 key
   f32x4 v[9];
 };
 
+// COMPACT: the row comes from the paper's compact table of this (type, head) -- 3 312 floats instead of 144 x 144 --
+// through the position index of reference layers.py:319-357 in closed form:
+//   index(query, key) = (zq + 2 zk) * 828 + (hq + 6 hk) * 23 + (wq - wk + 11),  n = 72 z + 12 h + w.
+// The 4 keys 16j + 4lg + r of a lane share (zk, hk) (12 | 4-aligned runs) and their wk rises with r, so their entries are 4
+// CONSECUTIVE floats in falling order: one dword-aligned 16-B load, reversed.  Same values in the same registers as the
+// expanded tile gives: the two modes are bit-identical (tests/test_gpu_extras.py).
+typedef f32x4 f32x4_a4 __attribute__((aligned(4)));
+constexpr int PANGU_COMPACT_BIAS = 3312;
+
+template <bool COMPACT>
 __device__ inline BiasRowF load_bias_row(const float* __restrict__ bias_tile, int qn, int lg) {
-  const float* brow = bias_tile + (size_t)qn * PANGU_WTOK + lg * 4;
   BiasRowF b;
+  if (COMPACT) {
+    const int zq = qn / 72, hq = (qn / 12) % 6, wq = qn % 12;
 #pragma unroll
-  for (int j = 0; j < 9; ++j) b.v[j] = *reinterpret_cast<const f32x4*>(brow + j * 16);
+    for (int j = 0; j < 9; ++j) {
+      const int k0 = j * 16 + lg * 4;
+      const int zk = k0 / 72, hk = (k0 / 12) % 6, wk = k0 % 12;
+      const int idx = (zq + 2 * zk) * 828 + (hq + 6 * hk) * 23 + (wq - wk + 11);      // key k0; key k0 + r: idx - r
+      const f32x4 v = *reinterpret_cast<const f32x4_a4*>(bias_tile + idx - 3);
+      b.v[j] = f32x4{v[3], v[2], v[1], v[0]};
+    }
+  } else {
+    const float* brow = bias_tile + (size_t)qn * PANGU_WTOK + lg * 4;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) b.v[j] = *reinterpret_cast<const f32x4*>(brow + j * 16);
+  }
   return b;
 }
 
@@ -243,7 +265,7 @@ __device__ __forceinline__ void softmax_with_next_scores(f32x4 (&sc)[9], f32x4 (
 // v_exp ~12 cycles of the SIMD's MFMA issue time even at 3 waves/SIMD, so the gain is only the removed dependency
 // stalls; ablations -- no bias loads, no exp, head-fastest block order -- change nothing, no global loads/stores at all
 // gives 0.58 ms of the 0.79 ms at stage 0: the kernel is bound by MFMA issue + its own VALU/LDS instruction stream).
-template <bool SHIFTED>
+template <bool SHIFTED, bool COMPACT>
 __global__ __launch_bounds__(192, 3) void window_attn_f32_kernel(const float* __restrict__ qkv,
                                                               const float* __restrict__ qkv_bias,
                                                               const float* __restrict__ esb,
@@ -264,7 +286,7 @@ __global__ __launch_bounds__(192, 3) void window_attn_f32_kernel(const float* __
   const int lq = lane & 15, lg = lane >> 4;
   const int C3 = 3 * C;
   const float scale = 0.17677669529663687f;   // 32^-0.5, reference layers.py:289
-  const float* bias_tile = esb + (size_t)(t * heads + hd) * PANGU_WTOK * PANGU_WTOK;
+  const float* bias_tile = esb + (size_t)(t * heads + hd) * (COMPACT ? PANGU_COMPACT_BIAS : PANGU_WTOK * PANGU_WTOK);
 
   // ---- up-front loads.  Q fragment: lane group lg owns dims {4lg..4lg+3} and {16+4lg..16+4lg+3} (the MFMA k index is
   // permuted the same way for K: chunk pairs (lg, lg^1) inside every ds_read_b128 lane group keep the swizzled reads
@@ -281,7 +303,7 @@ __global__ __launch_bounds__(192, 3) void window_attn_f32_kernel(const float* __
   }
   f32x4 sA[9], sB[9];
   {
-    const BiasRowF b0 = load_bias_row(bias_tile, wave * 16 + lq, lg);
+    const BiasRowF b0 = load_bias_row<COMPACT>(bias_tile, wave * 16 + lq, lg);
 #pragma unroll
     for (int j = 0; j < 9; ++j) sA[j] = b0.v[j];
   }
@@ -327,7 +349,7 @@ __global__ __launch_bounds__(192, 3) void window_attn_f32_kernel(const float* __
   float mx, sum;
   // tile 0 scores; bias row of tile 1 -> sB
   {
-    const BiasRowF b1 = load_bias_row(bias_tile, (wave + 3) * 16 + lq, lg);
+    const BiasRowF b1 = load_bias_row<COMPACT>(bias_tile, (wave + 3) * 16 + lq, lg);
     s_phase(sA, opaque(Ks), q0[0], q1[0], lq, lg);
 #pragma unroll
     for (int j = 0; j < 9; ++j) sB[j] = b1.v[j];
@@ -335,7 +357,7 @@ __global__ __launch_bounds__(192, 3) void window_attn_f32_kernel(const float* __
   // tile 0 softmax  ||  tile 1 scores
   softmax_with_next_scores<SHIFTED>(sA, sB, Ks, q0[1], q1[1], wave * 16 + lq, lq, lg, zcut, hcut, kz_bits, kh_bits, mx, sum);
   {
-    const BiasRowF b2 = load_bias_row(bias_tile, (wave + 6) * 16 + lq, lg);
+    const BiasRowF b2 = load_bias_row<COMPACT>(bias_tile, (wave + 6) * 16 + lq, lg);
     pv_phase(sA, opaque(Vs), mx, sum, qtok[0], lq, lg, out, lse, C, heads, hd);
 #pragma unroll
     for (int j = 0; j < 9; ++j) sA[j] = b2.v[j];
@@ -374,9 +396,8 @@ int check_geom(int Z, int H, int W) {
 
 }  // namespace
 
-extern "C" int pangu_window_attn_fwd(pangu_stream_t stream, const float* qkv, const float* qkv_bias,
-                                     const float* esb, float* out, float* lse, int Z, int H, int W, int C,
-                                     int heads, int shifted) {
+static int launch_attn_fwd(pangu_stream_t stream, const float* qkv, const float* qkv_bias, const float* esb, float* out,
+                           float* lse, int Z, int H, int W, int C, int heads, int shifted, bool compact) {
   if (!qkv || !qkv_bias || !esb || !out) return PANGU_E_NULL;
   if (int e = check_geom(Z, H, W)) return e;
   if (heads <= 0 || C != heads * PANGU_HEAD_DIM) return PANGU_E_SHAPE;
@@ -384,13 +405,28 @@ extern "C" int pangu_window_attn_fwd(pangu_stream_t stream, const float* qkv, co
   const int n_pairs = g.types * heads;
   const int grid = ((n_pairs + 7) / 8) * 8 * g.nLon;
   hipStream_t s = (hipStream_t)stream;
-  if (shifted)
-    hipLaunchKernelGGL(window_attn_f32_kernel<true>, dim3(grid), dim3(192), 0, s, qkv, qkv_bias, esb, out, lse, g, C,
-                       heads, n_pairs);
-  else
-    hipLaunchKernelGGL(window_attn_f32_kernel<false>, dim3(grid), dim3(192), 0, s, qkv, qkv_bias, esb, out, lse, g,
-                       C, heads, n_pairs);
+#define PANGU_LAUNCH_ATTN(SH, CP)                                                                                      \
+  hipLaunchKernelGGL((window_attn_f32_kernel<SH, CP>), dim3(grid), dim3(192), 0, s, qkv, qkv_bias, esb, out, lse, g, C, \
+                     heads, n_pairs)
+  if (shifted) {
+    if (compact) PANGU_LAUNCH_ATTN(true, true); else PANGU_LAUNCH_ATTN(true, false);
+  } else {
+    if (compact) PANGU_LAUNCH_ATTN(false, true); else PANGU_LAUNCH_ATTN(false, false);
+  }
+#undef PANGU_LAUNCH_ATTN
   return pangu_launch_status();
+}
+
+extern "C" int pangu_window_attn_fwd(pangu_stream_t stream, const float* qkv, const float* qkv_bias,
+                                     const float* esb, float* out, float* lse, int Z, int H, int W, int C,
+                                     int heads, int shifted) {
+  return launch_attn_fwd(stream, qkv, qkv_bias, esb, out, lse, Z, H, W, C, heads, shifted, false);
+}
+
+extern "C" int pangu_window_attn_fwd_compact(pangu_stream_t stream, const float* qkv, const float* qkv_bias,
+                                             const float* esb_compact, float* out, float* lse, int Z, int H, int W, int C,
+                                             int heads, int shifted) {
+  return launch_attn_fwd(stream, qkv, qkv_bias, esb_compact, out, lse, Z, H, W, C, heads, shifted, true);
 }
 
 extern "C" int pangu_window_index_export(pangu_stream_t stream, int32_t* out, int Z, int H, int W, int shifted) {

@@ -72,10 +72,13 @@ def earth_block(blk, x, Z, H, W, roll, out=None):
     s2 = dp.sample_scale(blk.training) if hasattr(dp, "sample_scale") else 1.0
     if s1 != 0.0:
         qkv = ops.linear(x2, att.linear1.weight, att.linear1.bias)                      # (B*N, 3C)
-        esb = att.earth_specific_bias[0]
+        # inference on the paper's compact bias table (PanguModel.use_compact_bias): 10 MB instead of 62 MB per block
+        esb_c = getattr(att, "_esb_compact", None)
+        cp = esb_c is not None
+        esb = esb_c if cp else att.earth_specific_bias[0]
         o = torch.cat([ops.window_attention(qkv[b * N:(b + 1) * N], att.linear1.bias, esb, Z, H, W,
-                                            att.head_number, roll) for b in range(B)], 0) if B > 1 else \
-            ops.window_attention(qkv, att.linear1.bias, esb, Z, H, W, att.head_number, roll)
+                                            att.head_number, roll, compact=cp) for b in range(B)], 0) if B > 1 else \
+            ops.window_attention(qkv, att.linear1.bias, esb, Z, H, W, att.head_number, roll, compact=cp)
         if _FUSE_LN and C in (192, 384):     # projection + post-norm residual in one launch (the GEMM tile spans the row)
             x1 = ops.linear_ln_residual(o, att.linear2.weight, att.linear2.bias, x2, blk.norm1.weight, blk.norm1.bias,
                                         branch_scale=s1)

@@ -270,19 +270,25 @@ def linear_wgrad(dc, a, want_bias=True):
     return dw, db
 
 
-def window_attention(qkv, qkv_bias, esb, Z, H, W, heads, shifted, want_lse=False):
+def window_attention(qkv, qkv_bias, esb, Z, H, W, heads, shifted, want_lse=False, compact=False):
+    """esb: the expanded (types, heads, 144, 144) table, or with compact=True the paper's compact table laid out
+    (types, heads, 3312) (weights.compact_bias_table): same result bit for bit, 6.3x fewer bias bytes."""
     lib = _lib.load()
     N, C3 = qkv.shape
     C = C3 // 3
     if N != Z * H * W:
         raise RuntimeError(f"window_attention: {N} tokens != {Z}x{H}x{W}")
+    types = (Z // 2) * ((H + 5) // 6)
+    want = (types, heads, 3312) if compact else (types, heads, 144, 144)
+    if tuple(esb.shape) != want:
+        raise RuntimeError(f"window_attention: bias table {tuple(esb.shape)} != {want}")
     out = torch.empty((N, C), dtype=torch.float32, device=qkv.device)
     lse = torch.empty((N, heads), dtype=torch.float32, device=qkv.device) if want_lse else None
     Np = (Z // 2) * ((H + 5) // 6) * (W // 12) * 144          # padded token count: the core's FLOPs (4*Np*144*C)
     with _timed("attn", 4.0 * Np * 144 * C):
-        _lib.check(lib.pangu_window_attn_fwd(_stream(), _chk(qkv, "qkv"), _chk(qkv_bias, "qkv_bias"), _chk(esb, "esb"),
-                                             out.data_ptr(), lse.data_ptr() if want_lse else None, Z, H, W, C, heads,
-                                             int(shifted)), "window_attn_fwd")
+        fn = lib.pangu_window_attn_fwd_compact if compact else lib.pangu_window_attn_fwd
+        _lib.check(fn(_stream(), _chk(qkv, "qkv"), _chk(qkv_bias, "qkv_bias"), _chk(esb, "esb"), out.data_ptr(),
+                      lse.data_ptr() if want_lse else None, Z, H, W, C, heads, int(shifted)), "window_attn_fwd")
     return (out, lse) if want_lse else out
 
 

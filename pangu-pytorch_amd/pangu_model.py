@@ -43,6 +43,7 @@ class PanguModel(nn.Module):
         self.compute_dtype = torch.float32
         self.f32_split = False
         self._shadow = None
+        self._compact_bias = False
 
     def set_compute_dtype(self, dtype, f32_split=False):
         """torch.float32 (default; parity <= 1e-3 with the reference) or torch.bfloat16 (inference: bf16 activations and
@@ -64,6 +65,43 @@ class PanguModel(nn.Module):
         through `param.data` in place (`p.data.copy_(..)`), which leaves no trace the cache could check."""
         if self._shadow is not None:
             self._shadow.clear()
+        for m in self.modules():              # compact bias tables are derived from the parameters too
+            if hasattr(m, "_esb_compact"):
+                m._esb_compact = None
+
+    def use_compact_bias(self, enable=True):
+        """fp32 INFERENCE on the paper's compact Earth-specific bias (reference layers.py:306-357, :384-391: a
+        (3312, types, heads) table gathered through `position_index`; this model, like the reference, keeps the EXPANDED
+        (1, types, heads, 144, 144) parameter of the ONNX export).  Each block's expanded parameter is folded back to the
+        compact table once (weights.compact_bias_table) and the attention kernel gathers from it: 10 MB instead of 62 MB
+        of bias per block, results bit-identical.  Raises ValueError when a block's parameter is not an expansion of a
+        compact table (e.g. the reference's random initialisation of the expanded tensor): nothing is approximated.
+        The tables are dropped whenever the weights may have changed (invalidate_shadows) and rebuilt on the next forward;
+        training and the bf16 path always read the expanded parameter."""
+        self._compact_bias = bool(enable)
+        if not enable:
+            for m in self.modules():
+                if hasattr(m, "_esb_compact"):
+                    m._esb_compact = None
+            return self
+        self._build_compact_bias()
+        return self
+
+    def _build_compact_bias(self):
+        from . import weights
+        for name, m in self.named_modules():
+            p = getattr(m, "earth_specific_bias", None)
+            if p is None:
+                continue
+            stamp = (p._version, p.data_ptr(), p.device)            # an optimizer step / in-place edit bumps _version
+            if getattr(m, "_esb_compact", None) is not None and getattr(m, "_esb_compact_stamp", None) == stamp:
+                continue
+            m._esb_compact = None
+            table = weights.compact_bias_table(p.detach())
+            if table is None:
+                raise ValueError(f"{name}.earth_specific_bias is not an expansion of a compact (3312, types, heads) table: "
+                                 "compact-bias inference would change the result; call use_compact_bias(False)")
+            m._esb_compact, m._esb_compact_stamp = table, stamp
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
@@ -123,6 +161,8 @@ class PanguModel(nn.Module):
                 return autograd_bf16.forward_train(self, input, input_surface, statistics, maps, const_h)
             return fused_bf16.forward(self, input, input_surface, statistics, maps, const_h)
         from . import ops
+        if self._compact_bias and not grad_path:
+            self._build_compact_bias()            # no-op while the tables exist (dropped with the weight shadows)
         with ops.f32_split(self.f32_split):
             return self._forward_f32(input, input_surface, statistics, maps, const_h, grad_path)
 

@@ -60,6 +60,22 @@ def expand_bias(compact):
     return compact[idx].view(WTOK, WTOK, types, heads).permute(2, 3, 0, 1).unsqueeze(0).contiguous()
 
 
+def compact_bias_table(expanded):
+    """(1, types, heads, 144, 144) -> the kernel-side compact table (types, heads, 3312) fp32, or None when the expanded
+    tensor is NOT an expansion of a compact table (e.g. the reference's trunc-normal initialisation of the expanded
+    parameter, layers.py:306-314): every entry must equal the entries it shares a position index with, bit for bit.  The
+    published weights are expansions (the paper trains the compact table; the ONNX export expanded it)."""
+    idx = position_index(expanded.device)
+    types, heads = expanded.shape[1], expanded.shape[2]
+    e = expanded[0].reshape(types, heads, WTOK * WTOK)
+    first = torch.zeros(3312, dtype=torch.long, device=e.device)
+    first.scatter_(0, idx.flip(0), torch.arange(WTOK * WTOK - 1, -1, -1, device=e.device))     # first position of every index
+    table = e[:, :, first].contiguous()
+    if not torch.equal(table[:, :, idx], e):
+        return None
+    return table.float().contiguous()
+
+
 def compact_bias(expanded):
     """(1, types, heads, 144, 144) -> (3312, types, heads): mean over the entries that share a position index (exact
     inverse of expand_bias; for a trained expanded table it is the least-squares compact fit).  6.3x fewer bytes."""

@@ -74,3 +74,58 @@ def test_onnx_route_and_checkpoint_forward_golden(golden_dir, tmp_path):
         out, out_s = m2(inp, inp_s, stats, maps, const_h)
     assert cases.compare_summary(out, g, "model.out", 1e-3) < 1e-3
     assert cases.compare_summary(out_s, g, "model.out_surface", 1e-3) < 1e-3
+
+
+@pytest.mark.parametrize("C", [192, 384])
+@pytest.mark.parametrize("shifted", [False, True])
+def test_window_attention_compact_bias_bit_exact(P, C, shifted):
+    """Inference on the paper's compact bias table (reference layers.py:306-357, :384-391): the kernel's
+    closed-form position index + gather gives the SAME BITS as the expanded (types, heads, 144, 144) table of the same
+    values, and the table matches the oracle's attention through the expanded tensor."""
+    from pangu_pytorch_amd import weights
+    st = cases.STAGES[C]
+    Z, H, W, heads, types = st["Z"], st["H"], 24, st["heads"], st["types"]
+    N = Z * H * W
+    compact = synth.uniform((3312, types, heads), 91, 0.5)
+    esb = weights.expand_bias(compact)                                  # (1, types, heads, 144, 144)
+    qkv = synth.uniform((1, N, 3 * C), 92, 1.5)
+    b1 = synth.uniform((3 * C,), 93, 0.5)
+    table = weights.compact_bias_table(esb)
+    assert table is not None and torch.equal(table, compact.permute(1, 2, 0))
+    o_e, l_e = P.ops.window_attention(qkv[0].cuda(), b1.cuda(), esb[0].cuda(), Z, H, W, heads, shifted, want_lse=True)
+    o_c, l_c = P.ops.window_attention(qkv[0].cuda(), b1.cuda(), table.cuda(), Z, H, W, heads, shifted, want_lse=True, compact=True)
+    assert torch.equal(o_e, o_c) and torch.equal(l_e, l_c)
+    ref, _ = O.window_attention_core(qkv, b1, esb, Z, H, W, heads, shifted)
+    assert ((o_c.cpu() - ref[0]).abs().max() / ref.abs().max()).item() < 1e-5
+
+
+def test_model_compact_bias_mode(P):
+    """PanguModel.use_compact_bias: refuses the reference's random expanded initialisation; with expansions of compact
+    tables in every block the fp32 forward is bit-identical to the expanded path, survives an in-place weight edit (the
+    tables are rebuilt from the parameter's version stamp), and training still runs on the expanded parameter."""
+    from pangu_pytorch_amd import weights
+    torch.manual_seed(3)
+    m = P.PanguModel(device="cuda").cuda().eval()
+    with pytest.raises(ValueError):
+        m.use_compact_bias(True)
+    m.use_compact_bias(False)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    with torch.no_grad():
+        for mod in m.modules():
+            p = getattr(mod, "earth_specific_bias", None)
+            if p is not None:
+                c = torch.randn(3312, p.shape[1], p.shape[2], generator=g, device="cuda") * 0.02
+                p.copy_(weights.expand_bias(c))
+    inp, inp_s, stats, maps, const_h = cases.model_inputs("cuda")
+    with torch.no_grad():
+        ref, ref_s = m(inp, inp_s, stats, maps, const_h)
+        m.use_compact_bias(True)
+        out, out_s = m(inp, inp_s, stats, maps, const_h)
+        assert torch.equal(out, ref) and torch.equal(out_s, ref_s)
+        blk = m.layers[1].blocks[0].attention
+        assert blk._esb_compact is not None and blk._esb_compact.shape == (64, 12, 3312)
+        blk.earth_specific_bias.mul_(2.0)                             # still an expansion; the stamp changes
+        out2, _ = m(inp, inp_s, stats, maps, const_h)
+        m.use_compact_bias(False)
+        ref2, _ = m(inp, inp_s, stats, maps, const_h)
+        assert torch.equal(out2, ref2) and not torch.equal(out2, out)

@@ -85,3 +85,19 @@ def test_load_onnx_initializers_full_key_table(golden_dir):
     for k, p in m.named_parameters():
         assert torch.equal(p, want[k]), k
         assert not p.requires_grad
+
+
+def test_compact_bias_table_roundtrip_and_refusal():
+    """weights.compact_bias_table: an expansion of a compact table folds back to exactly that table (index axis last); an
+    expanded tensor that is NOT an expansion (the reference's random init of the expanded parameter, layers.py:306-314) is
+    refused -- the compact inference mode never approximates."""
+    from pangu_pytorch_amd import weights
+    g = torch.Generator().manual_seed(5)
+    compact = torch.randn(3312, 7, 3, generator=g)
+    expanded = weights.expand_bias(compact)
+    table = weights.compact_bias_table(expanded)
+    assert table.shape == (7, 3, 3312) and torch.equal(table, compact.permute(1, 2, 0))
+    bad = expanded.clone()
+    bad[0, 2, 1, 17, 5] += 1e-3                   # one of several entries sharing an index
+    assert weights.compact_bias_table(bad) is None
+    assert weights.compact_bias_table(torch.randn(1, 7, 3, 144, 144, generator=g)) is None

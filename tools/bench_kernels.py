@@ -203,12 +203,15 @@ def attn():
         qkv = torch.randn(N, 3 * C, device="cuda")
         b1 = torch.randn(3 * C, device="cuda")
         esb = torch.randn(types, heads, 144, 144, device="cuda") * 0.1
+        table = torch.randn(types, heads, 3312, device="cuda") * 0.1      # the paper's compact bias table, kernel layout
         for sh in (False, True):
             ms = timeit(lambda: ops.window_attention(qkv, b1, esb, Z, H, W, heads, sh))
+            msc = timeit(lambda: ops.window_attention(qkv, b1, table, Z, H, W, heads, sh, compact=True))
             Np = (Z // 2) * ((H + 5) // 6) * (W // 12) * 144
             fl = 4.0 * Np * 144 * C
             by = (N * 4 * C + esb.numel()) * 4.0
-            print(f"attn C={C} shifted={int(sh)}: {ms:7.3f} ms  {fl / ms / 1e9:6.1f} TF/s  {by / ms / 1e6:7.1f} GB/s (algorithmic)")
+            print(f"attn C={C} shifted={int(sh)}: {ms:7.3f} ms  {fl / ms / 1e9:6.1f} TF/s  {by / ms / 1e6:7.1f} GB/s (algorithmic)"
+                  f"   | compact bias table {msc:7.3f} ms  {fl / msc / 1e9:6.1f} TF/s")
 
 
 def rows():
