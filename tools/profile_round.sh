@@ -10,6 +10,9 @@ export TMPDIR=/tmp
 TAG=${1:-r02}
 mkdir -p gpurun_out
 bash tools/pmc_traffic.sh $TAG > gpurun_out/${TAG}_pmc_traffic.log 2>&1
+# bench.py reads roofline.traffic from profiles/pmc_traffic_<dtype>.json (and checks the kernel sources' hashes): let the
+# bench line at the end of this script see the tables just measured
+cp gpurun_out/pmc_${TAG}_f32/pmc_traffic_f32.json gpurun_out/pmc_${TAG}_bf16/pmc_traffic_bf16.json profiles/ 2>/dev/null
 for DT in f32 bf16; do
   rm -rf /tmp/tr_$DT
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr_$DT -- python3 tools/profile_train.py $DT 3 1 > gpurun_out/${TAG}_train_${DT}.log 2>&1
