@@ -251,7 +251,7 @@ def wgrad_workspace(device):
 
 def linear_wgrad(dc, a, want_bias=True):
     """dW[N,K] = dc[M,N]^T @ a[M,K], db[N] = colsum(dc), ADDED into zero-initialised buffers; the token slabs' partial tiles
-    travel through a per-device scratch buffer (96 MB, allocated on first use) and one reduce launch instead of fp32 atomics."""
+    travel through a per-device scratch buffer (96 MB, allocated on first use; one per device: do not run weight gradients of one device on two streams at once; the few fp32 shapes whose slabs need 108 MB keep the atomic tail, measured level) and one reduce launch instead of fp32 atomics."""
     lib = _lib.load()
     ws = wgrad_workspace(dc.device)
     dp, lddc = _rows(dc, "wgrad.dc")

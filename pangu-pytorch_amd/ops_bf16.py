@@ -202,7 +202,7 @@ _wgrad_workspace = ops.wgrad_workspace      # one scratch buffer per device for 
 
 def linear_wgrad(dc, a, want_bias=True):
     """dW[N,K] (fp32) = dc[M,N]^T @ a[M,K], db[N] = colsum(dc); bf16 operands (row-strided views allowed).  The partial tiles of
-    the token slabs travel through a per-device scratch buffer (96 MB, allocated on first use) instead of fp32 atomics."""
+    the token slabs travel through a per-device scratch buffer (96 MB, allocated on first use; one per device: do not run weight gradients of one device on two streams at once; the few fp32 shapes whose slabs need 108 MB keep the atomic tail, measured level) instead of fp32 atomics."""
     lib = _lib.load()
     ws = _wgrad_workspace(dc.device)
     dp, lddc = _rows(dc, "wgrad.dc")
