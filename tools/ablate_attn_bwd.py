@@ -16,7 +16,7 @@ P, I = ctypes.c_void_p, ctypes.c_int
 F32 = len(sys.argv) > 1 and sys.argv[1] == "f32"
 if F32:
     from pangu_pytorch_amd import ops  # noqa: E402
-    lib = ctypes.CDLL(os.path.join(ROOT, "scratch", "libattn_bwd_stamp.so"))
+    lib = ctypes.CDLL(os.path.join(ROOT, "scratch", os.environ.get("PANGU_BWD_LIB", "libattn_bwd_stamp.so")))
     lib.pangu_window_attn_bwd.argtypes = [P] * 10 + [I] * 6
     stream = torch.cuda.current_stream().cuda_stream
     for C, Z, H, W, heads, types in ((192, 8, 181, 360, 6, 124), (384, 8, 91, 180, 12, 64)):
@@ -45,7 +45,7 @@ if F32:
             print(f"f32 C={C} shifted={sh}: {a.elapsed_time(e):.3f} ms; owner wave per window (cycles): staging pass {v[0] / n:.0f} (wait at the top barrier {v[6] / n:.0f}, "
                   f"LDS writes + barrier {v[7] / n:.0f})  phase 1 {v[1] / n:.0f}  barriers A+B {v[2] / n:.0f}  dK/dV hand-over {v[3] / n:.0f}  phase 2 {v[4] / n:.0f}")
     sys.exit(0)
-lib = ctypes.CDLL(os.path.join(ROOT, "scratch", "libattn_bwd_stamp.so"))
+lib = ctypes.CDLL(os.path.join(ROOT, "scratch", os.environ.get("PANGU_BWD_LIB", "libattn_bwd_stamp.so")))
 lib.pangu_window_attn_bwd_bf16.argtypes = [P] * 10 + [I] * 6
 bf = torch.bfloat16
 stream = torch.cuda.current_stream().cuda_stream

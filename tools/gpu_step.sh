@@ -2,6 +2,10 @@
 # scratch driver for one gpurun call (rewritten per run)
 cd /root/repo
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_bf16.py -x -q -k "proj_mlp or mlp_ln_residual" 2>&1 | tail -8 > gpurun_out/pm_test.log
-timeout 300 python tools/bench_kernels.py mlp_fused 2>&1 | grep -v amdgpu > gpurun_out/pm_bench.log
-cat gpurun_out/pm_test.log gpurun_out/pm_bench.log
+for rep in 1 2; do
+for v in 0 1; do
+  echo "stagger=$v" >> gpurun_out/stag.log
+  PANGU_BWD_LIB=libbwd_stag$v.so timeout 300 python tools/ablate_attn_bwd.py 2>&1 | grep "^C=" | cut -c1-40 >> gpurun_out/stag.log
+done
+done
+cat gpurun_out/stag.log
