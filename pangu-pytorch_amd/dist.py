@@ -16,10 +16,22 @@ import torch
 import torch.distributed as tdist
 
 
-def init_dist(launcher="pytorch", backend="nccl", **kwargs):
-    """reference utils_dist.py:13-28: rank from the environment, one GPU per process."""
-    if launcher != "pytorch":
-        raise ValueError(f"unsupported launcher {launcher!r} (only the torch.distributed.run env:// rendezvous)")
+def init_dist(launcher="pytorch", backend="nccl", port=None, **kwargs):
+    """reference utils_dist.py:13-59: one GPU per process; `launcher` = "pytorch" (rank from the torch.distributed.run
+    environment, :24-28) or "slurm" (rank / world / master from SLURM_PROCID / SLURM_NTASKS / SLURM_NODELIST, :31-59)."""
+    if launcher == "slurm":
+        import subprocess
+        proc_id, ntasks = int(os.environ["SLURM_PROCID"]), int(os.environ["SLURM_NTASKS"])
+        if port is not None:
+            os.environ["MASTER_PORT"] = str(port)
+        os.environ.setdefault("MASTER_PORT", "29500")           # torch.distributed's default port, as the reference
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"] = subprocess.getoutput(
+                f"scontrol show hostname {os.environ['SLURM_NODELIST']} | head -n1")
+        os.environ["WORLD_SIZE"], os.environ["RANK"] = str(ntasks), str(proc_id)
+        os.environ["LOCAL_RANK"] = str(proc_id % max(torch.cuda.device_count(), 1))
+    elif launcher != "pytorch":
+        raise ValueError(f"Invalid launcher type: {launcher}")
     rank = int(os.environ["RANK"])
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend == "nccl":
@@ -100,14 +112,18 @@ class FlatGradSync:
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
         # the kernels that WRITE a whole parameter gradient (the Earth-specific bias tables: 1.04 of the 1.107 GB) store it
         # straight into its flat slot (ops.grad_slot); what is left for _on_grad to copy are the small accumulated tensors
-        if dev.type == "cuda":
+        self._cuda = dev.type == "cuda"
+        if self._cuda:
             from . import ops
-            ops.register_grad_slots({p: v for p, (_, v) in self._slot.items() if p.dim() == 5})
+            self._ops = ops
+            ops.register_grad_slots({p: v for p, (_, v) in self._slot.items() if p.dim() == 5}, owner=self)
         self.copied_bytes = 0      # bytes moved by the copy fallback since construction (diagnostic)
 
     # -- per-parameter hook: move the fresh gradient into its flat slot; launch every bucket that became complete
     def _on_grad(self, p):
         bi, view = self._slot[p]
+        if self._cuda:
+            self._ops.release_grad_slot(p)      # every node's gradient has arrived: the slot may be claimed again
         if p.grad is None:              # a custom Function returned None (DropPath-dropped branch): contributes zeros
             view.zero_()
             p.grad = view
@@ -149,6 +165,9 @@ class FlatGradSync:
         self._fired = set()
         self._next = 0
         self._pending = [len(b[2]) for b in self.buckets]
+        if self._cuda:
+            for p in self._slot:
+                self._ops.release_grad_slot(p)
 
     def zero_grad(self):
         """Zero the flat buffer in one memset; gradients stay views into it."""
@@ -158,9 +177,8 @@ class FlatGradSync:
         for h in self._hooks:
             h.remove()
         self._hooks = []
-        if self.flat.is_cuda:
-            from . import ops
-            ops.register_grad_slots({})
+        if self._cuda:
+            self._ops.unregister_grad_slots(self)
 
 
 def gather_grad(params, world_size=None):

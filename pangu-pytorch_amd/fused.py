@@ -74,6 +74,10 @@ def earth_block(blk, x, Z, H, W, roll, out=None):
         qkv = ops.linear(x2, att.linear1.weight, att.linear1.bias)                      # (B*N, 3C)
         # inference on the paper's compact bias table (PanguModel.use_compact_bias): 10 MB instead of 62 MB per block
         esb_c = getattr(att, "_esb_compact", None)
+        if esb_c is not None:                 # stale table (weights changed since it was folded): the expanded parameter
+            p = att.earth_specific_bias
+            if getattr(att, "_esb_compact_stamp", None) != (p._version, p.data_ptr(), p.device) or esb_c.device != p.device:
+                att._esb_compact = esb_c = None
         cp = esb_c is not None
         esb = esb_c if cp else att.earth_specific_bias[0]
         o = torch.cat([ops.window_attention(qkv[b * N:(b + 1) * N], att.linear1.bias, esb, Z, H, W,

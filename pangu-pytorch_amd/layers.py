@@ -89,6 +89,15 @@ class EarthAttention3D(nn.Module):
         wtok = window_size[0] * window_size[1] * window_size[2]
         self.earth_specific_bias = nn.Parameter(torch.zeros(1, self.type_of_windows, heads, wtok, wtok, device=device))
         _trunc_normal_(self.earth_specific_bias, std=0.02)
+        self._construct_index()
+
+    def _construct_index(self):
+        """reference layers.py:319-357: `self.position_index`, int64 (20736,) in [0, 3312) -- a plain attribute there too
+        (not a buffer, not in state_dict); the reference builds it and never reads it (the gather is commented out,
+        :384-391).  Here it is the closed form of weights.position_index (bit-exact against the reference's loops,
+        tests/test_weights.py) and what weights.expand_bias / compact_bias index with."""
+        from . import weights
+        self.position_index = weights.position_index()
 
 
 class EarthSpecificBlock(nn.Module):
@@ -108,6 +117,17 @@ class EarthSpecificBlock(nn.Module):
 
     def forward(self, x, Z, H, W, roll, out=None):
         return fused.earth_block(self, x, Z, H, W, roll, out=out)
+
+    def gen_mask(self, x):
+        """reference layers.py:153-181: the shifted-window attention mask for a padded activation `x` (1, Z, Hp, W, C) ->
+        (W/12, types, 144, 144) fp32 in {0, -100}.  The attention kernels never materialise it (closed form per lane,
+        csrc/common.h win_mask); this returns the same kernel-side closed form, exported by `pangu_window_mask_export`
+        (bit-exact against the reference's slicing construction, tests/test_gpu_parity.py), expanded over the longitude
+        windows as the reference's tensor is (its values do not depend on the longitude window: no W slicing)."""
+        from . import ops
+        _, Z, Hp, W, _ = x.shape
+        m = ops.window_mask(Z, Hp - self.padding_back - self.padding_front, W, x.device)      # (types, 144, 144)
+        return m.unsqueeze(0).expand(W // self.window_size[2], -1, -1, -1)
 
 
 class EarthSpecificLayer(nn.Module):

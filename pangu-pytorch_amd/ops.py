@@ -98,24 +98,45 @@ _zero_arena = None        # [flat fp32 zeros, used elements]: see zero_arena
 # Gradient slots (dist.FlatGradSync): parameter storage address -> the fp32 view of the flat gradient buffer that will hold
 # that parameter's gradient.  Backward kernels that WRITE (not accumulate) a parameter gradient -- the Earth-specific bias
 # tables, 94 % of the 1.107 GB -- store straight into the slot, so the flat buffer is filled without a copy pass.
-_grad_slots = {}
+_grad_slots = {}          # parameter storage address -> (parameter, flat view, owner)
+_grad_claimed = set()     # addresses whose slot was handed to a kernel since the parameter's gradient was last accumulated
 
 
-def register_grad_slots(slots):
-    """slots: {parameter: flat-buffer view}; replaces the registry (dist.FlatGradSync calls this; {} clears it)."""
-    global _grad_slots
-    _grad_slots = {p.data_ptr(): (p, v) for p, v in slots.items()}
+def register_grad_slots(slots, owner=None):
+    """slots: {parameter: flat-buffer view}, MERGED into the registry under `owner` (a dist.FlatGradSync); a parameter
+    registered before moves to the new owner."""
+    for p, v in slots.items():
+        _grad_slots[p.data_ptr()] = (p, v, owner)
+        _grad_claimed.discard(p.data_ptr())
+
+
+def unregister_grad_slots(owner):
+    """Drop the entries registered under `owner` (only those: another FlatGradSync's slots stay)."""
+    for k in [k for k, hit in _grad_slots.items() if hit[2] is owner]:
+        del _grad_slots[k]
+        _grad_claimed.discard(k)
+
+
+def release_grad_slot(param):
+    """The parameter's gradient has been accumulated (or the step is over): its slot may be handed out again."""
+    _grad_claimed.discard(param.data_ptr())
 
 
 def grad_slot(param):
-    """The flat-buffer view for this parameter's gradient, or None: no registry entry, or the parameter already holds a
-    gradient (accumulation over several backward passes: autograd must ADD, so the kernel may not overwrite the slot)."""
-    hit = _grad_slots.get(param.data_ptr())
-    if hit is None:
+    """The flat-buffer view for this parameter's gradient, or None.  None when: no registry entry; the parameter already
+    holds a gradient (accumulation over several backward passes: autograd must ADD, so a kernel may not overwrite the slot);
+    or the slot was ALREADY handed out in this backward pass -- one parameter can feed several autograd nodes (per-GPU batch
+    B > 1 calls the block function once per sample; a model applied twice in one graph) and autograd's input buffer still
+    holds the first node's result as an alias of the slot until every edge has arrived: a second kernel writing the same
+    memory would turn g1 + g2 into 2*g2.  Later nodes get None, write a fresh tensor, and autograd adds it to the slot."""
+    k = param.data_ptr()
+    hit = _grad_slots.get(k)
+    if hit is None or k in _grad_claimed:
         return None
-    p, v = hit
+    p, v, _ = hit
     if p.grad is not None or v.numel() != param.numel() or v.device != param.device:
         return None
+    _grad_claimed.add(k)
     return v
 
 

@@ -15,6 +15,12 @@ from .layers import (DownSample, EarthSpecificLayer, PatchEmbedding_pretrain, Pa
                      _trunc_normal_)
 
 
+def compact_bias_stamp(p):
+    """What a compact bias table was derived from: an optimizer step / in-place edit bumps `_version`, `p.data = w` swaps
+    the storage.  fused.earth_block compares it at the point of use (a block called directly after a weight update)."""
+    return (p._version, p.data_ptr(), p.device)
+
+
 class PanguModel(nn.Module):
     def __init__(self, depths=[2, 6, 6, 2], num_heads=[6, 12, 12, 6], dims=[192, 384, 384, 192],
                  patch_size=(2, 4, 4), device=None):
@@ -93,7 +99,7 @@ class PanguModel(nn.Module):
             p = getattr(m, "earth_specific_bias", None)
             if p is None:
                 continue
-            stamp = (p._version, p.data_ptr(), p.device)            # an optimizer step / in-place edit bumps _version
+            stamp = compact_bias_stamp(p)
             if getattr(m, "_esb_compact", None) is not None and getattr(m, "_esb_compact_stamp", None) == stamp:
                 continue
             m._esb_compact = None
@@ -112,6 +118,9 @@ class PanguModel(nn.Module):
         out = super()._apply(fn, *args, **kwargs)
         if getattr(self, "_shadow", None) is not None:
             self._shadow.clear()
+        for m in self.modules():              # derived from the parameters as well (device / dtype moves)
+            if getattr(m, "_esb_compact", None) is not None:
+                m._esb_compact = None
         return out
 
     def __getstate__(self):

@@ -1,5 +1,5 @@
-"""Worker of tests/test_gpu_dp2.py: one rank of a 2-rank data-parallel training step of the REAL model on one GPU
-(gloo backend, both ranks share cuda:0).  Usage: torchrun --nproc-per-node 2 dp2_worker.py <out_dir> <dtype>"""
+"""Worker of tests/test_gpu_dp2.py: one rank of an N-rank data-parallel training step of the REAL model on one GPU
+(gloo backend, all ranks share cuda:0).  Usage: torchrun --nproc-per-node N dp2_worker.py <out_dir> <dtype>"""
 import os
 import sys
 
@@ -39,11 +39,13 @@ def main():
     torch.cuda.set_device(0)
     D.init_dist("pytorch", backend="gloo")
     rank, world = D.get_dist_info()
-    assert world == 2
     model = P.PanguModel(device="cuda").cuda().train()            # train(): DropPath ON (rates up to 0.2)
     model.load_state_dict(synth.fill_state_dict(cases.model_param_shapes(), "cuda"))
     model.set_compute_dtype(dtype)
     sync = D.FlatGradSync(model)
+    launches = []                       # bucket indices in the order this rank issued their collectives
+    launch = sync._launch
+    sync._launch = lambda bi: (launches.append(bi), launch(bi))[1]
     one_backward(model, rank, sync)
     torch.cuda.synchronize()
     names = {id(p): n for n, p in model.named_parameters()}
@@ -53,7 +55,9 @@ def main():
     pattern = [(n, m.n_dropped) for n, m in model.named_modules() if getattr(m, "n_dropped", 0)]
     info = {"copied_bytes": sync.copied_bytes, "flat_bytes": total, "launched_in_backward": sync.launched_in_backward,
             "buckets": len(sync.buckets), "dropped_branches": dropped, "pattern": pattern,
-            "order": [names[id(b[2][0][0])] for b in sync.buckets][:3]}
+            "order": [names[id(b[2][0][0])] for b in sync.buckets][:3], "launches": launches, "world": world,
+            "peak_gb": torch.cuda.max_memory_allocated() / 2**30}
+    torch.save(info, os.path.join(out_dir, f"dp_info_r{rank}.pt"))
     if rank == 0:
         torch.save({"flat": sync.flat.cpu(), "info": info}, os.path.join(out_dir, "dp2.pt"))
     torch.distributed.barrier()

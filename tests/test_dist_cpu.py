@@ -141,3 +141,74 @@ def test_default_buckets_on_real_model():
     # one ~62-64 MB bias table per block bucket
     for blk in b[1:3]:
         assert sum(p.numel() for p in blk) * 4 > 60e6
+
+
+class _SlotWriter(torch.autograd.Function):
+    """Like the HIP block function: its backward WRITES the parameter's gradient into the flat-buffer slot when
+    ops.grad_slot hands one out (pangu-pytorch_amd/autograd.py: desb_out=ops.grad_slot(esb))."""
+
+    @staticmethod
+    def forward(ctx, x, w, k):
+        ctx.k, ctx.w = k, w
+        return x * 1.0
+
+    @staticmethod
+    def backward(ctx, g):
+        from pangu_pytorch_amd import ops
+        out = ops.grad_slot(ctx.w)
+        gw = torch.full_like(ctx.w, float(ctx.k))
+        if out is not None:
+            out.copy_(gw)          # the kernel overwrites the slot
+            gw = out
+        return g, gw, None
+
+
+def test_grad_slot_handed_out_once_per_backward():
+    """one parameter feeding two slot-writing nodes in one backward (per-GPU batch B > 1, or a model applied
+    twice) must accumulate g1 + g2, not 2 * g_last: the slot is handed out once until the parameter's gradient is accumulated."""
+    from pangu_pytorch_amd import ops
+    w = torch.nn.Parameter(torch.zeros(4))
+    flat = torch.zeros(4)
+    owner = object()
+    ops.register_grad_slots({w: flat}, owner=owner)
+    try:
+        x = torch.ones(3, requires_grad=True)
+        y = _SlotWriter.apply(x, w, 1.0) + _SlotWriter.apply(x, w, 10.0)
+        hook = w.register_post_accumulate_grad_hook(lambda p: ops.release_grad_slot(p))
+        y.sum().backward()
+        assert torch.equal(w.grad, torch.full((4,), 11.0)), w.grad
+        # released by the hook: the next backward (gradient cleared) may claim the slot again
+        w.grad = None
+        assert ops.grad_slot(w) is flat and ops.grad_slot(w) is None
+        ops.release_grad_slot(w)
+        # a parameter that already holds a gradient never gets the slot (autograd must add)
+        w.grad = torch.ones(4)
+        assert ops.grad_slot(w) is None
+        hook.remove()
+        # registries of two owners are independent
+        w2, other = torch.nn.Parameter(torch.zeros(2)), object()
+        ops.register_grad_slots({w2: torch.zeros(2)}, owner=other)
+        ops.unregister_grad_slots(owner)
+        w.grad = None
+        assert ops.grad_slot(w) is None and ops.grad_slot(w2) is not None
+        ops.unregister_grad_slots(other)
+    finally:
+        ops.unregister_grad_slots(owner)
+
+
+def test_init_dist_slurm_launcher():
+    """reference utils_dist.py:31-59: rank / world / master taken from the SLURM environment."""
+    import subprocess
+    env = dict(os.environ, SLURM_PROCID="0", SLURM_NTASKS="1", SLURM_NODELIST="localhost", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from pangu_pytorch_amd import dist as D\n"
+            "D.init_dist('slurm', backend='gloo', port=%d)\n"
+            "import os, torch.distributed as t\n"
+            "assert D.get_dist_info() == (0, 1) and os.environ['RANK'] == '0' and os.environ['WORLD_SIZE'] == '1'\n"
+            "t.destroy_process_group()\n"
+            "try:\n    D.init_dist('mpi')\nexcept ValueError as e:\n    assert 'Invalid launcher' in str(e)\nelse:\n    raise SystemExit(3)\n"
+            % (ROOT, _free_port()))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]

@@ -22,10 +22,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_two_rank_train_step_matches_single_process_mean(tmp_path, dtype):
+@pytest.mark.parametrize("dtype,world", [("f32", 2), ("bf16", 2), ("bf16", 4)])
+def test_n_rank_train_step_matches_single_process_mean(tmp_path, dtype, world):
+    """world 4: four ranks of the bf16 model on one GPU (4 x 37 GB), DropPath on."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "helpers", "dp2_worker.py"), str(tmp_path), dtype]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -47,14 +48,19 @@ def test_two_rank_train_step_matches_single_process_mean(tmp_path, dtype):
     model.load_state_dict(synth.fill_state_dict(cases.model_param_shapes(), "cuda"))
     model.set_compute_dtype({"f32": torch.float32, "bf16": torch.bfloat16}[dtype])
     order = [p for b in D.default_buckets(model) for p in b if p.requires_grad]
+    # strictly equal collective order on every rank, all of it issued from inside backward
+    per_rank = [torch.load(os.path.join(tmp_path, f"dp_info_r{r}.pt")) for r in range(world)]
+    assert all(i["launches"] == list(range(20)) and i["launched_in_backward"] == 20 for i in per_rank), \
+        [(i["launches"], i["launched_in_backward"]) for i in per_rank]
+    assert len({tuple(map(tuple, i["pattern"])) for i in per_rank}) > 1      # the ranks did draw different DropPath patterns
     mean = torch.zeros_like(flat)
-    for rank in range(2):
+    for rank in range(world):
         model.zero_grad(set_to_none=True)
         W.one_backward(model, rank)
         off = 0
         for p in order:
             g = p.grad.float().flatten().cpu() if p.grad is not None else torch.zeros(p.numel())
-            mean[off:off + p.numel()] += 0.5 * g
+            mean[off:off + p.numel()] += g / world
             off += p.numel()
     # identical kernels on both sides; the weight-gradient kernels accumulate with fp32 atomics (order-dependent last bits)
     names = {id(p): n for n, p in model.named_parameters()}
@@ -67,7 +73,60 @@ def test_two_rank_train_step_matches_single_process_mean(tmp_path, dtype):
     print("dp2 worst parameters (abs err, name, max |mean|, max |flat|):", worst[:4])
     err = (flat - mean).abs().max().item() / mean.abs().max().item()
     l2 = ((flat - mean).norm() / mean.norm()).item()
-    print(f"dp2 {dtype}: max err rel to max |g| {err:.2e}, rel-L2 {l2:.2e}, copied {info['copied_bytes'] / 2**20:.1f} MiB of "
+    print(f"dp{world} {dtype}: max err rel to max |g| {err:.2e}, rel-L2 {l2:.2e}, copied {info['copied_bytes'] / 2**20:.1f} MiB of "
           f"{info['flat_bytes'] / 2**20:.0f} MiB; rank 0 dropped {info['dropped_branches']} branches, "
           f"{info['launched_in_backward']}/{info['buckets']} buckets launched inside backward")
     assert err < 1e-4 and l2 < 1e-4
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_flat_grad_sync_batch2_matches_per_sample_mean(dtype):
+    """ADVICE r2 (high): per-GPU batch B = 2 (the reference's BATCH_SIZE // n_gpus, finetune_fully.py:77) calls the block
+    function once per sample, so every Earth-specific bias table feeds TWO autograd nodes of one backward.  With
+    FlatGradSync registered the flat buffer must hold g(sample 0) + g(sample 1) of the batch loss -- the slot is handed to
+    the first node only (ops.grad_slot), the second node's gradient is added by autograd."""
+    import dp2_worker as W
+    import cases
+    import synth
+    import pangu_pytorch_amd as P
+    from pangu_pytorch_amd import dist as D, train
+    model = P.PanguModel(device="cuda").cuda().eval()      # autograd path, DropPath off (its draw ORDER differs between
+    # a B = 2 batch -- per block -- and two B = 1 passes -- per sample)
+    model.load_state_dict(synth.fill_state_dict(cases.model_param_shapes(), "cuda"))
+    model.set_compute_dtype({"f32": torch.float32, "bf16": torch.bfloat16}[dtype])
+    s0, s1 = W.sample(0), W.sample(1)
+    stats, maps, const_h = s0[4:]
+    order = [p for b in D.default_buckets(model) for p in b if p.requires_grad]
+    # reference: the two samples one at a time (B = 1 each, no FlatGradSync), same DropPath draw sequence
+    want = torch.zeros(sum(p.numel() for p in order))
+    for smp in (s0, s1):
+        model.zero_grad(set_to_none=True)
+        out, out_s = model(smp[0], smp[1], stats, maps, const_h)
+        train.weighted_l1_loss(out, out_s, smp[2], smp[3]).backward()
+        off = 0
+        for p in order:
+            if p.grad is not None:
+                want[off:off + p.numel()] += 0.5 * p.grad.float().flatten().cpu()
+            off += p.numel()
+    model.zero_grad(set_to_none=True)
+    sync = D.FlatGradSync(model)
+    try:
+            cat = lambda a, b: torch.cat((a, b), 0)
+        out, out_s = model(cat(s0[0], s1[0]), cat(s0[1], s1[1]), stats, maps, const_h)
+        train.weighted_l1_loss(out, out_s, cat(s0[2], s1[2]), cat(s0[3], s1[3])).backward()
+        sync.finish()
+        torch.cuda.synchronize()
+        got = sync.flat.cpu()
+    finally:
+        sync.remove()
+    # per bias table (the slot-written tensors) and overall
+    names = {id(p): n for n, p in model.named_parameters()}
+    off, worst = 0, (0.0, "")
+    for p in order:
+        if p.dim() == 5:
+            a, b = got[off:off + p.numel()], want[off:off + p.numel()]
+            worst = max(worst, (((a - b).norm() / b.norm().clamp_min(1e-30)).item(), names[id(p)]))
+        off += p.numel()
+    l2 = ((got - want).norm() / want.norm()).item()
+    print(f"B=2 FlatGradSync {dtype}: rel-L2 {l2:.2e}; worst bias table {worst}")
+    assert l2 < 2e-3 and worst[0] < 2e-3      # identical kernels; atomics order + bf16 rounding of the batch-mean loss scale

@@ -45,6 +45,19 @@ def test_window_mask_bit_exact(P, Z, H, W):
     assert torch.equal(got, O.shift_mask(Z, H, W))
 
 
+def test_block_gen_mask_dropin(P, golden_dir):
+    """EarthSpecificBlock.gen_mask(x) of the reference (layers.py:153-181): (nLon, types, 144, 144) in {0, -100}."""
+    g = np.load(os.path.join(golden_dir, "index.npz"))
+    for C, heads in ((192, 6), (384, 12)):
+        st = cases.STAGES[C]
+        blk = P.layers.EarthSpecificBlock(C, 0.0, heads, device="cuda")
+        x = torch.zeros(1, st["Z"], st["H"] + 5, 24, 1, device="cuda")          # the padded activation the reference passes
+        m = blk.gen_mask(x)
+        assert m.shape == (2, blk.type_of_windows, 144, 144) and m.dtype == torch.float32
+        assert torch.equal(m[0].cpu(), O.shift_mask(st["Z"], st["H"], 24)) and torch.equal(m[0], m[1])
+        assert np.array_equal(np.packbits(m[0].cpu().numpy() != 0), g[f"mask_bits_{C}"])
+
+
 def test_window_index_golden(P, golden_dir):
     g = np.load(os.path.join(golden_dir, "index.npz"))
     for C in (192, 384):

@@ -21,6 +21,18 @@ def test_position_index_matches_reference(golden_dir):
     assert int(mine.max()) == 3311 and mine.unique().numel() == 3312
 
 
+def test_attention_module_position_index_attribute(golden_dir):
+    """The reference's EarthAttention3D.position_index (layers.py:319-357): a plain attribute of every attention module,
+    not part of the state_dict."""
+    import pangu_pytorch_amd as P
+    g = np.load(os.path.join(golden_dir, "index.npz"))
+    for dim, heads in ((192, 6), (384, 12)):
+        att = P.layers.EarthAttention3D(dim, heads, 0, (2, 6, 12))
+        assert att.position_index.dtype == torch.int64 and att.position_index.shape == (20736,)
+        assert np.array_equal(att.position_index.numpy(), g["position_index"].astype(np.int64))
+        assert "position_index" not in att.state_dict()
+
+
 def test_expand_bias_matches_reference_gather(golden_dir):
     g = np.load(os.path.join(golden_dir, "extras.npz"))
     compact = synth.uniform((3312, 64, 12), synth.name_seed("compact_bias"), 0.5)
