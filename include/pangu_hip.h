@@ -43,6 +43,7 @@ extern "C" {
 #define PANGU_ACT_GELU 1       /* exact erf GELU, reference layers.py:261; aux (optional) receives the pre-activation */
 #define PANGU_ACT_GELU_BWD 2   /* C = (A @ W^T) * gelu'(aux): backward through the GELU, aux = saved pre-activation */
 #define PANGU_ACT_ADD 3        /* C = A @ W^T + bias + aux: residual-gradient accumulation fused into the data-gradient GEMM */
+#define PANGU_ACT_GELU_BWD_H 4 /* bf16 only (pangu_linear_gelu_bwd_bf16): PANGU_ACT_GELU_BWD, and h = GELU(aux) is written too */
 
 typedef void* pangu_stream_t;  /* hipStream_t */
 
@@ -225,6 +226,20 @@ int pangu_linear_ln_residual_fwd_bf16(pangu_stream_t stream, const void* A, int 
 int pangu_mlp_ln_residual_fwd_bf16(pangu_stream_t stream, const void* x, int ldx, const void* w_packed, const float* b1,
                                    const float* b2, const float* gamma, const float* beta, void* out, int ldo, int M,
                                    int C, float branch_scale);
+/* Training forward of the same branch (the bf16 counterpart of reference models/pangu_sample.py:45-77's forward through
+ * layers.py:251, :264-270): as above, and the two tensors the backward needs leave from the registers they live in --
+ *   pre [M][4C] bf16 (row stride ldp): x W1^T + b1 BEFORE the GELU; may be NULL (recompute mode: nothing but m is kept);
+ *   m   [M][C]  bf16 (row stride ldm): GELU(pre) W2^T + b2 BEFORE the LayerNorm.
+ * The hidden activation h = GELU(pre) is not stored: pangu_linear_gelu_bwd_bf16 re-creates it in the backward. */
+int pangu_mlp_ln_residual_train_fwd_bf16(pangu_stream_t stream, const void* x, int ldx, const void* w_packed,
+                                         const float* b1, const float* b2, const float* gamma, const float* beta, void* out,
+                                         int ldo, void* pre, int ldp, void* m, int ldm, int M, int C, float branch_scale);
+/* Backward through Mlp.linear2 + GELU in one launch (reference layers.py:264-270 under autograd):
+ *   dpre[M,N] = (A[M,K] @ W[N,K]^T) * gelu'(pre[M,N]),   h[M,N] = GELU(pre[M,N])
+ * A = dm (row stride lda), W = linear2.weight^T laid out (N = 4C, K = C), pre dense [M][N]; dpre (row stride ldc) and h
+ * (dense, may be NULL) bf16.  h feeds the weight gradient of linear2 (dW2 = dm^T h) and is transient. */
+int pangu_linear_gelu_bwd_bf16(pangu_stream_t stream, const void* A, int lda, const void* W, void* dpre, int ldc, int M,
+                               int N, int K, const void* pre, void* h);
 int pangu_downsample_ln_fwd_bf16(pangu_stream_t stream, const void* x, int ldx, const float* gamma, const float* beta,
                                  void* out, int Z, int H, int W, int C);
 int pangu_upsample_ln_fwd_bf16(pangu_stream_t stream, const void* y, const float* gamma, const float* beta, void* out,

@@ -38,6 +38,8 @@ SIGNATURES = {
     "pangu_ln_residual_fwd_bf16": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _F],
     "pangu_linear_ln_residual_fwd_bf16": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
     "pangu_mlp_ln_residual_fwd_bf16": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F],
+    "pangu_mlp_ln_residual_train_fwd_bf16": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _F],
+    "pangu_linear_gelu_bwd_bf16": [_P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P],
     "pangu_downsample_ln_fwd_bf16": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I],
     "pangu_upsample_ln_fwd_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I],
     "pangu_patch_embed_gather_bf16": [_P] * 11 + [_I, _I],

@@ -2,10 +2,25 @@
 bf16 weight shadows / activations / activation gradients, fp32 LayerNorm + softmax + accumulation.
 
 Same kernel sequence as autograd.py on the bf16 entry points; saved activations are bf16 (32 GB instead of 64 GB)."""
+import os
+
 import torch
 
 from . import ops
 from . import ops_bf16 as ob
+
+# MLP branch of the training forward (A/B knob PANGU_BF16_TRAIN_MLP): 0 = three launches (MLP-up + GELU writing pre AND h,
+# MLP-down, LayerNorm + residual), 1 = ONE launch that keeps the hidden activation on chip and writes only what the backward
+# needs (pre, m); the backward's data-gradient GEMM re-creates h = GELU(pre) for the W2 weight gradient, 2 = the same for
+# C = 384 only, 3 = one launch writing m only and the backward RE-RUNS the MLP-up GEMM (the reference's answer to
+# activation memory, layers.py:115-119, restricted to this branch; measured in profiles/ as the recompute A/B).
+_TRAIN_MLP = int(os.environ.get("PANGU_BF16_TRAIN_MLP", "1"))
+
+
+def _mlp_mode(C):
+    if C not in (192, 384) or _TRAIN_MLP == 0 or (_TRAIN_MLP == 2 and C != 384):
+        return 0
+    return 3 if _TRAIN_MLP == 3 else 1
 
 
 class EarthBlockFnBF16(torch.autograd.Function):
@@ -13,7 +28,7 @@ class EarthBlockFnBF16(torch.autograd.Function):
     def forward(ctx, x, n1w, n1b, n2w, n2b, m1w, m1b, m2w, m2b, esb, a1w, a1b, a2w, a2b, geom, s1, s2, sh):
         Z, H, W, heads, shifted = geom
         ctx.geom, ctx.s1, ctx.s2, ctx.sh = geom, s1, s2, sh
-        ctx.params = (n1w, n2w, m1w, m2w, esb, a1w, a1b, a2w)
+        ctx.params = (n1w, n2w, m1w, m2w, esb, a1w, a1b, a2w, m1b)
         saved = [x]
         x1 = x
         if s1 != 0.0:
@@ -22,7 +37,12 @@ class EarthBlockFnBF16(torch.autograd.Function):
             y = ob.linear(o, sh.get(a2w), a2b)
             x1 = ob.ln_residual(y, x, n1w, n1b, branch_scale=s1)
             saved += [qkv, o, lse, y]
-        if s2 != 0.0:
+        ctx.mlp_mode = mode = _mlp_mode(x.shape[1]) if x1.is_contiguous() else 0
+        if s2 != 0.0 and mode:
+            x2, pre, m = ob.mlp_ln_residual_train(x1, sh.get_mlp(m1w, m2w), m1b, m2b, n2w, n2b, branch_scale=s2,
+                                                  want_pre=mode == 1)
+            saved += [x1, m] if pre is None else [x1, pre, m]
+        elif s2 != 0.0:
             pre = torch.empty((x.shape[0], m1w.shape[0]), dtype=torch.bfloat16, device=x.device)
             h = ob.linear(x1, sh.get(m1w), m1b, act=ob.ACT_GELU, aux=pre)
             m = ob.linear(h, sh.get(m2w), m2b)
@@ -45,7 +65,7 @@ class EarthBlockFnBF16(torch.autograd.Function):
     def _backward(ctx, dout):
         Z, H, W, heads, shifted = ctx.geom
         s1, s2, sh = ctx.s1, ctx.s2, ctx.sh
-        n1w, n2w, m1w, m2w, esb, a1w, a1b, a2w = ctx.params
+        n1w, n2w, m1w, m2w, esb, a1w, a1b, a2w, m1b = ctx.params
         sv = list(ctx.saved_tensors)
         x, rest = sv[0], sv[1:]
         if s1 != 0.0:
@@ -54,11 +74,22 @@ class EarthBlockFnBF16(torch.autograd.Function):
         g = {k: None for k in ("n1w", "n1b", "n2w", "n2b", "m1w", "m1b", "m2w", "m2b", "esb", "a1w", "a1b", "a2w", "a2b")}
         dx1 = dout
         if s2 != 0.0:
-            x1, pre, h, m = rest
+            mode = ctx.mlp_mode
+            if mode == 1:
+                x1, pre, m = rest
+            elif mode == 3:                # recompute: the MLP-up GEMM again (pre AND h, as the unfused forward writes them)
+                x1, m = rest
+                pre = torch.empty((x1.shape[0], m1w.shape[0]), dtype=torch.bfloat16, device=x1.device)
+                h = ob.linear(x1, sh.get(m1w), m1b, act=ob.ACT_GELU, aux=pre)
+            else:
+                x1, pre, h, m = rest
             dm, g["n2w"], g["n2b"] = ob.ln_residual_bwd(dout, m, n2w, s2)
+            if mode == 1:                  # h = GELU(pre) comes out of the data-gradient GEMM's epilogue (never stored by the forward)
+                dpre, h = ob.linear_gelu_bwd(dm, sh.get_t(m2w), pre)
+            else:
+                dpre = ob.linear(dm, sh.get_t(m2w), None, act=ob.ACT_GELU_BWD, aux=pre)
             g["m2w"], g["m2b"] = ob.linear_wgrad(dm, h)
-            dpre = ob.linear(dm, sh.get_t(m2w), None, act=ob.ACT_GELU_BWD, aux=pre)
-            del dm
+            del dm, h
             g["m1w"], g["m1b"] = ob.linear_wgrad(dpre, x1)
             if dout.is_contiguous():      # residual gradient added in the GEMM epilogue (no extra pass over N x C)
                 dx1 = ob.linear(dpre, sh.get_t(m1w), act=ob.ACT_ADD, aux=dout)

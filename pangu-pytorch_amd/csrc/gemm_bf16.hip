@@ -32,7 +32,7 @@ __device__ inline int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((r
 template <int TN, int ACT, bool HAS_BIAS, bool OUT_F32>
 __device__ __forceinline__ void bf16_epilogue(f32x4 (&acc)[4][2 * TN], unsigned char* smem, const float* __restrict__ bias,
                                               void* __restrict__ Cv, int ldc, int M, int N, u16* __restrict__ aux, int m0,
-                                              int n0, int wave, int lane) {
+                                              int n0, int wave, int lane, u16* __restrict__ aux2 = nullptr) {
   const int wm = wave >> 1, wn = wave & 1;
   const int lc = lane & 15, lg = lane >> 4;
   // ---- epilogue.  lane (lg, lc) of tile (i, j) holds C[m = wm*64 + 16i + lc][n = wn*32TN + 16j + 4lg + r], r = 0..3
@@ -72,7 +72,9 @@ __device__ __forceinline__ void bf16_epilogue(f32x4 (&acc)[4][2 * TN], unsigned 
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       aux, 0, aux ? (int)((size_t)M * N * sizeof(u16)) : 0, 0x00020000);
   constexpr int CPR = ROWB / 16;                           // 16-B chunks per patch row
-  if (ACT == PANGU_ACT_GELU_BWD || ACT == PANGU_ACT_ADD) {
+  const __amdgpu_buffer_rsrc_t h_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      aux2, 0, ACT == PANGU_ACT_GELU_BWD_H ? (int)((size_t)M * N * sizeof(u16)) : 0, 0x00020000);
+  if (ACT == PANGU_ACT_GELU_BWD || ACT == PANGU_ACT_GELU_BWD_H || ACT == PANGU_ACT_ADD) {
     // stage the saved pre-activation (or addend) patch first (coalesced 16-B loads), so gelu' can be applied in the MFMA layout
 #pragma unroll
     for (int it = 0; it < CPR; ++it) {
@@ -104,6 +106,22 @@ __device__ __forceinline__ void bf16_epilogue(f32x4 (&acc)[4][2 * TN], unsigned 
         v[1] *= gelu_erf_grad_lp(__builtin_bit_cast(float, xp[0] & 0xFFFF0000u));
         v[2] *= gelu_erf_grad_lp(__builtin_bit_cast(float, xp[1] << 16));
         v[3] *= gelu_erf_grad_lp(__builtin_bit_cast(float, xp[1] & 0xFFFF0000u));
+      }
+      if (ACT == PANGU_ACT_GELU_BWD_H) {
+        // gelu'(x) = Phi(x) + x phi(x) and h = gelu(x) = x Phi(x) share Phi: h leaves as an 8-B piece per lane (the 4 lanes
+        // of a row make one 32-B segment), like the pre-activation of the forward epilogue
+        const u32x2 xp = *reinterpret_cast<const u32x2*>(slot);
+        const f32x4 x = {__builtin_bit_cast(float, xp[0] << 16), __builtin_bit_cast(float, xp[0] & 0xFFFF0000u),
+                         __builtin_bit_cast(float, xp[1] << 16), __builtin_bit_cast(float, xp[1] & 0xFFFF0000u)};
+        f32x4 hh;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float phi_c = 0.5f * (1.0f + erf_poly(x[c] * 0.70710678118654752440f));
+          hh[c] = x[c] * phi_c;
+          v[c] *= phi_c + x[c] * 0.3989422804014327f * __expf(-0.5f * x[c] * x[c]);
+        }
+        const unsigned ho = col < N ? ((unsigned)(wave_m0 + i * 16 + lc) * (unsigned)N + (unsigned)col) * 2u : 0xFFFFFFFFu;
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(hh[0], hh[1]), pack2(hh[2], hh[3])}, h_rsrc, (int)ho, 0, 0);
       }
       if (ACT == PANGU_ACT_ADD) {
         const u32x2 xp = *reinterpret_cast<const u32x2*>(slot);
@@ -140,7 +158,7 @@ template <int TN, int ACT, bool HAS_BIAS, bool OUT_F32>
 __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const u16* __restrict__ A, int lda,
                                                               const u16* __restrict__ W, const float* __restrict__ bias,
                                                               void* __restrict__ Cv, int ldc, int M, int N, int K,
-                                                              int m_tiles, int n_tiles, u16* __restrict__ aux) {
+                                                              int m_tiles, int n_tiles, u16* __restrict__ aux, u16* __restrict__ aux2) {
   constexpr int BN = 64 * TN;
   constexpr int STAGE = (BBM + BN) * 128;                 // bytes per LDS stage
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -221,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const u16* __restr
     if (more) stash((kt + 1) & 1);
     __syncthreads();
   }
-  bf16_epilogue<TN, ACT, HAS_BIAS, OUT_F32>(acc, smem, bias, Cv, ldc, M, N, aux, m0, n0, wave, lane);
+  bf16_epilogue<TN, ACT, HAS_BIAS, OUT_F32>(acc, smem, bias, Cv, ldc, M, N, aux, m0, n0, wave, lane, aux2);
 }
 
 // ---- direct-to-LDS variant -------------------------------------------------------------------------------------------
@@ -248,7 +266,7 @@ template <int TN, int ACT, bool HAS_BIAS, bool OUT_F32, int RING>
 __global__ __launch_bounds__(256, RING == 2 ? 3 : 2) void gemm_tn_bf16_glds_kernel(const u16* __restrict__ A, int lda,
                                                                    const u16* __restrict__ W, const float* __restrict__ bias,
                                                                    void* __restrict__ Cv, int ldc, int M, int N, int K,
-                                                                   int m_tiles, int n_tiles, u16* __restrict__ aux) {
+                                                                   int m_tiles, int n_tiles, u16* __restrict__ aux, u16* __restrict__ aux2) {
   constexpr int BN = 64 * TN;
   constexpr int ROWS = BBM + BN;
   constexpr int STAGE = ROWS * 64;                        // bytes per ring slot
@@ -323,12 +341,12 @@ __global__ __launch_bounds__(256, RING == 2 ? 3 : 2) void gemm_tn_bf16_glds_kern
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
   }
   __syncthreads();                                         // every wave is done with the ring before the epilogue reuses it
-  bf16_epilogue<TN, ACT, HAS_BIAS, OUT_F32>(acc, smem, bias, Cv, ldc, M, N, aux, m0, n0, wave, lane);
+  bf16_epilogue<TN, ACT, HAS_BIAS, OUT_F32>(acc, smem, bias, Cv, ldc, M, N, aux, m0, n0, wave, lane, aux2);
 }
 
 template <int TN, bool OUT_F32>
 int launch_bf16(hipStream_t s, const u16* A, int lda, const u16* W, const float* bias, void* C, int ldc, int M, int N,
-                int K, int act, u16* aux) {
+                int K, int act, u16* aux, u16* aux2 = nullptr) {
   constexpr int BN = 64 * TN;
   const int m_tiles = (M + BBM - 1) / BBM, n_tiles = (N + BN - 1) / BN;
   const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
@@ -348,21 +366,23 @@ int launch_bf16(hipStream_t s, const u16* A, int lda, const u16* W, const float*
     if (glds && glds_mode == 2) {                                                                                     \
       auto kern = gemm_tn_bf16_glds_kernel<TN, ACT, HB, OUT_F32, 2>;                                                  \
       PANGU_ENSURE_DYN_LDS(kern, shm);                                                                                \
-      hipLaunchKernelGGL(kern, g, blk, shm, s, A, lda, W, bias, C, ldc, M, N, K, m_tiles, n_tiles, aux);              \
+      hipLaunchKernelGGL(kern, g, blk, shm, s, A, lda, W, bias, C, ldc, M, N, K, m_tiles, n_tiles, aux, aux2);        \
       break;                                                                                                          \
     }                                                                                                                 \
     if (glds) {                                                                                                       \
       auto kern = gemm_tn_bf16_glds_kernel<TN, ACT, HB, OUT_F32, GST>;                                                \
       PANGU_ENSURE_DYN_LDS(kern, shm);                                                                                \
-      hipLaunchKernelGGL(kern, g, blk, shm, s, A, lda, W, bias, C, ldc, M, N, K, m_tiles, n_tiles, aux);              \
+      hipLaunchKernelGGL(kern, g, blk, shm, s, A, lda, W, bias, C, ldc, M, N, K, m_tiles, n_tiles, aux, aux2);        \
       break;                                                                                                          \
     }                                                                                                                 \
     auto kern = gemm_tn_bf16_kernel<TN, ACT, HB, OUT_F32>;                                                            \
     PANGU_ENSURE_DYN_LDS(kern, shm);                                                                                  \
-    hipLaunchKernelGGL(kern, g, blk, shm, s, A, lda, W, bias, C, ldc, M, N, K, m_tiles, n_tiles, aux);                \
+    hipLaunchKernelGGL(kern, g, blk, shm, s, A, lda, W, bias, C, ldc, M, N, K, m_tiles, n_tiles, aux, aux2);          \
   } while (0)
   if (act == PANGU_ACT_GELU) {
     if (bias) PANGU_BGEMM(PANGU_ACT_GELU, true); else PANGU_BGEMM(PANGU_ACT_GELU, false);
+  } else if (act == PANGU_ACT_GELU_BWD_H) {
+    if constexpr (OUT_F32) return PANGU_E_ARG; else PANGU_BGEMM(PANGU_ACT_GELU_BWD_H, false);
   } else if (act == PANGU_ACT_GELU_BWD) {
     if (OUT_F32) return PANGU_E_ARG;
     PANGU_BGEMM(PANGU_ACT_GELU_BWD, false);
@@ -379,7 +399,27 @@ int launch_bf16(hipStream_t s, const u16* A, int lda, const u16* W, const float*
 }  // namespace
 
 int pangu_linear_ws_bf16(hipStream_t s, const void* A, int lda, const void* W, const float* bias, void* C, int ldc, int M,
-                         int N, int K, int act, void* aux, int out_f32);      // gemm_ws_bf16.hip
+                         int N, int K, int act, void* aux, int out_f32, void* aux2 = nullptr);      // gemm_ws_bf16.hip
+
+extern "C" int pangu_linear_gelu_bwd_bf16(pangu_stream_t stream, const void* A, int lda, const void* W, void* dpre, int ldc,
+                                          int M, int N, int K, const void* pre, void* h) {
+  if (!A || !W || !dpre || !pre) return PANGU_E_NULL;
+  if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (N & 7) || lda < K || ldc < N || (lda & 7) || (ldc & 7)) return PANGU_E_SHAPE;
+  if (!pangu_fits_u32(M, lda, 2) || !pangu_fits_u32(M, ldc, 2) || !pangu_fits_u32(M, N, 2)) return PANGU_E_RANGE;
+  hipStream_t s = (hipStream_t)stream;
+  const int act = h ? PANGU_ACT_GELU_BWD_H : PANGU_ACT_GELU_BWD;
+  static const bool allow_ws = !(getenv("PANGU_BF16_WS") && atoi(getenv("PANGU_BF16_WS")) == 0);
+  if (allow_ws && M >= 4096) {
+    const int rc = pangu_linear_ws_bf16(s, A, lda, W, nullptr, dpre, ldc, M, N, K, act, const_cast<void*>(pre), 0, h);
+    if (rc != PANGU_E_SHAPE) return rc;
+  }
+  const u16* a = (const u16*)A;
+  const u16* w = (const u16*)W;
+  u16* x = (u16*)const_cast<void*>(pre);
+  if ((N % 192 == 0) || (N > 128 && N < 192)) return launch_bf16<3, false>(s, a, lda, w, nullptr, dpre, ldc, M, N, K, act, x, (u16*)h);
+  if (N % 128 == 0) return launch_bf16<2, false>(s, a, lda, w, nullptr, dpre, ldc, M, N, K, act, x, (u16*)h);
+  return launch_bf16<1, false>(s, a, lda, w, nullptr, dpre, ldc, M, N, K, act, x, (u16*)h);
+}
 
 extern "C" int pangu_linear_fwd_bf16(pangu_stream_t stream, const void* A, int lda, const void* W, const float* bias,
                                      void* C, int ldc, int M, int N, int K, int act, void* aux, int out_dtype) {

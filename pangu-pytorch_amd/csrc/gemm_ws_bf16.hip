@@ -41,7 +41,7 @@ template <int BNW, int KMAX, int ACT, bool HAS_BIAS, bool OUT_F32>
 __global__ __launch_bounds__(512, 2) void gemm_ws_bf16_kernel(const u16* __restrict__ A, int lda, const u16* __restrict__ W,
                                                               const float* __restrict__ bias, void* __restrict__ Cv,
                                                               int ldc, int M, int N, int K, int n_slices, int m_tiles,
-                                                              u16* __restrict__ aux) {
+                                                              u16* __restrict__ aux, u16* __restrict__ aux2) {
   constexpr int NT = BNW / 16;                 // 16-column tiles per wave row-block
   constexpr int KS = KMAX / 32;                // K-steps of one MFMA (32 k-values)
   constexpr int ROWB = BNW * (OUT_F32 ? 4 : 2);
@@ -78,6 +78,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_bf16_kernel(const u16* __restr
       Cv, 0, (int)(((size_t)(M - 1) * ldc + N) * (OUT_F32 ? 4 : 2)), 0x00020000);
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       aux, 0, aux ? (int)((size_t)M * N * sizeof(u16)) : 0, 0x00020000);
+
+  const __amdgpu_buffer_rsrc_t h_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      aux2, 0, ACT == PANGU_ACT_GELU_BWD_H ? (int)((size_t)M * N * sizeof(u16)) : 0, 0x00020000);
 
   // activation fragments of one tile: [k-step][row sub-tile]; rows past M read as zeros (range-checked descriptor)
   u32x4 af[KS][2];
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_bf16_kernel(const u16* __restr
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       constexpr int CPR = ROWB / 16;
-      if (ACT == PANGU_ACT_GELU_BWD) {
+      if (ACT == PANGU_ACT_GELU_BWD || ACT == PANGU_ACT_GELU_BWD_H) {
 #pragma unroll
         for (int it = 0; it < (16 * (BNW / 8) + 63) / 64; ++it) {
           const int f = lane + 64 * it, row = f / (BNW / 8), ch = f % (BNW / 8);
@@ -142,6 +145,20 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_bf16_kernel(const u16* __restr
           v[1] *= gelu_erf_grad_lp(__builtin_bit_cast(float, xp[0] & 0xFFFF0000u));
           v[2] *= gelu_erf_grad_lp(__builtin_bit_cast(float, xp[1] << 16));
           v[3] *= gelu_erf_grad_lp(__builtin_bit_cast(float, xp[1] & 0xFFFF0000u));
+        }
+        if (ACT == PANGU_ACT_GELU_BWD_H) {      // gelu'(x) and h = gelu(x) share Phi(x); h leaves as an 8-B piece per lane
+          const u32x2 xp = *reinterpret_cast<const u32x2*>(ep + lc * EP_LD + (j * 16 + lg * 4) * 2);
+          const f32x4 x = {__builtin_bit_cast(float, xp[0] << 16), __builtin_bit_cast(float, xp[0] & 0xFFFF0000u),
+                           __builtin_bit_cast(float, xp[1] << 16), __builtin_bit_cast(float, xp[1] & 0xFFFF0000u)};
+          f32x4 hh;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float phi_c = 0.5f * (1.0f + erf_poly(x[c] * 0.70710678118654752440f));
+            hh[c] = x[c] * phi_c;
+            v[c] *= phi_c + x[c] * 0.3989422804014327f * __expf(-0.5f * x[c] * x[c]);
+          }
+          const unsigned ho = col < N ? ((unsigned)(m_cur + mt * 16 + lc) * (unsigned)N + (unsigned)col) * 2u : 0xFFFFFFFFu;
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(hh[0], hh[1]), pack2(hh[2], hh[3])}, h_rsrc, (int)ho, 0, 0);
         }
         if (ACT == PANGU_ACT_GELU) {
           if (aux) {
@@ -170,7 +187,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_bf16_kernel(const u16* __restr
 
 template <int BNW, int KMAX, bool OUT_F32>
 int launch_ws(hipStream_t s, const u16* A, int lda, const u16* W, const float* bias, void* C, int ldc, int M, int N, int K,
-              int act, u16* aux) {
+              int act, u16* aux, u16* aux2) {
   const int n_slices = (N + BNW - 1) / BNW;
   const int m_tiles = (M + WS_BM - 1) / WS_BM;
   int per_slice = 256 / n_slices;                       // one persistent workgroup per CU
@@ -182,12 +199,14 @@ int launch_ws(hipStream_t s, const u16* A, int lda, const u16* W, const float* b
   do {                                                                                                                \
     auto kern = gemm_ws_bf16_kernel<BNW, KMAX, ACT, HB, OUT_F32>;                                                     \
     PANGU_ENSURE_DYN_LDS(kern, shm);                                                                                  \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), shm, s, A, lda, W, bias, C, ldc, M, N, K, n_slices, m_tiles, aux); \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), shm, s, A, lda, W, bias, C, ldc, M, N, K, n_slices, m_tiles, aux, aux2); \
   } while (0)
   if (act == PANGU_ACT_GELU) {
     if (bias) PANGU_WS(PANGU_ACT_GELU, true); else PANGU_WS(PANGU_ACT_GELU, false);
   } else if (act == PANGU_ACT_GELU_BWD) {
     PANGU_WS(PANGU_ACT_GELU_BWD, false);
+  } else if (act == PANGU_ACT_GELU_BWD_H) {
+    if constexpr (OUT_F32) return PANGU_E_SHAPE; else PANGU_WS(PANGU_ACT_GELU_BWD_H, false);
   } else {
     if (bias) PANGU_WS(PANGU_ACT_NONE, true); else PANGU_WS(PANGU_ACT_NONE, false);
   }
@@ -200,21 +219,22 @@ int launch_ws(hipStream_t s, const u16* A, int lda, const u16* W, const float* b
 // Internal entry used by pangu_linear_fwd_bf16's dispatcher (same argument meaning); returns PANGU_E_SHAPE when the shape is
 // not one this kernel covers.
 int pangu_linear_ws_bf16(hipStream_t s, const void* A, int lda, const void* W, const float* bias, void* C, int ldc, int M,
-                         int N, int K, int act, void* aux, int out_f32) {
+                         int N, int K, int act, void* aux, int out_f32, void* aux2) {
   // Measured (tools/bench_kernels.py gemm_bf16, MI355X): with K <= 192 a 192-column slice is resident and the kernel beats
   // the tiled one by 5-25 %; with K = 384 only 96 columns fit (activations re-read twice as often) and it LOSES 20-40 %,
   // so those shapes stay on the tiled kernel.  The <96,384> instantiation is kept for PANGU_BF16_WS=2 experiments.
   static const int mode = getenv("PANGU_BF16_WS") ? atoi(getenv("PANGU_BF16_WS")) : 1;
   if ((K & 31) || K > (mode == 2 ? 384 : 192) || (lda & 7) || (N & 7)) return PANGU_E_SHAPE;
   if (out_f32 && K <= 192) return PANGU_E_SHAPE;            // fp32 patch of a 192-wide slice does not fit next to W
-  if (act == PANGU_ACT_GELU_BWD && (out_f32 || bias)) return PANGU_E_SHAPE;
+  if ((act == PANGU_ACT_GELU_BWD || act == PANGU_ACT_GELU_BWD_H) && (out_f32 || bias)) return PANGU_E_SHAPE;
   const u16* a = (const u16*)A;
   const u16* w = (const u16*)W;
   u16* x = (u16*)aux;
+  u16* x2 = (u16*)aux2;
   if (K <= 192) {
-    return out_f32 ? launch_ws<192, 192, true>(s, a, lda, w, bias, C, ldc, M, N, K, act, x)
-                   : launch_ws<192, 192, false>(s, a, lda, w, bias, C, ldc, M, N, K, act, x);
+    return out_f32 ? launch_ws<192, 192, true>(s, a, lda, w, bias, C, ldc, M, N, K, act, x, x2)
+                   : launch_ws<192, 192, false>(s, a, lda, w, bias, C, ldc, M, N, K, act, x, x2);
   }
-  return out_f32 ? launch_ws<96, 384, true>(s, a, lda, w, bias, C, ldc, M, N, K, act, x)
-                 : launch_ws<96, 384, false>(s, a, lda, w, bias, C, ldc, M, N, K, act, x);
+  return out_f32 ? launch_ws<96, 384, true>(s, a, lda, w, bias, C, ldc, M, N, K, act, x, x2)
+                 : launch_ws<96, 384, false>(s, a, lda, w, bias, C, ldc, M, N, K, act, x, x2);
 }

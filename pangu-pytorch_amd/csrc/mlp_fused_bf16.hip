@@ -63,6 +63,9 @@ constexpr float LN_EPS = 1e-5f;
 #ifndef PANGU_MLP_IGLP
 #define PANGU_MLP_IGLP 4        // VALU instructions placed behind each MFMA of a step (0 = leave it to the scheduler)
 #endif
+#ifndef PANGU_MLP_PRE_AT_TOP
+#define PANGU_MLP_PRE_AT_TOP 0  // training variant: pre-activation stores at the very top of an iteration instead of under the first fragment reads
+#endif
 constexpr int ABL = PANGU_MLP_ABLATE;
 constexpr int PD1 = PANGU_MLP_PD1, PD2 = PANGU_MLP_PD2, IGLP = PANGU_MLP_IGLP;
 
@@ -102,11 +105,16 @@ using Flag = std::integral_constant<bool, B>;
 template <int N>
 using Int = std::integral_constant<int, N>;
 
-template <int C, int T, int NW>
+// TR (training forward): two side outputs for the backward pass, written from the registers the values live in anyway --
+//   Pre[m][4C] (bf16): the first product + b1 BEFORE GELU (what gelu' needs; the backward's data-gradient GEMM also
+//                     re-creates h = GELU(pre) from it for the W2 weight gradient, so h is never stored by the forward);
+//                     may be null (recompute mode: the backward re-runs the MLP-up GEMM);
+//   Mo[m][C]   (bf16): the second product + b2 BEFORE LayerNorm (what the LayerNorm backward normalises again).
+template <int C, int T, int NW, int TR>      // TR: 0 inference, 1 training (Mo only: recompute mode), 2 training (Pre + Mo)
 __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_ln_residual_bf16_kernel(
     const u16* __restrict__ X, int ldx, const u16* __restrict__ Wimg, const float* __restrict__ b1,
     const float* __restrict__ b2, const float* __restrict__ gamma, const float* __restrict__ beta,
-    u16* __restrict__ Out, int ldo, int M, float scale) {
+    u16* __restrict__ Out, int ldo, int M, float scale, u16* __restrict__ Pre, int ldp, u16* __restrict__ Mo, int ldm) {
   constexpr int HID = 4 * C, NCH = HID / 32, KS = C / 16, RT = C / 32;
   constexpr int WB = 64 * C;                  // bytes of one W1 (or W2) chunk
   constexpr int NS = 3;                       // ring slots per stream
@@ -186,6 +194,33 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_ln_residual_bf16_kernel(
   bf16x8 hf[2][T];           // packed GELU output of the chunk before that: B operand (k-step s) of the second product
   float gt[16 * T];          // GELU temporaries, one per element
 
+  // TR: the pre-activation of chunk `chunk` (still untouched in hg: the GELU's last stage overwrites it) leaves as 16-B
+  // pieces: lane (token, half h) holds hidden 8q + 4h + r (q = register quad, r = 0..3); two v_permlane32_swap per quad
+  // pair give half 0 the eight consecutive hidden values of quad 2qp and half 1 those of quad 2qp + 1: per token row and
+  // chunk one contiguous 64-B segment, which the next chunk's stores extend (write-combined in L2).
+  const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      Pre, 0, TR == 2 ? (int)(((size_t)(M - 1) * ldp + HID) * sizeof(u16)) : 0, 0x00020000);
+  // one address register for all T tiles (tile tt adds a scalar offset); rows past M are dropped by the range check
+  const unsigned pre_off = ((unsigned)(m0 + lr) * (unsigned)ldp + 8 * lh) * 2u;
+  const int pre_tile = __builtin_amdgcn_readfirstlane(32 * ldp * 2);
+  auto store_pre = [&](int chunk) {
+    if (TR != 2) return;
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt) {
+#pragma unroll
+      for (int qp = 0; qp < 2; ++qp) {
+        // quads 2qp, 2qp+1 only: four packed registers live at a time (the kernel sits at the 512-register limit)
+        const unsigned a0 = pack_bf16x2(hg[tt][8 * qp], hg[tt][8 * qp + 1]), a1 = pack_bf16x2(hg[tt][8 * qp + 2], hg[tt][8 * qp + 3]);
+        const unsigned b0 = pack_bf16x2(hg[tt][8 * qp + 4], hg[tt][8 * qp + 5]), b1 = pack_bf16x2(hg[tt][8 * qp + 6], hg[tt][8 * qp + 7]);
+        const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{r0[0], r1[0], r0[1], r1[1]}, p_rsrc, (int)pre_off,
+                                               tt * pre_tile + (chunk * 32 + 16 * qp) * 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
   // One iteration: G2 = second product of chunk ch-2 (operand hf), GE = GELU of chunk ch-1 (hg), G1 = first product of
   // chunk ch (-> hacc); I1 / I2: request W1 chunk ch+2 / W2 chunk ch.  All flags are compile-time (peeled prologue /
   // drain iterations), so the steady-state body is one basic block.
@@ -222,6 +257,15 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_ln_residual_bf16_kernel(
     auto gelu_step = [&](int g) {
       if (g > 0) gelu_ops(FRONT + (NOPS - FRONT) * (g - 1) / (NSTEPS - 1), FRONT + (NOPS - FRONT) * g / (NSTEPS - 1));
     };
+#if PANGU_MLP_PRE_AT_TOP
+    // TR: chunk ch-1's pre-activation leaves first, where the fewest registers are live (no fragments, no GELU temporaries)
+    if constexpr (GE) {
+      if (TR == 2) {
+        store_pre(ch - 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#endif
     // ---- second product of chunk ch-2: 2 RT steps (row tile, k-step) of T MFMAs, fragment reads PD2 steps ahead
     if constexpr (G2) {
       constexpr int NSTEP = 2 * RT;
@@ -233,6 +277,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_ln_residual_bf16_kernel(
       for (int st = 0; st < PD2 && st < NSTEP; ++st) fa[st] = rd(st);
       if constexpr (GE) {
         __builtin_amdgcn_sched_barrier(0);
+        if (TR == 2 && !PANGU_MLP_PRE_AT_TOP) store_pre(ch - 1);      // chunk ch-1's pre-activation leaves under the first reads' flight
         gelu_ops(0, FRONT);                                // under the first reads' flight
       }
 #pragma unroll
@@ -258,7 +303,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_ln_residual_bf16_kernel(
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
-      if constexpr (GE) gelu_ops(0, FRONT + (NOPS - FRONT) * (2 * RT - 1) / (NSTEPS - 1));
+      if constexpr (GE) {
+        if (TR == 2 && !PANGU_MLP_PRE_AT_TOP) store_pre(ch - 1);
+        gelu_ops(0, FRONT + (NOPS - FRONT) * (2 * RT - 1) / (NSTEPS - 1));
+      }
       if (I2) {
 #pragma unroll
         for (int i = 0; i < LPS; ++i) issue_piece(1, ch, a, i);
@@ -402,6 +450,25 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_ln_residual_bf16_kernel(
       const auto r13 = __builtin_amdgcn_permlane32_swap(f[1], f[3], false, false);
       sc[ks] = u32x4{r02[0], r13[0], r02[1], r13[1]};
     }
+    if (TR) {
+      // pre-LayerNorm rows (second product + b2) -> Mo, through the same per-wave patch as the result below
+      const __amdgpu_buffer_rsrc_t m_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          Mo, 0, (int)(((size_t)(M - 1) * ldm + C) * sizeof(u16)), 0x00020000);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<u32x2*>(patch + lr * PLD + (32 * rt + 8 * q + 4 * lh) * 2) =
+              u32x2{pack_bf16x2(yacc[rt][tt][4 * q], yacc[rt][tt][4 * q + 1]),
+                    pack_bf16x2(yacc[rt][tt][4 * q + 2], yacc[rt][tt][4 * q + 3])};
+#pragma unroll
+      for (int it = 0; it < 32 * CPR / 64; ++it) {
+        const int f = lane + 64 * it, row = f / CPR, chk = f - row * CPR;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(patch + row * PLD + chk * 16);
+        const unsigned off = tok0 + row < M ? ((unsigned)(tok0 + row) * (unsigned)ldm + chk * 8) * 2u : 0xFFFFFFFFu;
+        __builtin_amdgcn_raw_buffer_store_b128(v, m_rsrc, (int)off, 0, 0);
+      }
+    }
     // LayerNorm statistics: four independent partial sums (a single dependent add chain stalls the lone wave on every add)
     float s4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -456,17 +523,19 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_ln_residual_bf16_kernel(
 #endif
 }
 
-template <int C, int T, int NW>
+template <int C, int T, int NW, int TR = 0>
 int launch_mlp(hipStream_t s, const u16* x, int ldx, const u16* wimg, const float* b1, const float* b2,
-               const float* gamma, const float* beta, u16* out, int ldo, int M, float scale) {
+               const float* gamma, const float* beta, u16* out, int ldo, int M, float scale, u16* pre = nullptr,
+               int ldp = 0, u16* mo = nullptr, int ldm = 0) {
   constexpr size_t ring = (size_t)6 * 64 * C;
   constexpr size_t epi = (size_t)NW * 32 * (2 * C + 16);
   constexpr size_t shm = 7 * C * sizeof(float) + (ring > epi ? ring : epi);
   static_assert(shm <= 160 * 1024, "LDS");
-  auto kern = mlp_ln_residual_bf16_kernel<C, T, NW>;
+  auto kern = mlp_ln_residual_bf16_kernel<C, T, NW, TR>;
   PANGU_ENSURE_DYN_LDS(kern, shm);
   const int grid = (M + 32 * T * NW - 1) / (32 * T * NW);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), shm, s, x, ldx, wimg, b1, b2, gamma, beta, out, ldo, M, scale);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), shm, s, x, ldx, wimg, b1, b2, gamma, beta, out, ldo, M, scale, pre,
+                     ldp, mo, ldm);
   return pangu_launch_status();
 }
 
@@ -491,6 +560,28 @@ extern "C" int pangu_mlp_ln_residual_fwd_bf16(pangu_stream_t stream, const void*
   if (C == 384)
     return launch_mlp<384, 1, 4>(s, (const u16*)x, ldx, (const u16*)w_packed, b1, b2, gamma, beta, (u16*)out, ldo, M,
                                  branch_scale);
+  return PANGU_E_SHAPE;
+}
+
+// Training forward of the same branch: additionally writes what the backward needs (see the kernel's TR note):
+// pre (M x 4C bf16, row stride ldp; may be null = recompute mode) and m (M x C bf16, the pre-LayerNorm value, row stride ldm).
+extern "C" int pangu_mlp_ln_residual_train_fwd_bf16(pangu_stream_t stream, const void* x, int ldx, const void* w_packed,
+                                                    const float* b1, const float* b2, const float* gamma,
+                                                    const float* beta, void* out, int ldo, void* pre, int ldp, void* m,
+                                                    int ldm, int M, int C, float branch_scale) {
+  if (!x || !w_packed || !b1 || !b2 || !gamma || !beta || !out || !m) return PANGU_E_NULL;
+  if (M <= 0 || ldx < C || ldo < C || ldm < C || (ldx & 7) || (ldo & 7) || (ldm & 7)) return PANGU_E_SHAPE;
+  if (pre && (ldp < 4 * C || (ldp & 7))) return PANGU_E_SHAPE;
+  if (!pangu_fits_u32(M, ldx, 2) || !pangu_fits_u32(M, ldo, 2) || !pangu_fits_u32(M, ldm, 2) ||
+      (pre && !pangu_fits_u32(M, ldp, 2)))
+    return PANGU_E_RANGE;
+  hipStream_t s = (hipStream_t)stream;
+#define PANGU_MLP_TR(CC, TT, MODE)                                                                                        \
+  launch_mlp<CC, TT, 4, MODE>(s, (const u16*)x, ldx, (const u16*)w_packed, b1, b2, gamma, beta, (u16*)out, ldo, M,        \
+                              branch_scale, (u16*)pre, ldp, (u16*)m, ldm)
+  if (C == 192) return pre ? PANGU_MLP_TR(192, 2, 2) : PANGU_MLP_TR(192, 2, 1);
+  if (C == 384) return pre ? PANGU_MLP_TR(384, 1, 2) : PANGU_MLP_TR(384, 1, 1);
+#undef PANGU_MLP_TR
   return PANGU_E_SHAPE;
 }
 

@@ -101,25 +101,44 @@ def linear_ln_residual(a, weight, bias, shortcut, gamma, beta, out=None):
     return out
 
 
-def pack_mlp_weights(w1, w2):
-    """Chunk image of an Mlp's weights for `mlp_ln_residual` (layout: csrc/mlp_fused_bf16.hip header).  w1 (4C, C), w2 (C, 4C),
-    any float dtype, C in (192, 384) -> bf16 (2, 4C/32, 32*C): plane 0 = per 32 hidden units the W1 rows (16-B chunks XOR-swizzled
-    for conflict-free fragment reads), plane 1 = the W2 columns in the k order the first product's accumulators come in."""
+_mlp_pack_index = {}      # (C, device) -> int64 gather index of the packed image into cat(w1.flatten(), w2.flatten())
+
+
+def _mlp_pack_layout(w1, w2):
+    """The chunk image as indexing operations on (w1 (4C, C), w2 (C, 4C)) of any dtype -> (2, 4C/32, 32*C)."""
     HID, C = w1.shape
-    if C not in (192, 384) or HID != 4 * C or tuple(w2.shape) != (C, HID):
-        raise RuntimeError(f"pack_mlp_weights: w1 {tuple(w1.shape)} w2 {tuple(w2.shape)}")
     dev = w1.device
     nch = HID // 32
     hr = torch.arange(32, device=dev)
     pos = torch.arange(C // 8, device=dev)
     f = (hr & 15) if C == 384 else ((hr >> 1) & 7)
     src = pos[None, :] ^ f[:, None]                                           # logical chunk stored at (row, position)
-    w1b = w1.to(torch.bfloat16).reshape(nch, 32, C // 8, 8)
+    w1b = w1.reshape(nch, 32, C // 8, 8)
     w1img = w1b[:, hr[:, None], src, :]                                       # (nch, 32, C/8, 8)
     perm = torch.tensor([16 * s + 8 * (j >> 2) + 4 * h + (j & 3) for s in range(2) for h in range(2) for j in range(8)],
                         device=dev)
-    w2img = w2.to(torch.bfloat16).reshape(C, nch, 32)[:, :, perm].reshape(C, nch, 4, 8).permute(1, 2, 0, 3)
+    w2img = w2.reshape(C, nch, 32)[:, :, perm].reshape(C, nch, 4, 8).permute(1, 2, 0, 3)
     return torch.stack([w1img.reshape(nch, 32 * C), w2img.reshape(nch, 32 * C)], 0).contiguous()
+
+
+def pack_mlp_weights(w1, w2):
+    """Chunk image of an Mlp's weights for `mlp_ln_residual` (layout: csrc/mlp_fused_bf16.hip header).  w1 (4C, C), w2 (C, 4C),
+    any float dtype, C in (192, 384) -> bf16 (2, 4C/32, 32*C): plane 0 = per 32 hidden units the W1 rows (16-B chunks XOR-swizzled
+    for conflict-free fragment reads), plane 1 = the W2 columns in the k order the first product's accumulators come in.
+    The layout is a fixed permutation: it is built once per (C, device) as a gather index (by pushing element numbers through
+    `_mlp_pack_layout`), so re-packing after an optimizer step is three launches (concatenate, cast, gather)."""
+    HID, C = w1.shape
+    if C not in (192, 384) or HID != 4 * C or tuple(w2.shape) != (C, HID):
+        raise RuntimeError(f"pack_mlp_weights: w1 {tuple(w1.shape)} w2 {tuple(w2.shape)}")
+    key = (C, w1.device)
+    idx = _mlp_pack_index.get(key)
+    if idx is None:
+        n = HID * C
+        e1 = torch.arange(n, device=w1.device).view(HID, C)
+        e2 = torch.arange(n, 2 * n, device=w1.device).view(C, HID)
+        idx = _mlp_pack_index[key] = _mlp_pack_layout(e1, e2).reshape(-1)
+    flat = torch.cat((w1.reshape(-1), w2.reshape(-1))).to(torch.bfloat16)
+    return flat[idx].view(2, HID // 32, 32 * C)
 
 
 def mlp_ln_residual(x, w_packed, b1, b2, gamma, beta, out=None, branch_scale=1.0):
@@ -145,6 +164,49 @@ def mlp_ln_residual(x, w_packed, b1, b2, gamma, beta, out=None, branch_scale=1.0
             _p(gamma, "gamma", torch.float32), _p(beta, "beta", torch.float32), op, ldo, M, C, float(branch_scale)),
             "mlp_ln_residual_fwd_bf16")
     return out
+
+
+def mlp_ln_residual_train(x, w_packed, b1, b2, gamma, beta, branch_scale=1.0, want_pre=True):
+    """Training forward of the MLP branch in ONE launch: -> (out, pre, m) with out as `mlp_ln_residual`, pre (M, 4C) bf16 =
+    x W1^T + b1 before the GELU (None with want_pre=False: the backward re-runs the MLP-up GEMM) and m (M, C) bf16 =
+    GELU(pre) W2^T + b2 before the LayerNorm.  h = GELU(pre) is not stored (linear_gelu_bwd re-creates it)."""
+    lib = _lib.load()
+    xp, ldx = _rows(x, "mlp.x")
+    M, C = x.shape
+    if x.dtype != torch.bfloat16 or tuple(w_packed.shape) != (2, C // 8, 32 * C):
+        raise RuntimeError(f"mlp_ln_residual_train: x {tuple(x.shape)} {x.dtype} vs packed weights {tuple(w_packed.shape)}")
+    if _row_chunks(M, 2 * ldx, 8 * C) is not None:
+        raise RuntimeError("mlp_ln_residual_train: more than 4 GB of pre-activation rows in one call")
+    out = torch.empty((M, C), dtype=torch.bfloat16, device=x.device)
+    m = torch.empty((M, C), dtype=torch.bfloat16, device=x.device)
+    pre = torch.empty((M, 4 * C), dtype=torch.bfloat16, device=x.device) if want_pre else None
+    with _timed("mlp_fused_bf16", 16.0 * M * C * C):
+        _lib.check(lib.pangu_mlp_ln_residual_train_fwd_bf16(
+            _stream(), xp, ldx, _p(w_packed, "w_packed"), _p(b1, "b1", torch.float32), _p(b2, "b2", torch.float32),
+            _p(gamma, "gamma", torch.float32), _p(beta, "beta", torch.float32), out.data_ptr(), C,
+            pre.data_ptr() if want_pre else None, 4 * C, m.data_ptr(), C, M, C, float(branch_scale)),
+            "mlp_ln_residual_train_fwd_bf16")
+    return out, pre, m
+
+
+def linear_gelu_bwd(dm, w2_t, pre, want_h=True):
+    """Backward through Mlp.linear2 + GELU: -> (dpre, h) with dpre = (dm @ w2_t^T) * gelu'(pre) and h = GELU(pre) (None
+    with want_h=False).  dm (M, C) bf16 rows, w2_t (4C, C) bf16 (= linear2.weight transposed), pre (M, 4C) bf16."""
+    lib = _lib.load()
+    ap, lda = _rows(dm, "gelu_bwd.dm")
+    M, K = dm.shape
+    N = w2_t.shape[0]
+    if w2_t.shape[1] != K or tuple(pre.shape) != (M, N) or dm.dtype != torch.bfloat16:
+        raise RuntimeError(f"linear_gelu_bwd: dm {tuple(dm.shape)} w2_t {tuple(w2_t.shape)} pre {tuple(pre.shape)}")
+    dpre = torch.empty((M, N), dtype=torch.bfloat16, device=dm.device)
+    h = torch.empty((M, N), dtype=torch.bfloat16, device=dm.device) if want_h else None
+    chunks = _row_chunks(M, 2 * lda, 2 * N)
+    for m0, m1 in (chunks or [(0, M)]):
+        with _timed("linear_bf16", 2.0 * (m1 - m0) * N * K):
+            _lib.check(lib.pangu_linear_gelu_bwd_bf16(_stream(), ap + m0 * lda * 2, lda, _p(w2_t, "w2_t"),
+                                                      dpre[m0:m1].data_ptr(), N, m1 - m0, N, K, _p(pre, "pre") + m0 * N * 2,
+                                                      h[m0:m1].data_ptr() if want_h else None), "linear_gelu_bwd_bf16")
+    return dpre, h
 
 
 def ln_residual(y, shortcut, gamma, beta, out=None, branch_scale=1.0):

@@ -132,6 +132,54 @@ def test_mlp_ln_residual_fused_bf16(P, C, M, strided_out, scale):
         assert ((sep.double().cpu() - ref).norm() / ref.norm()).item() < 3e-3
 
 
+@pytest.mark.parametrize("C,M", [(192, 256), (192, 4099), (384, 128), (384, 2600)])
+@pytest.mark.parametrize("want_pre,scale", [(True, 1.0), (True, 1.25), (False, 1.0)])
+def test_mlp_ln_residual_train_fused_bf16(P, C, M, want_pre, scale):
+    """Training forward of the one-launch MLP branch: the result is the inference kernel's bit for bit; the side outputs are
+    pre = x W1^T + b1 (before GELU) and m = GELU(pre) W2^T + b2 (before LayerNorm) -- reference layers.py:264-270 -- ragged M."""
+    from pangu_pytorch_amd import ops_bf16 as ob
+    x = synth.uniform((M, C), 81, 1.5).to(BF)
+    w1 = synth.uniform((4 * C, C), 82, 1.5 / C ** 0.5).to(BF)
+    w2 = synth.uniform((C, 4 * C), 83, 1.0 / (2 * C ** 0.5)).to(BF)
+    b1, b2 = synth.uniform((4 * C,), 84, 0.5), synth.uniform((C,), 85, 0.5)
+    g, be = synth.uniform((C,), 86, 0.5, 1.0), synth.uniform((C,), 87, 0.3)
+    img = ob.pack_mlp_weights(w1.cuda(), w2.cuda())
+    args = (x.cuda(), img, b1.cuda(), b2.cuda(), g.cuda(), be.cuda())
+    want = ob.mlp_ln_residual(*args, branch_scale=scale)
+    out, pre, m = ob.mlp_ln_residual_train(*args, branch_scale=scale, want_pre=want_pre)
+    assert torch.equal(out, want)
+    ref_pre = x.double() @ w1.double().t() + b1.double()
+    ref_m = torch.nn.functional.gelu(ref_pre) @ w2.double().t() + b2.double()
+    assert (pre is None) == (not want_pre)
+    if want_pre:
+        assert pre.shape == (M, 4 * C) and pre.dtype == BF
+        e = (pre.double().cpu() - ref_pre).abs()
+        assert e.max().item() < ROUND * ref_pre.abs().max().item() and rel_err(pre, ref_pre.float()) < ROUND
+    assert m.shape == (M, C) and m.dtype == BF
+    assert rel_err(m, ref_m.float()) < ROUND and (m.double().cpu() - ref_m).abs().max().item() < 2.5 * ROUND * ref_m.abs().max().item()
+
+
+@pytest.mark.parametrize("M,C", [(1500, 192), (4099, 192), (5000, 384), (300, 384)])
+def test_linear_gelu_bwd_with_hidden_bf16(P, M, C):
+    """Backward through linear2 + GELU with h = GELU(pre) re-created in the same launch (weights-stationary kernel at
+    K = 192, LDS-DMA ring at K = 384): dpre is the plain GELU_BWD epilogue's bit for bit, h == gelu(pre) to bf16 rounding."""
+    from pangu_pytorch_amd import ops_bf16 as ob
+    N = 4 * C
+    pre = synth.uniform((M, N), 70, 2.5).to(BF).cuda()
+    dm, w2t = synth.uniform((M, C), 68).to(BF).cuda(), synth.uniform((N, C), 69, 0.05).to(BF).cuda()
+    want = ob.linear(dm, w2t, None, act=ob.ACT_GELU_BWD, aux=pre)
+    dpre, h = ob.linear_gelu_bwd(dm, w2t, pre)
+    assert torch.equal(dpre, want)
+    ref_h = torch.nn.functional.gelu(pre.double().cpu())
+    assert (h.double().cpu() - ref_h).abs().max().item() < ROUND * ref_h.abs().max().item()
+    assert rel_err(h, ref_h.float()) < ROUND
+    x = pre.float().cpu().requires_grad_(True)
+    (torch.nn.functional.gelu(x) * (dm.float().cpu() @ w2t.float().cpu().t())).sum().backward()
+    assert rel_err(dpre, x.grad) < ROUND
+    d2, h2 = ob.linear_gelu_bwd(dm, w2t, pre, want_h=False)
+    assert h2 is None and torch.equal(d2, want)
+
+
 def test_linear_bf16_random_shapes(P):
     """Ragged M, K % 8 == 0, every kernel family (weights-stationary, LDS-DMA ring, register-staged), bias / GELU / add."""
     import random

@@ -97,7 +97,7 @@ def test_flat_grad_sync_batch2_matches_per_sample_mean(dtype):
     s0, s1 = W.sample(0), W.sample(1)
     stats, maps, const_h = s0[4:]
     order = [p for b in D.default_buckets(model) for p in b if p.requires_grad]
-    # reference: the two samples one at a time (B = 1 each, no FlatGradSync), same DropPath draw sequence
+    # reference: the two samples one at a time (B = 1 each, no FlatGradSync)
     want = torch.zeros(sum(p.numel() for p in order))
     for smp in (s0, s1):
         model.zero_grad(set_to_none=True)
@@ -111,7 +111,7 @@ def test_flat_grad_sync_batch2_matches_per_sample_mean(dtype):
     model.zero_grad(set_to_none=True)
     sync = D.FlatGradSync(model)
     try:
-            cat = lambda a, b: torch.cat((a, b), 0)
+        cat = lambda a, b: torch.cat((a, b), 0)
         out, out_s = model(cat(s0[0], s1[0]), cat(s0[1], s1[1]), stats, maps, const_h)
         train.weighted_l1_loss(out, out_s, cat(s0[2], s1[2]), cat(s0[3], s1[3])).backward()
         sync.finish()
