@@ -29,6 +29,9 @@ FWD_GFLOP_EXEC = 8302.3     # executed here: the QKV / output projections skip t
 XGMI_LINK_GBS = 153.0       # one xGMI link, one direction (7 links per GPU, point to point)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 PEAK_HBM_GBS = 8000.0
+ACHIEVABLE_HBM_GBS = 6290.0    # MI355X_MICROARCH.md: float4 copy
+PEAK_BF16_MFMA_TFLOPS = 2500.0
+SHARED_SOURCES = ["common.h", os.path.join("..", "..", "include", "pangu_hip.h")]      # hashed with every kernel family (tools/pmc_to_json.py too)
 
 
 def cpu_baseline():
@@ -103,12 +106,31 @@ def pmc_traffic(dtype, family):
         j = json.load(open(os.path.join(ROOT, "profiles", f"pmc_traffic_{dtype}.json")))
         e = j[family]
         h = hashlib.sha256()
-        for f in e["sources"]:
+        for f in list(e["sources"]) + SHARED_SOURCES:        # the kernel files of the family + what every kernel includes
             h.update(open(os.path.join(ROOT, "pangu-pytorch_amd", "csrc", f), "rb").read())
         stale = h.hexdigest()[:16] != e["source_sha"]
         return (None if stale else e["hbm_bytes_per_launch"]), (None if stale else e["mfma_busy_frac"]), stale, j.get("commit")
     except (OSError, KeyError, ValueError):
         return None, None, None, None
+
+
+def pmc_train(tag):
+    """HBM bytes per training step (sum over every kernel of the step: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc
+    passes of tools/profile_train.py, written by tools/pmc_train_table.py --json -> profiles/pmc_train.json), or None when the
+    table is missing or any kernel source changed since it was taken."""
+    import glob
+    import hashlib
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "pmc_train.json")))
+        e = j[tag]
+        h = hashlib.sha256()
+        csrc = os.path.join(ROOT, "pangu-pytorch_amd", "csrc")
+        for f in sorted(glob.glob(os.path.join(csrc, "*.hip"))) + [os.path.join(csrc, f) for f in SHARED_SOURCES]:
+            h.update(open(f, "rb").read())
+        stale = h.hexdigest()[:16] != j.get("source_sha")
+        return (None if stale else e), stale, j.get("commit")
+    except (OSError, KeyError, ValueError):
+        return None, None, None
 
 
 def synthetic_inputs(dev, seed):
@@ -173,12 +195,19 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ops.timing_start()                     # HIP-event pairs around every GEMM launch of the timed region
-    t0 = time.perf_counter()
+    t0 = time.perf_counter()               # the HEADLINE loop is un-instrumented: nothing but the K steps between the barriers
     for _ in range(args.steps):
         out = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    # second pass over the same K steps with HIP-event pairs around every GEMM / attention launch (~170 event records per
+    # step on the launch stream): the per-kernel roofline numbers come from here, its step time is reported beside the headline
+    ops.timing_start()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed_instr = time.perf_counter() - t1
     gemm_ms, gemm_flop, gemm_launches, other = ops.timing_stop("linear", also=("linear_ln", "attn"))
     fused_ms, fused_flop, fused_launches = other["linear_ln"]      # GEMMs with the fused LayerNorm+residual epilogue
     attn_ms, attn_flop, attn_launches = other["attn"]              # fused window attention (QK^T + bias + mask + softmax + PV)
@@ -326,6 +355,20 @@ def main():
                     "steps": args.train_steps, "loss": float(loss),
                     "peak_mem_gb": torch.cuda.max_memory_allocated() / 2**30,
                     "model_tflops": 3 * FWD_GFLOP_EXEC / (t_train / args.train_steps * 1e3)}
+                # roofline block of the training step: bytes per step from the committed PMC table, both fractions
+                pm, pm_stale, pm_commit = pmc_train("bf16" if dt == torch.bfloat16 else "f32")
+                t_s = t_train / args.train_steps
+                flop = 3 * FWD_GFLOP_EXEC * 1e9
+                peak = PEAK_BF16_MFMA_TFLOPS if dt == torch.bfloat16 else PEAK_F32_MFMA_TFLOPS
+                train_res[tag]["roofline"] = {
+                    "algorithmic_flop_per_step": flop, "mfma_peak": peak, "mfma_frac": flop / t_s / 1e12 / peak,
+                    "hbm_bytes_per_step": pm["hbm_bytes_per_step"] if pm else None,
+                    "hbm_frac_of_8TBps": pm["hbm_bytes_per_step"] / t_s / 1e9 / PEAK_HBM_GBS if pm else None,
+                    "hbm_frac_of_achievable_6.29TBps": pm["hbm_bytes_per_step"] / t_s / 1e9 / ACHIEVABLE_HBM_GBS if pm else None,
+                    "bound": ("hbm" if pm and pm["hbm_bytes_per_step"] / PEAK_HBM_GBS / 1e9 > flop / peak / 1e12 else "mfma"),
+                    "traffic_stale": pm_stale, "traffic_commit": pm_commit,
+                    "traffic_unit": "HBM bytes per step = sum over all kernels of one step (FETCH_SIZE x2 + WRITE_SIZE; rocprofv3 --pmc "
+                                    "passes of tools/profile_train.py -> profiles/pmc_train.json)"}
                 if sync:
                     train_res[tag]["exposed_allreduce_ms_per_step"] = sum(a.elapsed_time(b) for a, b in exposed) / max(len(exposed), 1)
                     train_res[tag]["grad_copy_fallback_mib"] = sync.copied_bytes / 2**20
@@ -347,6 +390,7 @@ def main():
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
+        ms_i = elapsed_instr / args.steps * 1e3          # step time of the instrumented pass (this rank)
         achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         # HBM bytes per launch of the same kernel family from the committed rocprofv3 PMC run (separate --pmc passes,
         # FETCH_SIZE doubled per MI355X_MICROARCH.md): counters cannot be read from inside this process
@@ -369,18 +413,22 @@ def main():
                                          "null + traffic_stale when the kernel source changed since)",
                          "algorithmic_flop_per_launch": gemm_flop / max(gemm_launches, 1),
                          "mfma_busy_frac_pmc": mfma_busy, "launches": gemm_launches, "avg_launch_ms": gemm_ms / max(gemm_launches, 1),
-                         "share_of_step": gemm_ms / (ms * args.steps),
+                         "share_of_step": gemm_ms / (ms_i * args.steps),
+                         "timing_pass": {"note": "per-kernel durations come from a SECOND pass over the same K steps with HIP-event pairs around "
+                                                 "each launch; the headline value / ms_per_step come from the un-instrumented loop",
+                                         "instrumented_ms_per_step": ms_i, "event_overhead_ms_per_step": ms_i - ms,
+                                         "event_pairs_per_step": (gemm_launches + fused_launches + attn_launches) / args.steps},
                          "fused_ln_gemm": {"kernel": "gemm_ln_residual_f32_dma_kernel (projection + LayerNorm + residual)",
                                            "launches": fused_launches, "avg_launch_ms": fused_ms / max(fused_launches, 1),
                                            "achieved": fused_flop / (fused_ms * 1e-3) / 1e12 if fused_ms > 0 else 0.0,
-                                           "share_of_step": fused_ms / (ms * args.steps)},
+                                           "share_of_step": fused_ms / (ms_i * args.steps)},
                          "attention": {"kernel": "window_attn_f32_kernel (QK^T + Earth bias + shift mask + softmax + PV, one launch per block)",
                                        "bound": "mfma", "achieved": a_achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                        "frac": a_achieved / PEAK_F32_MFMA_TFLOPS, "launches": attn_launches,
                                        "avg_launch_ms": attn_ms / max(attn_launches, 1),
                                        "algorithmic_flop_per_launch": attn_flop / max(attn_launches, 1),
                                        "traffic": a_traffic, "traffic_stale": a_stale, "mfma_busy_frac_pmc": a_busy,
-                                       "share_of_step": attn_ms / (ms * args.steps)}},
+                                       "share_of_step": attn_ms / (ms_i * args.steps)}},
         }
         if split_res is not None:
             res["f32_split_forward"] = split_res

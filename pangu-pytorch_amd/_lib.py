@@ -9,7 +9,9 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpangu_hip.so")
+# PANGU_HIP_LIB: development override (tools/ A/B builds of one kernel file linked into a second library); the product loads
+# the in-tree library next to this file
+LIB_PATH = os.environ.get("PANGU_HIP_LIB") or os.path.join(_HERE, "libpangu_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "pangu_hip.h")
 
 _c = ctypes

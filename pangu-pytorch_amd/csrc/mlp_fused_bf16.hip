@@ -63,6 +63,9 @@ constexpr float LN_EPS = 1e-5f;
 #ifndef PANGU_MLP_IGLP
 #define PANGU_MLP_IGLP 4        // VALU instructions placed behind each MFMA of a step (0 = leave it to the scheduler)
 #endif
+#ifndef PANGU_MLP_PRE_VARIANT
+#define PANGU_MLP_PRE_VARIANT 0 // training variant, how the pre-activation leaves: 0 = 16-B pieces via v_permlane32_swap, 1 = the same with s_nop padding (hazard probe), 2 = 8-B pieces, no exchange
+#endif
 #ifndef PANGU_MLP_PRE_AT_TOP
 #define PANGU_MLP_PRE_AT_TOP 0  // training variant: pre-activation stores at the very top of an iteration instead of under the first fragment reads
 #endif
@@ -202,6 +205,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_ln_residual_bf16_kernel(
       Pre, 0, TR == 2 ? (int)(((size_t)(M - 1) * ldp + HID) * sizeof(u16)) : 0, 0x00020000);
   // one address register for all T tiles (tile tt adds a scalar offset); rows past M are dropped by the range check
   const unsigned pre_off = ((unsigned)(m0 + lr) * (unsigned)ldp + 8 * lh) * 2u;
+  [[maybe_unused]] const unsigned pre_off8 = ((unsigned)(m0 + lr) * (unsigned)ldp + 4 * lh) * 2u;      // (8-B pieces: PANGU_MLP_PRE_VARIANT 2)
   const int pre_tile = __builtin_amdgcn_readfirstlane(32 * ldp * 2);
   auto store_pre = [&](int chunk) {
     if (TR != 2) return;
@@ -210,12 +214,30 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_ln_residual_bf16_kernel(
 #pragma unroll
       for (int qp = 0; qp < 2; ++qp) {
         // quads 2qp, 2qp+1 only: four packed registers live at a time (the kernel sits at the 512-register limit)
-        const unsigned a0 = pack_bf16x2(hg[tt][8 * qp], hg[tt][8 * qp + 1]), a1 = pack_bf16x2(hg[tt][8 * qp + 2], hg[tt][8 * qp + 3]);
-        const unsigned b0 = pack_bf16x2(hg[tt][8 * qp + 4], hg[tt][8 * qp + 5]), b1 = pack_bf16x2(hg[tt][8 * qp + 6], hg[tt][8 * qp + 7]);
+        unsigned a0 = pack_bf16x2(hg[tt][8 * qp], hg[tt][8 * qp + 1]), a1 = pack_bf16x2(hg[tt][8 * qp + 2], hg[tt][8 * qp + 3]);
+        unsigned b0 = pack_bf16x2(hg[tt][8 * qp + 4], hg[tt][8 * qp + 5]), b1 = pack_bf16x2(hg[tt][8 * qp + 6], hg[tt][8 * qp + 7]);
+#if PANGU_MLP_PRE_VARIANT == 2
+        // no cross-lane exchange: each lane stores its own two 8-B pieces (hidden 8q + 4h .. +3 of quads 2qp, 2qp+1)
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{a0, a1}, p_rsrc, (int)pre_off8, tt * pre_tile + (chunk * 32 + 16 * qp) * 2, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{b0, b1}, p_rsrc, (int)pre_off8, tt * pre_tile + (chunk * 32 + 16 * qp + 8) * 2, 0);
+#else
+#if PANGU_MLP_PRE_VARIANT == 1
+        asm volatile("s_nop 7" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
+#endif
         const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
         const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{r0[0], r1[0], r0[1], r1[1]}, p_rsrc, (int)pre_off,
-                                               tt * pre_tile + (chunk * 32 + 16 * qp) * 2, 0);
+        u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
+#if PANGU_MLP_PRE_VARIANT == 1
+        asm volatile("s_nop 7" : "+v"(v));
+#endif
+        __builtin_amdgcn_raw_buffer_store_b128(v, p_rsrc, (int)pre_off, tt * pre_tile + (chunk * 32 + 16 * qp) * 2, 0);
+        // Write-after-read hazard the compiler does not cover (ROCm 7.2, gfx950): a 16-B buffer store reads its data
+        // registers over several cycles, and hipcc pads a following VALU write of those registers (s_nop) only when the
+        // store's soffset is an immediate; with soffset in an SGPR (the steady-state loop here) the GELU's first
+        // v_pk_mul_f32 re-used v[n:n+1] right behind the store and dword 1 of lanes 12-15 / 28-31 (+32) left with the
+        // product's bits (found by the oracle test as isolated wrong elements in columns 18, 19, 26, 27 mod 32).
+        asm volatile("s_nop 1" ::: "memory");
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
     }

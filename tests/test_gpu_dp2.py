@@ -97,16 +97,20 @@ def test_flat_grad_sync_batch2_matches_per_sample_mean(dtype):
     s0, s1 = W.sample(0), W.sample(1)
     stats, maps, const_h = s0[4:]
     order = [p for b in D.default_buckets(model) for p in b if p.requires_grad]
-    # reference: the two samples one at a time (B = 1 each, no FlatGradSync)
+    # reference: the two samples one at a time (B = 1 each, no FlatGradSync), each with HALF the loss -- what the batch-mean
+    # loss hands each sample.  (Halving afterwards instead is not bit-equivalent in bf16: a handful of gradient terms sit at
+    # the bottom of the exponent range -- gelu'(-20) * 1e-7, softmax weights of masked keys -- and flush differently at the
+    # two scales; one flipped bf16 rounding in a (N, 3C) tensor is then amplified 2-3x per block by the deliberately
+    # non-contractive golden weights: 3e-3 at the first block.  Same scale on both sides: equal to the last bit.)
     want = torch.zeros(sum(p.numel() for p in order))
     for smp in (s0, s1):
         model.zero_grad(set_to_none=True)
         out, out_s = model(smp[0], smp[1], stats, maps, const_h)
-        train.weighted_l1_loss(out, out_s, smp[2], smp[3]).backward()
+        (train.weighted_l1_loss(out, out_s, smp[2], smp[3]) * 0.5).backward()
         off = 0
         for p in order:
             if p.grad is not None:
-                want[off:off + p.numel()] += 0.5 * p.grad.float().flatten().cpu()
+                want[off:off + p.numel()] += p.grad.float().flatten().cpu()
             off += p.numel()
     model.zero_grad(set_to_none=True)
     sync = D.FlatGradSync(model)
@@ -129,4 +133,4 @@ def test_flat_grad_sync_batch2_matches_per_sample_mean(dtype):
         off += p.numel()
     l2 = ((got - want).norm() / want.norm()).item()
     print(f"B=2 FlatGradSync {dtype}: rel-L2 {l2:.2e}; worst bias table {worst}")
-    assert l2 < 2e-3 and worst[0] < 2e-3      # identical kernels; atomics order + bf16 rounding of the batch-mean loss scale
+    assert l2 < 1e-5 and worst[0] < 1e-6      # identical kernels at identical scales: only the fp32 atomics of the small tensors differ

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Register / scratch / LDS budget of every kernel of libpangu_hip.so, from the compiler's own resource report:
+
+  python tools/codeobj_resources.py > profiles/r03_codeobj_resources.md        (no GPU needed: hipcc cross-compiles gfx950)
+
+Each csrc/*.hip is compiled with the Makefile's flags plus -Rpass-analysis=kernel-resource-usage (the numbers that end up in
+the code object's kernel descriptors: .vgpr_count, .agpr_count, .private_segment_fixed_size, .group_segment_fixed_size).
+ScratchSize > 0 = spills (or a runtime-indexed private array): the VERDICT r2 item 4 rows are marked."""
+import glob
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "pangu-pytorch_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage",
+         "--cuda-device-only", "-c"]
+KEYS = ["VGPRs", "AGPRs", "ScratchSize [bytes/lane]", "SGPRs Spill", "VGPRs Spill", "Occupancy [waves/SIMD]", "LDS Size [bytes/block]",
+        "SGPRs"]
+
+
+def demangle(names):
+    out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout
+    return out.strip().split("\n")
+
+
+def main():
+    rows = []
+    for src in sorted(glob.glob(os.path.join(CSRC, "*.hip"))):
+        with tempfile.NamedTemporaryFile(suffix=".o") as tmp:
+            r = subprocess.run([HIPCC] + FLAGS + [src, "-o", tmp.name], capture_output=True, text=True)
+        cur = None
+        for line in r.stderr.splitlines():
+            m = re.search(r"remark: (?:Function Name: (\S+)|\s+([^:]+): (\S+))", line)
+            if not m:
+                continue
+            if m.group(1):
+                cur = {"file": os.path.basename(src), "name": m.group(1)}
+                rows.append(cur)
+            elif cur is not None:
+                cur[m.group(2).strip()] = m.group(3)
+    names = demangle([r["name"] for r in rows])
+    print("# Code-object resources of every kernel in libpangu_hip.so (gfx950, hipcc -O3; tools/codeobj_resources.py)\n")
+    print("VGPR + AGPR share one 512-entry file per SIMD lane (allocation granule 8): waves/SIMD = min(8, 512 // alloc).  "
+          "`scratch` = private_segment_fixed_size in bytes per lane (0 = no spill).\n")
+    print("| file | kernel | VGPR | AGPR | scratch B/lane | VGPR spills | waves/SIMD | static LDS B | SGPR |")
+    print("|---|---|---|---|---|---|---|---|---|")
+    for r, n in zip(rows, names):
+        n = n.replace("(anonymous namespace)::", "").replace("void ", "")
+        n = n.split("(")[0]
+        print(f"| {r['file']} | `{n[:90]}` | {r.get('VGPRs', '')} | {r.get('AGPRs', '')} | {r.get('ScratchSize [bytes/lane]', '')} | "
+              f"{r.get('VGPRs Spill', '')} | {r.get('Occupancy [waves/SIMD]', '')} | {r.get('LDS Size [bytes/block]', '')} | {r.get('SGPRs', '')} |")
+    spilled = [(r, n) for r, n in zip(rows, names) if r.get("ScratchSize [bytes/lane]", "0") not in ("0", "")]
+    print(f"\n{len(rows)} kernels, {len(spilled)} with scratch:")
+    for r, n in spilled:
+        print(f"* `{n.replace('(anonymous namespace)::', '').split('(')[0][:100]}` ({r['file']}): {r['ScratchSize [bytes/lane]']} B/lane, "
+              f"{r.get('VGPRs Spill', '?')} VGPRs spilled")
+
+
+if __name__ == "__main__":
+    main()

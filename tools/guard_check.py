@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Out-of-bounds write detector for the HIP path: runs a whole training step (forward + backward, B = 1) with every
+tensor the op wrappers allocate (torch.empty / empty_like / zeros) placed between two 1-MiB guard bands filled with a
+pattern, then checks every band.  A kernel that stores before the start or past the end of one of its outputs (harmless
+in a single-sample test when the neighbouring memory is free, silent corruption of a live neighbour otherwise) shows up
+with the Python call site that allocated the tensor.
+
+  python tools/guard_check.py [bf16|f32] [--poison]
+--poison: the guarded tensors are also pre-filled with NaNs, so an output element that a kernel leaves unwritten and a later
+kernel reads (fresh device memory is zero-filled, recycled memory is not) turns up as non-finite results.
+"""
+import math
+import os
+import sys
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+import pangu_pytorch_amd as P  # noqa: E402
+from pangu_pytorch_amd import train  # noqa: E402
+
+G = 1 << 20
+PAT = 0xA5
+POISON = "--poison" in sys.argv
+_empty, _empty_like, _zeros = torch.empty, torch.empty_like, torch.zeros
+live = []
+
+
+def _shape(size):
+    if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)):
+        return tuple(size[0])
+    return tuple(size)
+
+
+def g_empty(*size, dtype=None, device=None, **kw):
+    shape = _shape(size)
+    dtype = dtype or torch.float32
+    if device is None or torch.device(device).type != "cuda":
+        return _empty(*size, dtype=dtype, device=device, **kw)
+    nb = math.prod(shape) * torch.empty((), dtype=dtype).element_size()
+    pad = (-nb) % 256
+    buf = _empty(nb + pad + 2 * G, dtype=torch.uint8, device=device)
+    buf[:G].fill_(PAT)
+    buf[G + nb:].fill_(PAT)
+    if POISON and dtype in (torch.float32, torch.bfloat16, torch.float16):
+        buf[G:G + nb].fill_(0xFF)           # every element a NaN: an output element a kernel does not write, read later, poisons the results
+    where = "".join(traceback.format_stack(limit=6)[:-1][-3:])
+    live.append((buf, nb, where, shape, dtype))
+    return buf[G:G + nb].view(dtype).view(shape)
+
+
+def g_empty_like(t, dtype=None, **kw):
+    if not t.is_cuda:
+        return _empty_like(t, dtype=dtype, **kw)
+    return g_empty(tuple(t.shape), dtype=dtype or t.dtype, device=t.device)
+
+
+def g_zeros(*size, dtype=None, device=None, **kw):
+    if device is None or torch.device(device).type != "cuda":
+        return _zeros(*size, dtype=dtype, device=device, **kw)
+    t = g_empty(*size, dtype=dtype, device=device)
+    t.zero_()
+    return t
+
+
+def check():
+    bad = 0
+    for buf, nb, where, shape, dtype in live:
+        lo = int((buf[:G] != PAT).sum())
+        hi = int((buf[G + nb:] != PAT).sum())
+        if lo or hi:
+            bad += 1
+            idx_hi = (buf[G + nb:] != PAT).nonzero().flatten()
+            idx_lo = (buf[:G] != PAT).nonzero().flatten()
+            print(f"GUARD VIOLATION: tensor {shape} {dtype}: {lo} bytes changed BEFORE the start (last at -{G - int(idx_lo.max()) if lo else 0}), "
+                  f"{hi} bytes changed PAST the end (first at +{int(idx_hi.min()) if hi else 0}, last at +{int(idx_hi.max()) if hi else 0})\n{where}")
+    return bad
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = P.PanguModel(device=dev).to(dev).train()
+    inp, inp_s, stats, maps, const_h = bench.synthetic_inputs(dev, 1000)
+    tgt, tgt_s, *_ = bench.synthetic_inputs(dev, 2000)
+    model.set_compute_dtype(torch.bfloat16 if which == "bf16" else torch.float32)
+    torch.empty, torch.empty_like, torch.zeros = g_empty, g_empty_like, g_zeros
+    try:
+        for mode in ("train", "eval"):
+            model.train(mode == "train")
+            model.zero_grad(set_to_none=True)
+            out, out_s = model(inp, inp_s, stats, maps, const_h)
+            train.weighted_l1_loss(out, out_s, tgt, tgt_s).backward()
+            nan_params = [n for n, p in model.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()]
+            with torch.no_grad():
+                o2, o2s = model(inp, inp_s, stats, maps, const_h)
+            torch.cuda.synchronize()
+            print(f"{mode}: non-finite: output {not bool(torch.isfinite(out).all())}, no-grad output {not bool(torch.isfinite(o2).all())}, "
+                  f"parameter gradients {len(nan_params)} {nan_params[:6]}")
+            del out, out_s, o2, o2s
+    finally:
+        torch.empty, torch.empty_like, torch.zeros = _empty, _empty_like, _zeros
+    n = len(live)
+    bad = check()
+    print(f"{which}: {n} guarded tensors, {bad} with a damaged guard band")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -31,9 +31,12 @@ FAMILIES = {
 }
 
 
+SHARED_SOURCES = ["common.h", os.path.join("..", "..", "include", "pangu_hip.h")]      # as bench.py: hashed with every family
+
+
 def source_sha(files):
     h = hashlib.sha256()
-    for f in files:
+    for f in list(files) + SHARED_SOURCES:
         h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -39,6 +39,38 @@ def durations(d):
     return tot, cnt
 
 
+def step_totals(root, steps):
+    """Whole-step HBM bytes: every kernel of the traced command (warm-up steps included in `steps`), FETCH_SIZE x2 + WRITE_SIZE."""
+    rd, _ = counters(os.path.join(root, "p1"))
+    wr, _ = counters(os.path.join(root, "p2"))
+    r = sum(2.0 * v.get("FETCH_SIZE", 0.0) * 1024 for v in rd.values())
+    w = sum(v.get("WRITE_SIZE", 0.0) * 1024 for v in wr.values())
+    return {"hbm_read_bytes_per_step": r / steps, "hbm_write_bytes_per_step": w / steps, "hbm_bytes_per_step": (r + w) / steps,
+            "steps_in_trace": steps}
+
+
+def write_json(path, roots):
+    """roots: {"f32": (dir, steps), "bf16": (dir, steps)} -> profiles/pmc_train.json (bench.py's training roofline blocks)."""
+    import hashlib
+    import json
+    import subprocess
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(here, "pangu-pytorch_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip"))) + [os.path.join(csrc, "common.h"),
+                                                               os.path.join(csrc, "..", "..", "include", "pangu_hip.h")]:
+        h.update(open(f, "rb").read())
+    out = {k: step_totals(d, n) for k, (d, n) in roots.items()}
+    out["source_sha"] = h.hexdigest()[:16]
+    try:
+        commit = subprocess.run(["git", "-C", here, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except OSError:
+        commit = ""
+    out["commit"] = commit or os.environ.get("PANGU_COMMIT", "unknown")
+    out["command"] = "python3 tools/profile_train.py <dtype> 2 1 under rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes; FETCH_SIZE x2)"
+    json.dump(out, open(path, "w"), indent=1)
+
+
 def main(root):
     rd, n1 = counters(os.path.join(root, "p1"))
     wr, _ = counters(os.path.join(root, "p2"))
@@ -57,4 +89,7 @@ def main(root):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    if sys.argv[1] == "--json":          # --json <out.json> <f32 dir> <bf16 dir> <steps in each trace>
+        write_json(sys.argv[2], {"f32": (sys.argv[3], int(sys.argv[5])), "bf16": (sys.argv[4], int(sys.argv[5]))})
+    else:
+        main(sys.argv[1])

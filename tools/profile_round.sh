@@ -18,11 +18,16 @@ for DT in f32 bf16; do
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr_$DT -- python3 tools/profile_train.py $DT 3 1 > gpurun_out/${TAG}_train_${DT}.log 2>&1
   cp "$(find /tmp/tr_$DT -name '*kernel_stats.csv' | head -1)" gpurun_out/${TAG}_train_${DT}_kernel_stats.csv
 done
-P=/tmp/trpmc; rm -rf $P; mkdir -p $P
-timeout 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/p1 -- python3 tools/profile_train.py both 2 1 > $P/p1.log 2>&1
-timeout 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/p2 -- python3 tools/profile_train.py both 2 1 > $P/p2.log 2>&1
-timeout 500 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $P/p3 -- python3 tools/profile_train.py both 2 1 > $P/p3.log 2>&1
-python3 tools/pmc_train_table.py $P > gpurun_out/${TAG}_train_pmc_table.md 2> gpurun_out/${TAG}_train_pmc_table.err
+# per dtype (the two steps share kernel names -- Adam, row kernels, the reduce launch -- so each gets its own passes): per-kernel
+# table + whole-step byte totals (profiles/pmc_train.json: bench.py's training roofline blocks)
+for DT in f32 bf16; do
+  P=/tmp/trpmc_$DT; rm -rf $P; mkdir -p $P
+  timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/p1 -- python3 tools/profile_train.py $DT 2 1 > $P/p1.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/p2 -- python3 tools/profile_train.py $DT 2 1 > $P/p2.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $P/p3 -- python3 tools/profile_train.py $DT 2 1 > $P/p3.log 2>&1
+  { echo "## $DT training step"; python3 tools/pmc_train_table.py $P; } >> gpurun_out/${TAG}_train_pmc_table.md 2>> gpurun_out/${TAG}_train_pmc_table.err
+done
+python3 tools/pmc_train_table.py --json gpurun_out/pmc_train.json /tmp/trpmc_f32 /tmp/trpmc_bf16 3 && cp gpurun_out/pmc_train.json profiles/
 {
   for sec in mlp_fused attn_qkv_bf16 attn_bf16 gemm_bf16 wgrad_bf16 gemm_ln_bf16 attn attn_bwd gemm wgrad; do
     echo "## $sec"
