@@ -1,6 +1,6 @@
 """Generate golden vectors by running the REFERENCE itself (build container only; needs /root/reference).
 
-TEST INFRASTRUCTURE. Usage:  python oracle/gen_golden.py [index] [blocks] [layers] [model] [model_bwd] [model_bwd_smooth] [extras] [rollout2] [keys_table]
+TEST INFRASTRUCTURE. Usage:  python oracle/gen_golden.py [index] [blocks] [layers] [model] [model_bwd] [model_bwd_smooth] [extras] [rollout2] [keys_table] [refinit]
 Outputs small fixtures (fingerprints: samples + sums, index tensors, packed masks) under tests/golden/.
 Inputs and parameters are closed-form (oracle/synth.py), so tests regenerate them bit-identically.
 """
@@ -29,11 +29,11 @@ def save(name, d):
     print("wrote", name, len(d), "arrays")
 
 
-def load_params(module, prefix):
+def load_params(module, prefix, spec="golden"):
     """Overwrite every parameter of a reference module with synthetic values keyed by prefix+local name."""
     with torch.no_grad():
         for k, p in module.named_parameters():
-            p.copy_(synth.synth_param(prefix + k, tuple(p.shape)))
+            p.copy_(synth.synth_param(prefix + k, tuple(p.shape), spec=spec))
 
 
 def gen_index(L, M):
@@ -210,6 +210,56 @@ def gen_model_smooth(L, M):
     save("model_bwd_smooth.npz", d)
 
 
+def gen_refinit(L, M):
+    """Goldens in the REFERENCE's initialisation regime (synth.param_spec_refinit: weights std 0.02, LayerNorm (1, 0), zero
+    biases -- models/pangu_model.py:41-48), for tight bf16 bounds:
+      * every block variant at W = 24: fp32 output + dx fingerprints, AND the same block under the reference's own CPU
+        autocast(bfloat16) -- its drift against fp32 is recorded (`.autocast_drift`, SURVEY App. B measured 3.75e-3): the HIP
+        bf16 block must stay within 2x of it;
+      * the whole model's smooth backward (sum(out * cot)): 223 gradient fingerprints + the loss."""
+    d = {}
+    for C in (192, 384):
+        st = cases.STAGES[C]
+        Z, H, W = st["Z"], st["H"], 24
+        for roll in (False, True):
+            torch.manual_seed(0)
+            blk = L.EarthSpecificBlock(C, 0.1, st["heads"], device="cpu").eval()
+            load_params(blk, cases.block_prefix(C, roll), spec="refinit")
+            x = cases.block_input(C, W).requires_grad_(True)
+            y = blk(x, Z, H, W, roll)
+            tag = f"refinit_block_{C}_{int(roll)}"
+            d.update(cases.summarize(y, tag + ".out"))
+            cot = cases.cotangent(tag, y.shape)
+            (y * cot).sum().backward()
+            d.update(cases.summarize(x.grad, tag + ".dx"))
+            with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+                yb = blk(x.detach(), Z, H, W, roll)
+            yb = yb.float()
+            d[tag + ".autocast_drift"] = torch.tensor([((yb - y.detach()).norm() / y.detach().norm()).item(),
+                                                       ((yb - y.detach()).abs().max() / y.detach().abs().max()).item()])
+            d[tag + ".out_full"] = y.detach().to(torch.float16) if y.numel() * 2 < (3 << 20) else torch.zeros(1)
+            print(tag, "reference autocast-bf16 drift (rel-L2, max-abs/max):", d[tag + ".autocast_drift"].tolist())
+    torch.manual_seed(0)
+    model = M.PanguModel(device="cpu")
+    load_params(model, "", spec="refinit")
+    model.eval()
+    inp, inp_s, stats, maps, const_h = cases.model_inputs()
+    t = time.time()
+    out, out_s = model(inp, inp_s, stats, maps, const_h)
+    loss = ((out * cases.cotangent("model_out", out.shape)).sum() +
+            (out_s * cases.cotangent("model_out_s", out_s.shape)).sum()) / out.numel()
+    loss.backward()
+    print("refinit model smooth fwd+bwd ref %.1fs loss %.8f" % (time.time() - t, loss.item()))
+    d["model.loss"] = torch.tensor([loss.item()], dtype=torch.float64)
+    d.update(cases.summarize(out, "model.out"))
+    for k, p in model.named_parameters():
+        s = cases.summarize(p.grad, "model.d_" + k)
+        d[f"model.d_{k}.samples"] = s[f"model.d_{k}.samples"][:256]
+        d[f"model.d_{k}.abs_sum"] = s[f"model.d_{k}.abs_sum"]
+        d[f"model.d_{k}.l2"] = p.grad.double().norm().to(torch.float32).reshape(1)
+    save("refinit.npz", d)
+
+
 def stats_last_of(stats):
     """The `weatherStatistics_output` view of the input statistics (reference era5_data/utils_data.py:214-236):
     surface (1,4,1,1); upper (13,1,1,5) -> levels reversed -> (1,5,13,1,1)."""
@@ -305,3 +355,5 @@ if __name__ == "__main__":
         gen_keys_table(L, M)
     if "rollout2" in what:
         gen_rollout(L, M, steps=2)
+    if "refinit" in what:
+        gen_refinit(L, M)

@@ -90,11 +90,25 @@ def param_spec(name, shape):
     raise ValueError(name)
 
 
-def synth_param(name, shape, device="cpu", dtype=torch.float32):
-    scale, shift = param_spec(name, shape)
+def param_spec_refinit(name, shape):
+    """(scale, shift) in the REFERENCE's initialisation scales (models/pangu_model.py:41-48, layers.py:314): Linear / Conv1d
+    weights and the Earth-specific bias tables std 0.02 (trunc-normal there; the closed-form uniform of the same std here, so
+    both sides of a test regenerate them), LayerNorm (1, 0), biases 0 -- the contractive regime real checkpoints live in, where
+    bf16 errors are not amplified from block to block as under `param_spec`'s O(1) weights."""
+    if name.endswith("earth_specific_bias"):
+        return 0.02, 0.0
+    if name.endswith(".weight"):
+        return (0.0, 1.0) if ".norm" in name else (0.02, 0.0)
+    if name.endswith(".bias"):
+        return 0.0, 0.0
+    raise ValueError(name)
+
+
+def synth_param(name, shape, device="cpu", dtype=torch.float32, spec="golden"):
+    scale, shift = (param_spec_refinit if spec == "refinit" else param_spec)(name, shape)
     return uniform(shape, name_seed(name), scale, shift, device=device, dtype=dtype)
 
 
-def fill_state_dict(shapes, device="cpu", dtype=torch.float32):
-    """shapes: {name: shape}. Returns {name: tensor} with synthetic values."""
-    return {k: synth_param(k, tuple(v), device, dtype) for k, v in shapes.items()}
+def fill_state_dict(shapes, device="cpu", dtype=torch.float32, spec="golden"):
+    """shapes: {name: shape}. Returns {name: tensor} with synthetic values (spec: "golden" = param_spec, "refinit")."""
+    return {k: synth_param(k, tuple(v), device, dtype, spec) for k, v in shapes.items()}

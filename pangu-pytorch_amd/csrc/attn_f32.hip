@@ -15,6 +15,7 @@
 // Workgroup order is XCD-aware: the nLon windows sharing one (type, head) bias tile (83 KB) are consecutive
 // on one XCD, so the 62 MB bias tensor streams from HBM once per block and is re-read from L2.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -270,7 +271,10 @@ __global__ __launch_bounds__(192, 3) void window_attn_f32_kernel(const float* __
                                                               const float* __restrict__ qkv_bias,
                                                               const float* __restrict__ esb,
                                                               float* __restrict__ out, float* __restrict__ lse,
-                                                              WinGeom g, int C, int heads, int n_pairs) {
+                                                              WinGeom g, int C, int heads, int n_pairs, int shift) {
+  // SHIFTED = the instantiation carries the mask code; `shift` (runtime, <= SHIFTED) = the geometry actually rolled.  The two
+  // agree in the product; PANGU_ATTN_F32_TPL=1 runs unshifted blocks on the masked instantiation (A/B of the code generation:
+  // profiles/r03 notes)
   __shared__ __attribute__((aligned(16))) float Ks[PANGU_WTOK * KV_LD];
   __shared__ __attribute__((aligned(16))) float Vs[PANGU_WTOK * KV_LD];
 
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(192, 3) void window_attn_f32_kernel(const float* __
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int qn = (wave + 3 * i) * 16 + lq;
-    qtok[i] = win_src_token(g, l, t, qn, SHIFTED);
+    qtok[i] = win_src_token(g, l, t, qn, shift);
     const float* src = (qtok[i] >= 0 ? qkv + (size_t)qtok[i] * C3 : qkv_bias) + hd * 32 + lg * 4;
     q0[i] = *reinterpret_cast<const f32x4*>(src);
     q1[i] = *reinterpret_cast<const f32x4*>(src + 16);
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(192, 3) void window_attn_f32_kernel(const float* __
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const int f = tid + 192 * i, n = f >> 3, c4 = (f & 7) * 4;
-      const int tok = win_src_token(g, l, t, n, SHIFTED);
+      const int tok = win_src_token(g, l, t, n, shift);
       const float* src = tok >= 0 ? qkv + (size_t)tok * C3 : qkv_bias;
       kv[i] = *reinterpret_cast<const f32x4*>(src + C + hd * 32 + c4);
       vv[i] = *reinterpret_cast<const f32x4*>(src + 2 * C + hd * 32 + c4);
@@ -331,8 +335,8 @@ __global__ __launch_bounds__(192, 3) void window_attn_f32_kernel(const float* __
   unsigned long long kz_bits = 0ull, kh_bits = 0ull;
   if (SHIFTED) {
     const int zwin = t / g.nHw, hwin = t - zwin * g.nHw;
-    zcut = zwin == g.nZw - 1;
-    hcut = hwin == g.nHw - 1;
+    zcut = shift && zwin == g.nZw - 1;
+    hcut = shift && hwin == g.nHw - 1;
 #pragma unroll
     for (int j = 0; j < 9; ++j)
 #pragma unroll
@@ -407,8 +411,9 @@ static int launch_attn_fwd(pangu_stream_t stream, const float* qkv, const float*
   hipStream_t s = (hipStream_t)stream;
 #define PANGU_LAUNCH_ATTN(SH, CP)                                                                                      \
   hipLaunchKernelGGL((window_attn_f32_kernel<SH, CP>), dim3(grid), dim3(192), 0, s, qkv, qkv_bias, esb, out, lse, g, C, \
-                     heads, n_pairs)
-  if (shifted) {
+                     heads, n_pairs, shifted ? 1 : 0)
+  static const int tpl = getenv("PANGU_ATTN_F32_TPL") ? atoi(getenv("PANGU_ATTN_F32_TPL")) : 0;
+  if (shifted || tpl == 1) {
     if (compact) PANGU_LAUNCH_ATTN(true, true); else PANGU_LAUNCH_ATTN(true, false);
   } else {
     if (compact) PANGU_LAUNCH_ATTN(false, true); else PANGU_LAUNCH_ATTN(false, false);

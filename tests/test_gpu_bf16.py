@@ -528,6 +528,82 @@ def test_full_backward_smooth_bf16_vs_reference(P, golden_dir):
     assert masses[0][0] < BF16_GRAD_MASS_TOL, masses[0]
 
 
+@pytest.mark.parametrize("C,roll", [(192, False), (192, True), (384, False), (384, True)])
+def test_block_bf16_drift_within_2x_of_reference_autocast(P, golden_dir, C, roll):
+    """in the REFERENCE's initialisation regime (weights std 0.02, LayerNorm (1, 0), zero biases:
+    models/pangu_model.py:41-48; synth.param_spec_refinit) the HIP bf16 block -- training forward and no-grad forward -- drifts
+    from fp32 by no more than 2x what the reference's own CPU autocast(bfloat16) block does on the same input
+    (tests/golden/refinit.npz: 4.2e-3 rel-L2, recorded by oracle/gen_golden.py refinit)."""
+    from pangu_pytorch_amd import autograd_bf16 as AB, fused_bf16
+    g = np.load(os.path.join(golden_dir, "refinit.npz"))
+    tag = f"refinit_block_{C}_{int(roll)}"
+    st = cases.STAGES[C]
+    blk = P.layers.EarthSpecificBlock(C, 0.0, st["heads"], device="cuda").cuda().eval()
+    pre = cases.block_prefix(C, roll)
+    blk.load_state_dict({k: synth.synth_param(pre + k, sh_, "cuda", spec="refinit") for k, sh_ in cases.block_param_shapes(C).items()})
+    x = cases.block_input(C, 24, "cuda")
+    with torch.no_grad():
+        y32 = blk(x, st["Z"], st["H"], 24, roll)                        # fp32 HIP path
+    # ... which IS the reference's fp32 block (golden fingerprint of the reference's output)
+    pos = synth.sample_positions(y32.numel(), cases.NSAMP, synth.name_seed("pos_" + tag + ".out"), device="cuda")
+    gs = torch.as_tensor(g[tag + ".out.samples"])
+    assert ((y32.flatten()[pos].cpu() - gs).abs().max() / gs.abs().max()).item() < 1e-4
+    ref_drift = float(g[tag + ".autocast_drift"][0])
+    att, shd = blk.attention, fused_bf16.WeightShadow()
+    xb = x[0].to(BF)
+    yb_train = AB.EarthBlockFnBF16.apply(xb.clone().requires_grad_(True), blk.norm1.weight, blk.norm1.bias, blk.norm2.weight,
+                                         blk.norm2.bias, blk.linear.linear1.weight, blk.linear.linear1.bias,
+                                         blk.linear.linear2.weight, blk.linear.linear2.bias, att.earth_specific_bias,
+                                         att.linear1.weight, att.linear1.bias, att.linear2.weight, att.linear2.bias,
+                                         (st["Z"], st["H"], 24, st["heads"], roll), 1.0, 1.0, shd).detach()
+    with torch.no_grad():
+        yb_inf = fused_bf16._block(blk, shd, xb, st["Z"], st["H"], 24, roll)
+    l2 = lambda a: ((a.double() - y32[0].double()).norm() / y32[0].double().norm()).item()
+    d_train, d_inf = l2(yb_train.float()), l2(yb_inf.float())
+    print(f"{tag}: bf16 drift vs fp32: training forward {d_train:.2e}, inference forward {d_inf:.2e}; reference autocast {ref_drift:.2e}")
+    # measured on MI355X: 1.00-1.04x the reference's own autocast drift (4.2-4.4e-3 vs 4.2-4.3e-3); the bound asked for is 2x
+    assert d_train < 1.25 * ref_drift and d_inf < 1.25 * ref_drift
+
+
+def test_full_backward_smooth_bf16_refinit_vs_reference(P, golden_dir):
+    """whole-model bf16 backward against the REFERENCE's fp32 autograd in the reference's initialisation
+    regime (tests/golden/refinit.npz): the loss, the output, and every one of the 223 gradient tensors -- worst tensor bounded
+    at 5e-2 rel-L2 over its stored samples (the O(1) non-contractive golden weights need 0.35: they amplify, this regime
+    does not)."""
+    g = np.load(os.path.join(golden_dir, "refinit.npz"))
+    m = P.PanguModel(device="cuda").cuda().eval()
+    m.load_state_dict(synth.fill_state_dict(cases.model_param_shapes(), "cuda", spec="refinit"))
+    inp, inp_s, stats, maps, const_h = cases.model_inputs("cuda")
+
+    def run(dt):
+        m.set_compute_dtype(dt)
+        m.zero_grad(set_to_none=True)
+        out, out_s = m(inp, inp_s, stats, maps, const_h)
+        loss = ((out * cases.cotangent("model_out", out.shape, "cuda")).sum() +
+                (out_s * cases.cotangent("model_out_s", out_s.shape, "cuda")).sum()) / out.numel()
+        loss.backward()
+        res = []
+        for k, p in m.named_parameters():
+            flat = p.grad.detach().float().flatten()
+            assert torch.isfinite(flat).all(), k
+            pos = synth.sample_positions(flat.numel(), cases.NSAMP, synth.name_seed("pos_model.d_" + k), device=flat.device)[:256]
+            gs = torch.as_tensor(g[f"model.d_{k}.samples"]).double()
+            res.append((((flat[pos].cpu().double() - gs).norm() / gs.norm().clamp_min(1e-30)).item(),
+                        abs(flat.double().norm().item() - float(g[f"model.d_{k}.l2"][0])) / float(g[f"model.d_{k}.l2"][0]), k))
+        pos = synth.sample_positions(out.numel(), cases.NSAMP, synth.name_seed("pos_model.out"), device="cuda")
+        go = torch.as_tensor(g["model.out.samples"]).double()
+        return loss.item(), ((out.detach().flatten()[pos].cpu().double() - go).norm() / go.norm()).item(), res
+
+    for dt, tol_s, tol_n, tol_o in ((torch.float32, 2e-3, 1e-3, 1e-4), (BF, 5e-2, 2e-2, 1.5e-2)):
+        loss, oerr, res = run(dt)
+        worst_s, worst_n = max(res), max((r[1], r[2]) for r in res)
+        med = sorted(r[0] for r in res)[len(res) // 2]
+        print(f"REFINIT {dt}: loss {loss:.8f} (reference {float(g['model.loss'][0]):.8f}), output rel-L2 {oerr:.2e}; gradient samples "
+              f"worst {worst_s[0]:.2e} ({worst_s[2]}), median {med:.2e}; gradient norm worst {worst_n[0]:.2e} ({worst_n[1]})")
+        assert oerr < tol_o and worst_s[0] < tol_s and worst_n[0] < tol_n
+        assert abs(loss - float(g["model.loss"][0])) < (2e-6 if dt == torch.float32 else 2e-5)
+
+
 @pytest.mark.parametrize("s1,s2", [(0.0, 1.25), (1.25, 0.0), (1.25, 1.25), (1.0, 1.0)])
 def test_block_bf16_nograd_droppath(P, s1, s2):
     """bf16 inference block in train() mode under no_grad: DropPath factors per branch like the fp32 path (a dropped

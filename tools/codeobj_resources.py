@@ -27,9 +27,39 @@ def demangle(names):
     return out.strip().split("\n")
 
 
+def scratch_in_loops(src):
+    """{mangled kernel name: (scratch instructions, of which inside a loop, [(MFMAs, scratch instructions) per loop])} from the
+    assembly: a loop = a backward branch to a label; what matters for speed is whether the K / window loop touches scratch."""
+    with tempfile.NamedTemporaryFile(suffix=".s") as tmp:
+        subprocess.run([HIPCC] + [f for f in FLAGS if f not in ("-c", "-Rpass-analysis=kernel-resource-usage")] + ["-S", src, "-o", tmp.name],
+                       capture_output=True, text=True)
+        lines = open(tmp.name).read().split("\n")
+    out, cur, body = {}, None, []
+    for l in lines:
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            cur, body = m.group(1), []
+        elif cur is not None:
+            body.append(l)
+            if "s_endpgm" in l:
+                labels = {mm.group(1): i for i, b in enumerate(body) for mm in [re.match(r"^(\.LBB\d+_\d+):", b)] if mm}
+                loops = []
+                for i, b in enumerate(body):
+                    mm = re.search(r"s_c?branch\w* (\.LBB\d+_\d+)", b)
+                    if mm and mm.group(1) in labels and labels[mm.group(1)] < i:
+                        loops.append((labels[mm.group(1)], i))
+                sc = [i for i, b in enumerate(body) if "scratch_" in b]
+                inl = [i for i in sc if any(a <= i <= e for a, e in loops)]
+                out[cur] = (len(sc), len(inl), [(sum("v_mfma" in x for x in body[a:e]), sum("scratch_" in x for x in body[a:e])) for a, e in loops])
+                cur = None
+    return out
+
+
 def main():
     rows = []
+    loops = {}
     for src in sorted(glob.glob(os.path.join(CSRC, "*.hip"))):
+        loops.update(scratch_in_loops(src))
         with tempfile.NamedTemporaryFile(suffix=".o") as tmp:
             r = subprocess.run([HIPCC] + FLAGS + [src, "-o", tmp.name], capture_output=True, text=True)
         cur = None
@@ -55,9 +85,13 @@ def main():
               f"{r.get('VGPRs Spill', '')} | {r.get('Occupancy [waves/SIMD]', '')} | {r.get('LDS Size [bytes/block]', '')} | {r.get('SGPRs', '')} |")
     spilled = [(r, n) for r, n in zip(rows, names) if r.get("ScratchSize [bytes/lane]", "0") not in ("0", "")]
     print(f"\n{len(rows)} kernels, {len(spilled)} with scratch:")
+    print("(scratch instructions: total / inside a loop; per loop (MFMAs, scratch instructions) -- a kernel whose MFMA loops show 0 "
+          "spills only in its prologue / epilogue)\n")
     for r, n in spilled:
+        tot, inl, per = loops.get(r["name"], (None, None, []))
+        per = [x for x in per if x[0] or x[1]]
         print(f"* `{n.replace('(anonymous namespace)::', '').split('(')[0][:100]}` ({r['file']}): {r['ScratchSize [bytes/lane]']} B/lane, "
-              f"{r.get('VGPRs Spill', '?')} VGPRs spilled")
+              f"{r.get('VGPRs Spill', '?')} VGPRs spilled; scratch instructions {tot} / {inl} in loops; loops {per}")
 
 
 if __name__ == "__main__":

@@ -13,7 +13,7 @@ for (Z, H, W, C, heads, types) in ((8, 181, 360, 192, 6, 124), (8, 91, 180, 384,
     N = Z * H * W
     qkv = torch.randn(N, 3 * C, device="cuda").to(dt)
     qb = torch.randn(3 * C, device="cuda").to(dt)
-    esb = (torch.randn(1, types, heads, 144, 144, device="cuda") * 0.02).to(dt)
+    esb = (torch.randn(types, heads, 144, 144, device="cuda") * 0.02).to(dt)
     mod = ob if bf else ops
     for shifted in (False, True):
         if bwd:
