@@ -174,6 +174,15 @@ int pangu_patch_embed_gather(pangu_stream_t stream, const float* input, const fl
  *   y_surface [H4*W4][64]  col = v*16 + ph*4 + pw          -> output_surface [4][LAT][LON] */
 int pangu_patch_recover_scatter(pangu_stream_t stream, const float* y_upper, const float* y_surface,
                                 float* output, float* output_surface, int LAT, int LON);
+/* The same scatter with the reference's `normBackData` (era5_data/utils_data.py:324-330) folded in for the rollout: besides
+ * the normalised fields every element is also written in physical units, phys = out * std + mean (a multiply, then an add,
+ * as the reference's expression rounds) of its (variable, level) plane, into phys [5][13][LAT][LON] / phys_surface
+ * [4][LAT][LON] -- the next step's input buffers.  upper_mean / upper_std: [5][13] (the `weather_statistics_last` layout,
+ * utils_data.py:214-236), surface_mean / surface_std: [4]. */
+int pangu_patch_recover_scatter_denorm(pangu_stream_t stream, const float* y_upper, const float* y_surface, float* output,
+                                       float* output_surface, float* phys, float* phys_surface, const float* upper_mean,
+                                       const float* upper_std, const float* surface_mean, const float* surface_std, int LAT,
+                                       int LON);
 
 /* Backward of the scatter: gradients of the two field tensors -> dy_upper [7*H4*W4][160], dy_surface [H4*W4][64]
  * (cropped positions get 0). */
@@ -207,6 +216,12 @@ int pangu_window_attn_fwd_bf16(pangu_stream_t stream, const void* qkv, const voi
 int pangu_window_attn_qkv_fwd_bf16(pangu_stream_t stream, const void* x, int ldx, const void* w_qkv, const float* b_qkv,
                                    const void* esb, void* out, float* lse, int Z, int H, int W, int C, int heads,
                                    int shifted);
+/* Training forward of the same launch: additionally writes the projected qkv (n_tok x 3C bf16, dense; channel =
+ * which*C + head*32 + d, reference layers.py:368-371) and lse (n_tok x heads fp32) -- exactly what pangu_window_attn_bwd_bf16
+ * reads -- so the forward needs no separate QKV GEMM and the attention core does not re-read qkv from memory. */
+int pangu_window_attn_qkv_train_fwd_bf16(pangu_stream_t stream, const void* x, int ldx, const void* w_qkv, const float* b_qkv,
+                                         const void* esb, void* out, float* lse, void* qkv_out, int Z, int H, int W, int C,
+                                         int heads, int shifted);
 
 int pangu_ln_residual_fwd_bf16(pangu_stream_t stream, const void* y, const void* shortcut, int lds, const float* gamma,
                                const float* beta, void* out, int ldo, int N, int C, float branch_scale);

@@ -37,6 +37,7 @@ SIGNATURES = {
     "pangu_linear_fwd_bf16": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I],
     "pangu_window_attn_fwd_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I],
     "pangu_window_attn_qkv_fwd_bf16": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I],
+    "pangu_window_attn_qkv_train_fwd_bf16": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I],
     "pangu_ln_residual_fwd_bf16": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _F],
     "pangu_linear_ln_residual_fwd_bf16": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
     "pangu_mlp_ln_residual_fwd_bf16": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F],
@@ -60,6 +61,7 @@ SIGNATURES = {
     "pangu_upsample_ln_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I],
     "pangu_patch_embed_gather": [_P] * 11 + [_I, _I],
     "pangu_patch_recover_scatter": [_P, _P, _P, _P, _P, _I, _I],
+    "pangu_patch_recover_scatter_denorm": [_P] * 11 + [_I, _I],
 }
 _RESTYPES = {"pangu_error_string": _c.c_char_p}
 

@@ -17,6 +17,13 @@ from . import ops_bf16 as ob
 _TRAIN_MLP = int(os.environ.get("PANGU_BF16_TRAIN_MLP", "1"))
 
 
+# Attention branch of the training forward (A/B knob PANGU_BF16_TRAIN_QKV): 1 = the QKV projection inside the attention
+# launch with qkv + lse as side outputs (no QKV GEMM launch, no re-read of qkv by the attention core), 0 (default) = QKV GEMM +
+# attention.  Measured on MI355X (interleaved, profiles/r03 notes): 49.1 vs 48.8 ms per step -- writing the 0.3-0.6 GB qkv tensor
+# from the (window, head) workgroups (8-B pieces) costs what the saved re-read gains, so the two-launch form stays.
+_TRAIN_QKV = int(os.environ.get("PANGU_BF16_TRAIN_QKV", "0"))
+
+
 def _mlp_mode(C):
     if C not in (192, 384) or _TRAIN_MLP == 0 or (_TRAIN_MLP == 2 and C != 384):
         return 0
@@ -25,29 +32,38 @@ def _mlp_mode(C):
 
 class EarthBlockFnBF16(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, n1w, n1b, n2w, n2b, m1w, m1b, m2w, m2b, esb, a1w, a1b, a2w, a2b, geom, s1, s2, sh):
+    def forward(ctx, x, n1w, n1b, n2w, n2b, m1w, m1b, m2w, m2b, esb, a1w, a1b, a2w, a2b, geom, s1, s2, sh, dst=None):
+        # dst: optional 1-tuple holding a (N, C) row-strided view the block writes its result into (a half of the skip-concat
+        # buffer of reference pangu_model.py:81) -- wrapped so that autograd does not see a tensor argument
+        out = dst[0] if dst else None
         Z, H, W, heads, shifted = geom
         ctx.geom, ctx.s1, ctx.s2, ctx.sh = geom, s1, s2, sh
         ctx.params = (n1w, n2w, m1w, m2w, esb, a1w, a1b, a2w, m1b)
         saved = [x]
         x1 = x
         if s1 != 0.0:
-            qkv = ob.linear(x, sh.get(a1w), a1b)
-            o, lse = ob.window_attention(qkv, sh.get(a1b), sh.get(esb), Z, H, W, heads, shifted, want_lse=True)
+            if _TRAIN_QKV and x.shape[1] in (192, 384) and x.is_contiguous():
+                o, lse, qkv = ob.window_attention_qkv_train(x, sh.get(a1w), a1b, sh.get(esb), Z, H, W, heads, shifted)
+            else:
+                qkv = ob.linear(x, sh.get(a1w), a1b)
+                o, lse = ob.window_attention(qkv, sh.get(a1b), sh.get(esb), Z, H, W, heads, shifted, want_lse=True)
             y = ob.linear(o, sh.get(a2w), a2b)
             x1 = ob.ln_residual(y, x, n1w, n1b, branch_scale=s1)
             saved += [qkv, o, lse, y]
         ctx.mlp_mode = mode = _mlp_mode(x.shape[1]) if x1.is_contiguous() else 0
         if s2 != 0.0 and mode:
             x2, pre, m = ob.mlp_ln_residual_train(x1, sh.get_mlp(m1w, m2w), m1b, m2b, n2w, n2b, branch_scale=s2,
-                                                  want_pre=mode == 1)
+                                                  want_pre=mode == 1, out=out)
             saved += [x1, m] if pre is None else [x1, pre, m]
         elif s2 != 0.0:
             pre = torch.empty((x.shape[0], m1w.shape[0]), dtype=torch.bfloat16, device=x.device)
             h = ob.linear(x1, sh.get(m1w), m1b, act=ob.ACT_GELU, aux=pre)
             m = ob.linear(h, sh.get(m2w), m2b)
-            x2 = ob.ln_residual(m, x1, n2w, n2b, branch_scale=s2)
+            x2 = ob.ln_residual(m, x1, n2w, n2b, out=out, branch_scale=s2)
             saved += [x1, pre, h, m]
+        elif out is not None:
+            out.copy_(x1)
+            x2 = out
         else:
             x2 = x1
         ctx.save_for_backward(*saved)
@@ -117,7 +133,7 @@ class EarthBlockFnBF16(torch.autograd.Function):
         elif not dx.is_contiguous():
             dx = dx.contiguous()
         return (dx, g["n1w"], g["n1b"], g["n2w"], g["n2b"], g["m1w"], g["m1b"], g["m2w"], g["m2b"], g["esb"],
-                g["a1w"], g["a1b"], g["a2w"], g["a2b"], None, None, None, None)
+                g["a1w"], g["a1b"], g["a2w"], g["a2b"], None, None, None, None, None)
 
 
 class PatchEmbedFnBF16(torch.autograd.Function):
@@ -188,27 +204,40 @@ class UpSampleFnBF16(torch.autograd.Function):
 
 
 class PatchRecoverFnBF16(torch.autograd.Function):
+    """reference layers.py:511-545 on the channel concat of pangu_model.py:81.  `skip` and `x` are the two (N, C) halves of ONE
+    (N, 2C) buffer (the last blocks of layer 0 / layer 3 wrote them in place): no concat copy in the forward, and the backward
+    hands each half its own CONTIGUOUS gradient (two N = C products instead of one N = 2C product whose halves would be
+    row-strided views: the consumers' fast paths want dense rows)."""
+
     @staticmethod
-    def forward(ctx, x, cw, cb, sw, sb, geom, sh):
+    def forward(ctx, skip, x, cw, cb, sw, sb, geom, sh):
         n_s, LAT, LON = geom
-        y_s = ob.linear(x[:n_s], sh.get(sw), sb, out_dtype=torch.float32)
-        y_u = ob.linear(x[n_s:], sh.get(cw), cb, out_dtype=torch.float32)
-        ctx.save_for_backward(x)
+        N, C = skip.shape
+        adjacent = (skip.stride() == (2 * C, 1) and x.stride() == (2 * C, 1) and x.data_ptr() == skip.data_ptr() + 2 * C
+                    and skip.untyped_storage().data_ptr() == x.untyped_storage().data_ptr())
+        cat = torch.as_strided(skip, (N, 2 * C), (2 * C, 1), skip.storage_offset()) if adjacent else torch.cat((skip, x), dim=-1)
+        y_s = ob.linear(cat[:n_s], sh.get(sw), sb, out_dtype=torch.float32)
+        y_u = ob.linear(cat[n_s:], sh.get(cw), cb, out_dtype=torch.float32)
+        ctx.save_for_backward(cat)
         ctx.geom, ctx.sh, ctx.params = geom, sh, (cw, sw)
         return ops.patch_recover_scatter(y_u, y_s, LAT, LON)
 
     @staticmethod
     def backward(ctx, d_out, d_out_s):
-        (x,) = ctx.saved_tensors
+        (cat,) = ctx.saved_tensors
         cw, sw = ctx.params
         n_s, LAT, LON = ctx.geom
+        C = cat.shape[1] // 2
         dy_u, dy_s = ob.patch_recover_gather_bwd(d_out.contiguous(), d_out_s.contiguous())
-        dcw, dcb = ob.linear_wgrad(dy_u, x[n_s:])
-        dsw, dsb = ob.linear_wgrad(dy_s, x[:n_s])
-        dx = torch.empty_like(x)
-        ob.linear(dy_s, ctx.sh.get_t(sw), out=dx[:n_s])
-        ob.linear(dy_u, ctx.sh.get_t(cw), out=dx[n_s:])
-        return dx, dcw.reshape(cw.shape), dcb, dsw.reshape(sw.shape), dsb, None, None
+        dcw, dcb = ob.linear_wgrad(dy_u, cat[n_s:])
+        dsw, dsb = ob.linear_wgrad(dy_s, cat[:n_s])
+        wt_s, wt_u = ctx.sh.get_t(sw), ctx.sh.get_t(cw)                    # (2C, 64), (2C, 160): rows = input channels
+        d_skip = torch.empty((cat.shape[0], C), dtype=cat.dtype, device=cat.device)
+        d_x = torch.empty_like(d_skip)
+        for dst, rows in ((d_skip, slice(0, C)), (d_x, slice(C, 2 * C))):
+            ob.linear(dy_s, wt_s[rows], out=dst[:n_s])
+            ob.linear(dy_u, wt_u[rows], out=dst[n_s:])
+        return d_skip, d_x, dcw.reshape(cw.shape), dcb, dsw.reshape(sw.shape), dsb, None, None
 
 
 def forward_train(model, inp, inp_surface, statistics, maps, const_h):
@@ -226,7 +255,8 @@ def forward_train(model, inp, inp_surface, statistics, maps, const_h):
     emb, rec, dn, up = model._input_layer, model._output_layer, model.downsample, model.upsample
     H2, W2 = (H4 + 1) // 2, W4 // 2
 
-    def run_layer(layer, x, Z, H, W):
+    def run_layer(layer, x, Z, H, W, out=None):
+        last = len(layer.blocks) - 1
         for i, blk in enumerate(layer.blocks):
             att, dp = blk.attention, blk.drop_path
             s1 = dp.sample_scale(blk.training) if hasattr(dp, "sample_scale") else 1.0
@@ -235,7 +265,7 @@ def forward_train(model, inp, inp_surface, statistics, maps, const_h):
                 x, blk.norm1.weight, blk.norm1.bias, blk.norm2.weight, blk.norm2.bias, blk.linear.linear1.weight,
                 blk.linear.linear1.bias, blk.linear.linear2.weight, blk.linear.linear2.bias, att.earth_specific_bias,
                 att.linear1.weight, att.linear1.bias, att.linear2.weight, att.linear2.bias,
-                (Z, H, W, att.head_number, i % 2 == 1), s1, s2, sh)
+                (Z, H, W, att.head_number, i % 2 == 1), s1, s2, sh, (out,) if out is not None and i == last else None)
         return x
 
     outs, outs_s = [], []
@@ -243,14 +273,22 @@ def forward_train(model, inp, inp_surface, statistics, maps, const_h):
         x = PatchEmbedFnBF16.apply(emb.conv.weight, emb.conv.bias, emb.conv_surface.weight, emb.conv_surface.bias,
                                    inp[b].contiguous(), inp_surface[b].contiguous(), s_mean, s_std, u_mean, u_std, maps_c,
                                    const_c, sh)
-        skip = run_layer(model.layers[0], x, 8, H4, W4)
+        # skip connection (reference pangu_model.py:81): layer 0 / layer 3 write their results straight into the two halves of
+        # one (N, 2C) buffer -- no concat copy, as in the inference path
+        Nn, Cc = x.shape
+        cat = torch.empty((Nn, 2 * Cc), dtype=torch.bfloat16, device=dev)
+        # the two halves as tensors that SHARE cat's storage without being autograd views of it (a view returned by a custom
+        # Function whose base is written again -- the other half -- is refused by autograd)
+        halves = [torch.empty(0, dtype=torch.bfloat16, device=dev).set_(cat.untyped_storage(), off, (Nn, Cc), (2 * Cc, 1))
+                  for off in (0, Cc)]
+        skip = run_layer(model.layers[0], x, 8, H4, W4, out=halves[0])
         x = DownSampleFnBF16.apply(skip, dn.linear.weight, dn.norm.weight, dn.norm.bias, (8, H4, W4), sh)
         x = run_layer(model.layers[1], x, 8, H2, W2)
         x = run_layer(model.layers[2], x, 8, H2, W2)
         x = UpSampleFnBF16.apply(x, up.linear1.weight, up.linear2.weight, up.norm.weight, up.norm.bias, (8, H2, W2, H4), sh)
-        x = run_layer(model.layers[3], x, 8, H4, W4)
-        o, os_ = PatchRecoverFnBF16.apply(torch.cat((skip, x), dim=-1), rec.conv.weight, rec.conv.bias,
-                                          rec.conv_surface.weight, rec.conv_surface.bias, (H4 * W4, LAT, LON), sh)
+        x = run_layer(model.layers[3], x, 8, H4, W4, out=halves[1])
+        o, os_ = PatchRecoverFnBF16.apply(skip, x, rec.conv.weight, rec.conv.bias, rec.conv_surface.weight,
+                                          rec.conv_surface.bias, (H4 * W4, LAT, LON), sh)
         outs.append(o)
         outs_s.append(os_)
     if B == 1:

@@ -185,11 +185,20 @@ __global__ __launch_bounds__(256) void patch_embed_gather_kernel(
 }
 
 // ---- patch recover scatter -------------------------------------------------------------------------------
+// DENORM (rollout, reference era5_data/utils_data.py:324-330 `normBackData` folded in): every element also leaves in physical
+// units, phys = out * std + mean of its (variable, level) plane -- the same two roundings as the reference's expression
+// (a multiply, then an add: no fused multiply-add) -- into a second pair of fields: the next step's input buffers.
+template <bool DENORM>
 __global__ __launch_bounds__(256) void patch_recover_scatter_kernel(const float* __restrict__ y_upper,
                                                                     const float* __restrict__ y_surface,
                                                                     float* __restrict__ output,
                                                                     float* __restrict__ output_surface, int LAT,
-                                                                    int LON, int H4, int W4, int chunks) {
+                                                                    int LON, int H4, int W4, int chunks,
+                                                                    float* __restrict__ phys, float* __restrict__ phys_surface,
+                                                                    const float* __restrict__ u_mean,
+                                                                    const float* __restrict__ u_std,
+                                                                    const float* __restrict__ s_mean,
+                                                                    const float* __restrict__ s_std) {
   __shared__ float tile[EMB_TOK * 161];
   const int chunk = blockIdx.x % chunks, h4 = (blockIdx.x / chunks) % H4, zp = blockIdx.x / (chunks * H4);
   const int w0 = chunk * EMB_TOK;
@@ -211,14 +220,26 @@ __global__ __launch_bounds__(256) void patch_recover_scatter_kernel(const float*
     const int lat = 4 * h4 + ph;
     if (lat >= LAT) continue;
     float* dst;
+    float* dst2 = nullptr;
+    float mn = 0.f, sd = 1.f;
     if (zp == 0) {
       dst = output_surface + v * plane + (size_t)lat * LON;
+      if (DENORM) { dst2 = phys_surface + v * plane + (size_t)lat * LON; mn = s_mean[v]; sd = s_std[v]; }
     } else {
       const int lev = 2 * (zp - 1) + pz;
       if (lev >= 13) continue;
       dst = output + ((size_t)v * 13 + lev) * plane + (size_t)lat * LON;
+      if (DENORM) { dst2 = phys + ((size_t)v * 13 + lev) * plane + (size_t)lat * LON; mn = u_mean[v * 13 + lev]; sd = u_std[v * 13 + lev]; }
     }
-    for (int i = (tid & 63); i < 4 * ntok; i += 64) dst[4 * w0 + i] = tile[(i >> 2) * 161 + run * 4 + (i & 3)];
+    for (int i = (tid & 63); i < 4 * ntok; i += 64) {
+      const float val = tile[(i >> 2) * 161 + run * 4 + (i & 3)];
+      dst[4 * w0 + i] = val;
+      if (DENORM) {
+        float p = val * sd;
+        asm volatile("" : "+v"(p));        // the product is rounded before the add, as torch's `out * std + mean` rounds it
+        dst2[4 * w0 + i] = p + mn;         // (hipcc contracts even __fadd_rn(__fmul_rn(..)) into one v_fma_f32)
+      }
+    }
   }
 }
 
@@ -289,8 +310,24 @@ extern "C" int pangu_patch_recover_scatter(pangu_stream_t stream, const float* y
   if (!y_upper || !y_surface || !output || !output_surface) return PANGU_E_NULL;
   if (LAT <= 0 || LON <= 0 || (LON & 3)) return PANGU_E_SHAPE;
   const int H4 = (LAT + 3) / 4, W4 = LON / 4, chunks = (W4 + EMB_TOK - 1) / EMB_TOK;
-  hipLaunchKernelGGL(patch_recover_scatter_kernel, dim3(8 * H4 * chunks), dim3(256), 0, (hipStream_t)stream, y_upper,
-                     y_surface, output, output_surface, LAT, LON, H4, W4, chunks);
+  hipLaunchKernelGGL(patch_recover_scatter_kernel<false>, dim3(8 * H4 * chunks), dim3(256), 0, (hipStream_t)stream, y_upper,
+                     y_surface, output, output_surface, LAT, LON, H4, W4, chunks, nullptr, nullptr, nullptr, nullptr, nullptr,
+                     nullptr);
+  return pangu_launch_status();
+}
+
+extern "C" int pangu_patch_recover_scatter_denorm(pangu_stream_t stream, const float* y_upper, const float* y_surface,
+                                                  float* output, float* output_surface, float* phys, float* phys_surface,
+                                                  const float* upper_mean, const float* upper_std, const float* surface_mean,
+                                                  const float* surface_std, int LAT, int LON) {
+  if (!y_upper || !y_surface || !output || !output_surface || !phys || !phys_surface || !upper_mean || !upper_std ||
+      !surface_mean || !surface_std)
+    return PANGU_E_NULL;
+  if (LAT <= 0 || LON <= 0 || (LON & 3)) return PANGU_E_SHAPE;
+  const int H4 = (LAT + 3) / 4, W4 = LON / 4, chunks = (W4 + EMB_TOK - 1) / EMB_TOK;
+  hipLaunchKernelGGL(patch_recover_scatter_kernel<true>, dim3(8 * H4 * chunks), dim3(256), 0, (hipStream_t)stream, y_upper,
+                     y_surface, output, output_surface, LAT, LON, H4, W4, chunks, phys, phys_surface, upper_mean, upper_std,
+                     surface_mean, surface_std);
   return pangu_launch_status();
 }
 

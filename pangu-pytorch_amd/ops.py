@@ -430,10 +430,49 @@ def patch_embed_gather(inp, inp_surface, s_mean, s_std, u_mean, u_std, maps, con
     return a_s, a_u
 
 
+_denorm_target = None      # (phys_upper (B,5,13,LAT,LON), phys_surface (B,4,LAT,LON), (u_mean, u_std, s_mean, s_std) flat fp32, [sample counter])
+
+
+class scatter_denorm:
+    """Rollout: inside this context every `patch_recover_scatter` (the last kernel of a forward) ALSO writes its fields in
+    physical units (reference era5_data/utils_data.py:324-330 `normBackData`: out * std + mean, a multiply then an add) into
+    `phys_upper[b]` / `phys_surface[b]` -- the next step's input buffers -- instead of four elementwise passes over the 286 MB
+    afterwards.  stats_last = (s_mean (1,4,1,1), s_std, u_mean (1,5,13,1,1), u_std)."""
+
+    def __init__(self, phys_upper, phys_surface, stats_last):
+        s_mean, s_std, u_mean, u_std = stats_last
+        f = lambda t: t.to(device=phys_upper.device, dtype=torch.float32).reshape(-1).contiguous()
+        self.target = [phys_upper, phys_surface, (f(u_mean), f(u_std), f(s_mean), f(s_std)), 0]
+        if self.target[2][0].numel() != 65 or self.target[2][2].numel() != 4:
+            raise RuntimeError("scatter_denorm: stats_last must be (s_mean (1,4,1,1), s_std, u_mean (1,5,13,1,1), u_std)")
+
+    def __enter__(self):
+        global _denorm_target
+        self.prev, _denorm_target = _denorm_target, self.target
+        self.target[3] = 0
+        return self
+
+    def __exit__(self, *exc):
+        global _denorm_target
+        _denorm_target = self.prev
+
+
 def patch_recover_scatter(y_upper, y_surface, LAT, LON):
     lib = _lib.load()
     out = torch.empty((5, 13, LAT, LON), dtype=torch.float32, device=y_upper.device)
     out_s = torch.empty((4, LAT, LON), dtype=torch.float32, device=y_upper.device)
+    tgt = _denorm_target
+    if tgt is not None:
+        b = tgt[3]
+        tgt[3] += 1
+        pu, ps = tgt[0][b], tgt[1][b]
+        if tuple(pu.shape) != (5, 13, LAT, LON) or not pu.is_contiguous() or not ps.is_contiguous():
+            raise RuntimeError(f"scatter_denorm target {tuple(pu.shape)} does not match the (5, 13, {LAT}, {LON}) fields")
+        um, us, sm, ss = tgt[2]
+        _lib.check(lib.pangu_patch_recover_scatter_denorm(
+            _stream(), _chk(y_upper, "y_upper"), _chk(y_surface, "y_surface"), out.data_ptr(), out_s.data_ptr(), pu.data_ptr(),
+            ps.data_ptr(), um.data_ptr(), us.data_ptr(), sm.data_ptr(), ss.data_ptr(), LAT, LON), "patch_recover_scatter_denorm")
+        return out, out_s
     _lib.check(lib.pangu_patch_recover_scatter(_stream(), _chk(y_upper, "y_upper"), _chk(y_surface, "y_surface"),
                                                out.data_ptr(), out_s.data_ptr(), LAT, LON), "patch_recover_scatter")
     return out, out_s

@@ -3,8 +3,9 @@
 Shape of the loop: reference inference/inference_singleOutput.py:97-105 (the output of one 24 h step is the input of
 the next).  The torch model returns NORMALISED fields (reference models/layers.py:531,542 leave the de-normalisation
 commented out), so each step is followed by `normBackData` (reference era5_data/utils_data.py:324-330) before the
-fields are fed back; here that de-normalisation writes straight into the step's static input buffers, inside the same
-captured graph, so the 286 MB state never leaves the device and one rollout step is ONE graph launch.
+fields are fed back; here that de-normalisation is folded into the forward's last kernel (`pangu_patch_recover_scatter_denorm`
+writes the physical fields straight into the step's static input buffers), inside the same captured graph, so the 286 MB state
+never leaves the device, costs no extra pass, and one rollout step is ONE graph launch.
 """
 import torch
 
@@ -51,10 +52,13 @@ class GraphedStep:
         self.inp_surface.copy_(inp_surface)
 
     def _body(self):
-        out, out_s = self.model(self.inp, self.inp_surface, *self.consts)
         if self.feed_back:
-            norm_back_into(out, out_s, self.stats_last, self.inp, self.inp_surface)
-        return out, out_s
+            # normBackData folded into the forward's last kernel: the scatter writes the physical fields straight into the
+            # input buffers (read by the first kernel of this same forward, long finished by then)
+            from . import ops
+            with ops.scatter_denorm(self.inp, self.inp_surface, self.stats_last):
+                return self.model(self.inp, self.inp_surface, *self.consts)
+        return self.model(self.inp, self.inp_surface, *self.consts)
 
     def load(self, inp, inp_surface):
         self.inp.copy_(inp)

@@ -266,6 +266,37 @@ def test_window_attention_qkv_fused_bf16(P, C, shifted, ring, monkeypatch):
     assert rel_err(got, two) < ROUND
 
 
+@pytest.mark.parametrize("C", [192, 384])
+@pytest.mark.parametrize("shifted", [False, True])
+def test_window_attention_qkv_train_side_outputs_bf16(P, C, shifted):
+    """Training forward of the fused QKV + attention launch: out and lse are the inference launch's bit for bit; the side
+    output qkv equals the QKV GEMM's (x W^T + b rounded to bf16 once; reference layers.py:365-371) on every real token."""
+    from pangu_pytorch_amd import ops_bf16 as ob
+    st = cases.STAGES[C]
+    Z, H, W, heads = st["Z"], st["H"], 24, st["heads"]
+    N = Z * H * W
+    x = synth.uniform((N, C), 35, 1.5).to(BF).cuda()
+    w = synth.uniform((3 * C, C), 36, 1.5 / C ** 0.5).to(BF).cuda()
+    b = synth.uniform((3 * C,), 37, 0.5).cuda()
+    esb = synth.uniform((st["types"], heads, 144, 144), 38, 0.5).to(BF).cuda()
+    torch.full((N, 3 * C), float("nan"), dtype=BF, device="cuda")          # recycled memory is not zero: unwritten rows show up
+    want, want_lse = ob.window_attention_qkv(x, w, b, esb, Z, H, W, heads, shifted, want_lse=True)
+    out, lse, qkv = ob.window_attention_qkv_train(x, w, b, esb, Z, H, W, heads, shifted)
+    assert torch.equal(out, want) and torch.equal(lse, want_lse)
+    ref = x.double() @ w.double().t() + b.double()
+    assert torch.isfinite(qkv.float()).all()
+    err = (qkv.double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < ROUND / 2, err
+    gemm = ob.linear(x, w, b)
+    assert ((qkv.float() - gemm.float()).abs().max() / ref.abs().max()).item() < ROUND / 2      # fp32 accumulation order differs, one bf16 ulp
+    # the backward kernel on the side output == on the GEMM's qkv up to that ulp
+    do = synth.uniform((N, C), 39).to(BF).cuda()
+    g1 = ob.window_attention_bwd(qkv, b.to(BF), esb, out, lse, do, Z, H, W, heads, shifted)
+    o2, l2 = ob.window_attention(gemm, b.to(BF), esb, Z, H, W, heads, shifted, want_lse=True)
+    g2 = ob.window_attention_bwd(gemm, b.to(BF), esb, o2, l2, do, Z, H, W, heads, shifted)
+    assert rel_err(g1[0], g2[0]) < 4 * ROUND and rel_err(g1[2], g2[2]) < 4 * ROUND
+
+
 def _attn_qkv_ring3(ob, x, w, b, esb, Z, H, W, heads, shifted, ring):
     """The other pipeline instantiations are chosen by an environment variable read once per process: run them in a child."""
     import subprocess
