@@ -641,6 +641,8 @@ extern "C" int pangu_window_attn_bwd_bf16(pangu_stream_t stream, const void* qkv
   if (!qkv || !qkv_bias || !esb || !out || !lse || !dout || !dqkv || !dqkv_bias || !d_esb) return PANGU_E_NULL;
   if (Z <= 0 || H <= 0 || W <= 0 || Z % PANGU_WZ || (H + PANGU_PAD_H) % PANGU_WH || W % PANGU_WW) return PANGU_E_SHAPE;
   if (heads <= 0 || C != heads * PANGU_HEAD_DIM) return PANGU_E_SHAPE;
+  // 32-bit buffer offsets; the pad-row sentinel 0x80000000 must stay OUTSIDE the (n_tok x 3C) buffers
+  if ((size_t)Z * H * W * 3 * C * sizeof(u16) >= 0x7FFFFFF0ull) return PANGU_E_RANGE;
   const WinGeom g = make_geom(Z, H, W);
   const int n_pairs = (heads & 1) ? g.types * heads : ((g.types * heads / 2 + 7) / 8) * 16;    // padded to whole XCD rounds
   const size_t shm = 4 * (size_t)ROWIMG + 3 * (size_t)TIMG + 3 * PANGU_WTOK * sizeof(float) + 64 * sizeof(float) +

@@ -259,20 +259,23 @@ def linear_ln_residual(a, weight, bias, shortcut, gamma, beta, out=None, branch_
 
 
 _WGRAD_WS_BYTES = 96 << 20
-_wgrad_ws = {}      # device -> fp32 scratch buffer of the two-stage weight-gradient reduction (allocated once, shared with ops_bf16)
+_wgrad_ws = {}      # (device, stream) -> fp32 scratch buffer of the two-stage weight-gradient reduction (shared with ops_bf16)
 
 
 def wgrad_workspace(device):
-    ws = _wgrad_ws.get(device)
+    """One 96-MB scratch buffer per (device, stream): launches of one stream are ordered, so they can share it; a backward
+    running on a side stream gets its own instead of racing on the default stream's."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _wgrad_ws.get(key)
     if ws is None:
         ws = torch.empty(_WGRAD_WS_BYTES // 4, dtype=torch.float32, device=device)
-        _wgrad_ws[device] = ws
+        _wgrad_ws[key] = ws
     return ws
 
 
 def linear_wgrad(dc, a, want_bias=True):
     """dW[N,K] = dc[M,N]^T @ a[M,K], db[N] = colsum(dc), ADDED into zero-initialised buffers; the token slabs' partial tiles
-    travel through a per-device scratch buffer (96 MB, allocated on first use; one per device: do not run weight gradients of one device on two streams at once; the few fp32 shapes whose slabs need 108 MB keep the atomic tail, measured level) and one reduce launch instead of fp32 atomics."""
+    travel through a per-(device, stream) scratch buffer (96 MB, allocated on first use; the few fp32 shapes whose slabs need 108 MB keep the atomic tail, measured level) and one reduce launch instead of fp32 atomics."""
     lib = _lib.load()
     ws = wgrad_workspace(dc.device)
     dp, lddc = _rows(dc, "wgrad.dc")

@@ -98,6 +98,37 @@ def mlp_fused():
               f"   | separate launches {ms2:7.3f} ms {fl / ms2 / 1e9:7.1f} TF/s")
 
 
+def mlp_train():
+    """Training forms of the MLP branch (bf16): the one-launch forward with its side outputs against the three launches it
+    replaces, and the backward's data-gradient GEMM with / without re-creating h = GELU(pre)."""
+    from pangu_pytorch_amd import ops_bf16 as ob
+    bf = torch.bfloat16
+    for M, C, name in ((521280, 192, "s0"), (131040, 384, "s1")):
+        x = torch.randn(M, C, device="cuda").to(bf)
+        w1 = (torch.randn(4 * C, C, device="cuda") / C ** 0.5).to(bf)
+        w2 = (torch.randn(C, 4 * C, device="cuda") / (4 * C) ** 0.5).to(bf)
+        b1, b2 = torch.randn(4 * C, device="cuda") * 0.1, torch.randn(C, device="cuda") * 0.1
+        g, be = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+        img = ob.pack_mlp_weights(w1, w2)
+        t_inf = timeit(lambda: ob.mlp_ln_residual(x, img, b1, b2, g, be))
+        t_tr = timeit(lambda: ob.mlp_ln_residual_train(x, img, b1, b2, g, be))
+        t_m = timeit(lambda: ob.mlp_ln_residual_train(x, img, b1, b2, g, be, want_pre=False))
+
+        def sep():
+            pre = torch.empty((M, 4 * C), dtype=bf, device="cuda")
+            h = ob.linear(x, w1, b1, act=ob.ACT_GELU, aux=pre)
+            return ob.ln_residual(ob.linear(h, w2, b2), x, g, be)
+        t_sep = timeit(sep)
+        dm = torch.randn(M, C, device="cuda").to(bf)
+        pre = torch.randn(M, 4 * C, device="cuda").to(bf)
+        w2t = w2.t().contiguous()
+        t_b0 = timeit(lambda: ob.linear(dm, w2t, None, act=ob.ACT_GELU_BWD, aux=pre))
+        t_b1 = timeit(lambda: ob.linear_gelu_bwd(dm, w2t, pre))
+        print(f"{name} MLP forward  M={M:6d} C={C:3d}: inference launch {t_inf:6.3f} ms | training launch (pre + m out) {t_tr:6.3f} | "
+              f"training launch (m only: recompute mode) {t_m:6.3f} | three launches writing pre AND h {t_sep:6.3f}")
+        print(f"{name} MLP backward M={M:6d} C={C:3d}: dpre = (dm W2) * gelu'(pre) {t_b0:6.3f} ms | the same + h = GELU(pre) written {t_b1:6.3f}")
+
+
 def gemm_ln():
     for M, N, K, name in ((521280, 192, 192, "s0 proj+LN"), (521280, 192, 768, "s0 mlp2+LN"), (131040, 384, 384, "s1 proj+LN"),
                           (131040, 384, 1536, "s1 mlp2+LN")):
@@ -235,5 +266,5 @@ def rows():
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
     {"gemm": lambda: gemm("--lib-compare" in sys.argv), "attn": attn, "attn_bwd": attn_bwd, "rows": rows,
-     "gemm_bf16": lambda: gemm_bf16("--lib-compare" in sys.argv), "attn_bf16": attn_bf16, "gemm_ln_bf16": gemm_ln_bf16, "mlp_fused": mlp_fused, "attn_qkv_bf16": attn_qkv_bf16, "gemm_ln": gemm_ln,
+     "gemm_bf16": lambda: gemm_bf16("--lib-compare" in sys.argv), "attn_bf16": attn_bf16, "gemm_ln_bf16": gemm_ln_bf16, "mlp_fused": mlp_fused, "mlp_train": mlp_train, "attn_qkv_bf16": attn_qkv_bf16, "gemm_ln": gemm_ln,
      "wgrad_bf16": lambda: wgrad(True), "wgrad": lambda: wgrad(False)}[what]()
