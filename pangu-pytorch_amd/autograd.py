@@ -21,7 +21,10 @@ class EarthBlockFn(torch.autograd.Function):
     """reference models/layers.py:183-253 (+ attention :360-421, Mlp :264-270) for one sample."""
 
     @staticmethod
-    def forward(ctx, x, n1w, n1b, n2w, n2b, m1w, m1b, m2w, m2b, esb, a1w, a1b, a2w, a2b, geom, s1, s2):
+    def forward(ctx, x, n1w, n1b, n2w, n2b, m1w, m1b, m2w, m2b, esb, a1w, a1b, a2w, a2b, geom, s1, s2, dst=None):
+        # dst: optional 1-tuple holding the (N, C) row-strided tensor the block writes its result into (one half of the
+        # skip-concat buffer of reference pangu_model.py:81); wrapped so that autograd does not see a tensor argument
+        out = dst[0] if dst else None
         Z, H, W, heads, shifted = geom
         ctx.geom, ctx.s1, ctx.s2 = geom, s1, s2
         saved = [x, n1w, n2w, m1w, m2w, esb, a1w, a1b, a2w]
@@ -36,8 +39,11 @@ class EarthBlockFn(torch.autograd.Function):
             pre = torch.empty((x.shape[0], m1w.shape[0]), dtype=x.dtype, device=x.device)
             h = ops.linear(x1, m1w, m1b, act=ops.ACT_GELU, aux=pre)
             m = ops.linear(h, m2w, m2b)
-            x2 = ops.ln_residual(m, x1, n2w, n2b, branch_scale=s2)
+            x2 = ops.ln_residual(m, x1, n2w, n2b, out=out, branch_scale=s2)
             saved += [x1, pre, h, m]
+        elif out is not None:
+            out.copy_(x1)
+            x2 = out
         else:
             x2 = x1
         ctx.save_for_backward(*saved)
@@ -96,7 +102,7 @@ class EarthBlockFn(torch.autograd.Function):
         elif not dx.is_contiguous():
             dx = dx.contiguous()
         return (dx, g["n1w"], g["n1b"], g["n2w"], g["n2b"], g["m1w"], g["m1b"], g["m2w"], g["m2b"], g["esb"],
-                g["a1w"], g["a1b"], g["a2w"], g["a2b"], None, None, None)
+                g["a1w"], g["a1b"], g["a2w"], g["a2b"], None, None, None, None)
 
 
 class PatchEmbedFn(torch.autograd.Function):
@@ -192,3 +198,37 @@ class PatchRecoverFn(torch.autograd.Function):
         ops.linear(dy_s, _wt(sw), out=dx[:n_s])
         ops.linear(dy_u, _wt(cw), out=dx[n_s:])
         return dx, dcw.reshape(cw.shape), dcb, dsw.reshape(sw.shape), dsb, None
+
+
+class PatchRecoverHalvesFn(torch.autograd.Function):
+    """The same layer on the channel concat of reference pangu_model.py:81 given as its two (N, C) halves, which are the two
+    halves of ONE (N, 2C) buffer (layer 0 / layer 3 wrote them in place): no concat copy in the forward, and each half gets
+    its own DENSE gradient in the backward (two N = C products instead of row-strided views of one N = 2C product)."""
+
+    @staticmethod
+    def forward(ctx, skip, x, cw, cb, sw, sb, geom):
+        n_s, LAT, LON = geom
+        N, C = skip.shape
+        assert skip.stride() == (2 * C, 1) and x.stride() == (2 * C, 1) and x.data_ptr() == skip.data_ptr() + 4 * C
+        cat = torch.as_strided(skip, (N, 2 * C), (2 * C, 1), skip.storage_offset())
+        y_s = ops.linear(cat[:n_s], sw, sb)
+        y_u = ops.linear(cat[n_s:], cw, cb)
+        ctx.save_for_backward(cat, cw, sw)
+        ctx.geom = geom
+        return ops.patch_recover_scatter(y_u, y_s, LAT, LON)
+
+    @staticmethod
+    def backward(ctx, d_out, d_out_s):
+        cat, cw, sw = ctx.saved_tensors
+        n_s, LAT, LON = ctx.geom
+        C = cat.shape[1] // 2
+        dy_u, dy_s = ops.patch_recover_gather_bwd(d_out.contiguous(), d_out_s.contiguous())
+        dcw, dcb = ops.linear_wgrad(dy_u, cat[n_s:])
+        dsw, dsb = ops.linear_wgrad(dy_s, cat[:n_s])
+        wt_s, wt_u = _wt(sw), _wt(cw)                                      # (2C, 64), (2C, 160): rows = input channels
+        d_skip = torch.empty((cat.shape[0], C), dtype=torch.float32, device=cat.device)
+        d_x = torch.empty_like(d_skip)
+        for dst, rows in ((d_skip, slice(0, C)), (d_x, slice(C, 2 * C))):
+            ops.linear(dy_s, wt_s[rows], out=dst[:n_s])
+            ops.linear(dy_u, wt_u[rows], out=dst[n_s:])
+        return d_skip, d_x, dcw.reshape(cw.shape), dcb, dsw.reshape(sw.shape), dsb, None

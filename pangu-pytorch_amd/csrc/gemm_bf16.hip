@@ -408,8 +408,12 @@ extern "C" int pangu_linear_gelu_bwd_bf16(pangu_stream_t stream, const void* A, 
   if (!pangu_fits_u32(M, lda, 2) || !pangu_fits_u32(M, ldc, 2) || !pangu_fits_u32(M, N, 2)) return PANGU_E_RANGE;
   hipStream_t s = (hipStream_t)stream;
   const int act = h ? PANGU_ACT_GELU_BWD_H : PANGU_ACT_GELU_BWD;
-  static const bool allow_ws = !(getenv("PANGU_BF16_WS") && atoi(getenv("PANGU_BF16_WS")) == 0);
-  if (allow_ws && M >= 4096) {
+  // K <= 192: the weights-stationary kernel re-reads dm once per 192-column slice (4x at N = 768) next to the pre-activation
+  // read and the dpre / h writes; measured (tools/bench_kernels.py mlp_train, MI355X) the tiled LDS-DMA kernel is 7-13 % ahead
+  // on this epilogue (0.677 vs 0.729 ms with h, 0.479 vs 0.553 without), so it is the default; PANGU_BF16_WS_GELU_BWD=1 = the
+  // weights-stationary kernel
+  static const bool ws_bwd = getenv("PANGU_BF16_WS_GELU_BWD") && atoi(getenv("PANGU_BF16_WS_GELU_BWD")) == 1;
+  if (ws_bwd && M >= 4096) {
     const int rc = pangu_linear_ws_bf16(s, A, lda, W, nullptr, dpre, ldc, M, N, K, act, const_cast<void*>(pre), 0, h);
     if (rc != PANGU_E_SHAPE) return rc;
   }
@@ -434,7 +438,8 @@ extern "C" int pangu_linear_fwd_bf16(pangu_stream_t stream, const void* A, int l
   hipStream_t s = (hipStream_t)stream;
   // K <= 384: weights-stationary barrier-free kernel (PANGU_BF16_WS=0 disables it: A/B knob)
   static const bool allow_ws = !(getenv("PANGU_BF16_WS") && atoi(getenv("PANGU_BF16_WS")) == 0);
-  if (allow_ws && M >= 4096 && act != PANGU_ACT_ADD) {
+  static const bool ws_bwd = getenv("PANGU_BF16_WS_GELU_BWD") && atoi(getenv("PANGU_BF16_WS_GELU_BWD")) == 1;
+  if (allow_ws && M >= 4096 && act != PANGU_ACT_ADD && (act != PANGU_ACT_GELU_BWD || ws_bwd)) {      // GELU_BWD: see pangu_linear_gelu_bwd_bf16
     const int rc = pangu_linear_ws_bf16(s, A, lda, W, bias, C, ldc, M, N, K, act, aux, out_dtype == PANGU_F32);
     if (rc != PANGU_E_SHAPE) return rc;
   }

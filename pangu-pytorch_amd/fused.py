@@ -8,7 +8,7 @@ import os
 import torch
 
 from . import ops
-from .autograd import DownSampleFn, EarthBlockFn, PatchEmbedFn, PatchRecoverFn, UpSampleFn
+from .autograd import DownSampleFn, EarthBlockFn, PatchEmbedFn, PatchRecoverFn, PatchRecoverHalvesFn, UpSampleFn
 
 
 def _train_path(module, *tensors):
@@ -27,7 +27,8 @@ def _samples(x):
     into the graph (a zero fill + a copy of the whole activation per layer in backward: 2.8 ms of the fp32 step); the
     B = 1 case is a pure view, B > 1 goes through one unbind."""
     if x.shape[0] == 1:
-        return [x.reshape(x.shape[1:]).contiguous()]
+        t = x.reshape(x.shape[1:])
+        return [t if t.stride(-1) == 1 and t.dim() == 2 else t.contiguous()]      # row-strided rows are fine for every kernel
     return [t.contiguous() for t in x.unbind(0)]
 
 
@@ -54,6 +55,9 @@ def earth_block(blk, x, Z, H, W, roll, out=None):
     dp = blk.drop_path
     if _train_path(blk, x):
         outs = []
+        # out as a 2-D (N, C) row-strided tensor (B = 1): the block function writes its result there (a half of the
+        # skip-concat buffer, PanguModel._forward_f32) -- no copy
+        direct = out is not None and out.dim() == 2 and B == 1
         for xb in _samples(x):
             s1 = dp.sample_scale(blk.training) if hasattr(dp, "sample_scale") else 1.0
             s2 = dp.sample_scale(blk.training) if hasattr(dp, "sample_scale") else 1.0
@@ -61,9 +65,9 @@ def earth_block(blk, x, Z, H, W, roll, out=None):
                 xb, blk.norm1.weight, blk.norm1.bias, blk.norm2.weight, blk.norm2.bias,
                 blk.linear.linear1.weight, blk.linear.linear1.bias, blk.linear.linear2.weight, blk.linear.linear2.bias,
                 att.earth_specific_bias, att.linear1.weight, att.linear1.bias, att.linear2.weight, att.linear2.bias,
-                (Z, H, W, att.head_number, bool(roll)), s1, s2))
+                (Z, H, W, att.head_number, bool(roll)), s1, s2, (out,) if direct else None))
         y = _stack(outs, B)
-        if out is not None:
+        if out is not None and not direct:
             out.copy_(y)
             return out
         return y
@@ -164,6 +168,14 @@ def up_sample(m, x, Z, H2, W2, H, out=None):
         g = ops.upsample_ln(y[b * N:(b + 1) * N], m.norm.weight, m.norm.bias, Z, H2, W2, H)
         ops.linear(g, m.linear2.weight, out=_tok2d(out[b:b + 1]))
     return out
+
+
+def patch_recover_halves(m, skip, x, Z, H, W, LAT=721, LON=1440):
+    """Training path, B = 1: reference layers.py:511-545 on cat(skip, x) where skip / x (1, N, C) are the two halves of one
+    (N, 2C) buffer (PanguModel._forward_f32)."""
+    o, os_ = PatchRecoverHalvesFn.apply(skip[0], x[0], m.conv.weight, m.conv.bias, m.conv_surface.weight, m.conv_surface.bias,
+                                        (H * W, LAT, LON))
+    return o.unsqueeze(0), os_.unsqueeze(0)
 
 
 def patch_recover(m, x, Z, H, W, LAT=721, LON=1440):

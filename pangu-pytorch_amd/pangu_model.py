@@ -181,8 +181,23 @@ class PanguModel(nn.Module):
         N, C = x.shape[1], x.shape[2]
         # skip connection: layer 0 writes its result into the left half, layer 3 into the right half of one
         # (B,N,2C) buffer, so the channel concat of reference pangu_model.py:81 costs no copy
+        if grad_path and B == 1:
+            # autograd path, one sample: layer 0 / layer 3 write straight into the two halves of one (N, 2C) buffer, given
+            # to autograd as tensors that SHARE its storage without being views of it (a view returned by a custom Function
+            # whose base is written again -- the other half -- is refused)
+            from . import fused
+            cat = torch.empty((N, 2 * C), dtype=x.dtype, device=x.device)
+            halves = [torch.empty(0, dtype=x.dtype, device=x.device).set_(cat.untyped_storage(), off, (N, C), (2 * C, 1))
+                      for off in (0, C)]
+            skip = self.layers[0](x, 8, 181, 360, out=halves[0])
+            x = self.downsample(skip, 8, 181, 360)
+            x = self.layers[1](x, 8, 91, 180)
+            x = self.layers[2](x, 8, 91, 180)
+            x = self.upsample(x)
+            x = self.layers[3](x, 8, 181, 360, out=halves[1])
+            return fused.patch_recover_halves(self._output_layer, skip, x, 8, 181, 360)
         if grad_path:
-            skip = self.layers[0](x, 8, 181, 360)                 # autograd path: plain concat
+            skip = self.layers[0](x, 8, 181, 360)                 # autograd path, B > 1: plain concat
             x = self.downsample(skip, 8, 181, 360)
             x = self.layers[1](x, 8, 91, 180)
             x = self.layers[2](x, 8, 91, 180)

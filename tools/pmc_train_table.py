@@ -40,14 +40,26 @@ def durations(d):
     return tot, cnt
 
 
-def step_totals(root, steps):
-    """Whole-step HBM bytes: every kernel of the traced command (warm-up steps included in `steps`), FETCH_SIZE x2 + WRITE_SIZE."""
+def _totals(root):
     rd, _ = counters(os.path.join(root, "p1"))
     wr, _ = counters(os.path.join(root, "p2"))
-    r = sum(2.0 * v.get("FETCH_SIZE", 0.0) * 1024 for v in rd.values())
-    w = sum(v.get("WRITE_SIZE", 0.0) * 1024 for v in wr.values())
-    return {"hbm_read_bytes_per_step": r / steps, "hbm_write_bytes_per_step": w / steps, "hbm_bytes_per_step": (r + w) / steps,
-            "steps_in_trace": steps}
+    return (sum(2.0 * v.get("FETCH_SIZE", 0.0) * 1024 for v in rd.values()),
+            sum(v.get("WRITE_SIZE", 0.0) * 1024 for v in wr.values()))
+
+
+def step_totals(root, steps):
+    """Whole-step HBM bytes (FETCH_SIZE x2 + WRITE_SIZE over every kernel).  `root` holds the passes of `profile_train.py <dt>
+    <steps> 1`; when `root`_w0 exists (the passes of `profile_train.py <dt> 0 1`: model construction, weight init, the warm-up
+    step with Adam's state allocation) it is SUBTRACTED, so the figure is the steady-state step alone; without it the warm-up
+    step counts as one more step (init kernels included: a few GB too many per step)."""
+    r, w = _totals(root)
+    if os.path.isdir(root + "_w0"):
+        r0, w0 = _totals(root + "_w0")
+        r, w, n, how = r - r0, w - w0, steps, "steady-state steps only (warm-up + init trace subtracted)"
+    else:
+        n, how = steps + 1, "warm-up step and init kernels included"
+    return {"hbm_read_bytes_per_step": r / n, "hbm_write_bytes_per_step": w / n, "hbm_bytes_per_step": (r + w) / n,
+            "steps_in_trace": n, "accounting": how}
 
 
 def write_json(path, roots):

@@ -26,8 +26,12 @@ for DT in f32 bf16; do
   timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/p2 -- python3 tools/profile_train.py $DT 2 1 > $P/p2.log 2>&1
   timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $P/p3 -- python3 tools/profile_train.py $DT 2 1 > $P/p3.log 2>&1
   { echo "## $DT training step"; python3 tools/pmc_train_table.py $P; } >> gpurun_out/${TAG}_train_pmc_table.md 2>> gpurun_out/${TAG}_train_pmc_table.err
+  # the same command with ZERO measured steps (model construction + init + the warm-up step): subtracted from the byte totals
+  mkdir -p ${P}_w0
+  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d ${P}_w0/p1 -- python3 tools/profile_train.py $DT 0 1 > ${P}_w0/p1.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d ${P}_w0/p2 -- python3 tools/profile_train.py $DT 0 1 > ${P}_w0/p2.log 2>&1
 done
-python3 tools/pmc_train_table.py --json gpurun_out/pmc_train.json /tmp/trpmc_f32 /tmp/trpmc_bf16 3 && cp gpurun_out/pmc_train.json profiles/
+python3 tools/pmc_train_table.py --json gpurun_out/pmc_train.json /tmp/trpmc_f32 /tmp/trpmc_bf16 2 && cp gpurun_out/pmc_train.json profiles/
 {
   echo "## attn_qkv_bf16 with PANGU_ATTN_QKV_X=1 (rows register-resident, one workgroup per window: C = 192 only)"
   PANGU_ATTN_QKV_X=1 timeout 400 python3 tools/bench_kernels.py attn_qkv_bf16 2>&1 | grep -v "amdgpu.ids"

@@ -38,6 +38,9 @@ for dt in ([torch.float32, torch.bfloat16] if which == "both" else [torch.bfloat
         host += time.perf_counter() - h0
     b.record()
     torch.cuda.synchronize()
+    if steps == 0:
+        print("warm-up only")
+        continue
     wall = (time.perf_counter() - t0) / steps * 1e3
     print(f"{'bf16' if dt == torch.bfloat16 else 'f32'} train: wall {wall:.2f} ms/step, GPU (events) {a.elapsed_time(b) / steps:.2f} ms/step, "
           f"host time spent issuing a step {host / steps * 1e3:.2f} ms, loss {float(loss):.4f}")
