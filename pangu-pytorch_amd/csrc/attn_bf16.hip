@@ -537,6 +537,173 @@ __global__ __launch_bounds__(192, 2) void window_attn_qkv_bf16_kernel(const u16*
 }
 
 
+// ---- QKV projection fused in, HG heads of a window per workgroup (round 3) -----------------------------------------------
+// window_attn_qkvg_bf16_kernel: the (window, head) kernel above with HG heads of ONE window in a workgroup of 3 HG waves
+// (wave = (head of the group, token-tile triple): the per-wave code is unchanged).  What changes is the K-step's traffic:
+// the window's x slice (9 KB of a step's 15) is requested ONCE for the HG heads instead of once per head -- 33 KB instead
+// of 60 KB per step and four heads at C = 384 (HG = 4, twelve waves, one workgroup per CU), 21 instead of 30 KB per two
+// heads at C = 192 (HG = 2, two workgroups per CU): the same twelve waves per CU as before, and the K-loop runs at the
+// rate the CU's L2 -> LDS path delivers (73 GB/s per CU measured), so fewer bytes are what shortens it.
+template <bool SHIFTED, int C, int HG>
+__global__ __launch_bounds__(192 * HG, 3) void window_attn_qkvg_bf16_kernel(const u16* __restrict__ x, int ldx,
+                                                                            const u16* __restrict__ wqkv,
+                                                                            const float* __restrict__ bqkv,
+                                                                            const u16* __restrict__ esb, u16* __restrict__ out,
+                                                                            float* __restrict__ lse, WinGeom g, int n_tok,
+                                                                            int heads) {
+  constexpr int KS = C / 32;
+  constexpr int ROWS = PANGU_WTOK + 96 * HG;         // rows of one ring slot: 144 x rows, then HG x (q | k | v) weight rows
+  constexpr int SLOT = ROWS * 64;
+  constexpr int NW = 3 * HG;                         // waves
+  constexpr int NI = ROWS / 16;                      // 1-KB LDS-DMA instructions per step (16 rows of 64 B each)
+  constexpr int NIW = (NI + NW - 1) / NW;            // ... per wave (the last round is partial)
+  constexpr int NIX = PANGU_WTOK / 16;               // the first 9 instructions carry x rows
+  constexpr int IMG = PANGU_WTOK * 64 + 32 * VT_LD;  // one head's K + V^T images
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const ring = smem;                  // 2 slots; the HG image pairs reuse the memory behind the K-loop
+
+  // blocks b, b+8, .. share an XCD: the head groups of a window back to back (x leaves HBM once), then the next longitude
+  // window of the same type (its bias tiles stay in that L2)
+  const int ng = heads / HG;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, local = b >> 3;
+  const int hg = local % ng, wl = local / ng;
+  const int l = wl % g.nLon;
+  const int t = (wl / g.nLon) * 8 + xcd;
+  if (t >= g.types) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hsub = wave / 3, wt = wave - 3 * hsub;
+  const int hd = hg * HG + hsub;
+  const int lq = lane & 15, lg = lane >> 4;
+  const int tile0 = 3 * wt;
+  unsigned char* const Ks = smem + hsub * IMG;
+  unsigned char* const Vt = Ks + PANGU_WTOK * 64;
+  const u16* bias_tile = esb + (size_t)(t * heads + hd) * PANGU_WTOK * PANGU_WTOK;
+
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<u16*>(x), 0, (int)(((size_t)(n_tok - 1) * ldx + C) * sizeof(u16)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<u16*>(wqkv), 0, 3 * C * C * (int)sizeof(u16), 0x00020000);
+
+  // ---- LDS-DMA plan: instruction q covers slot rows 16q .. 16q+15; wave w issues q = w, w + NW, ..; this lane fills
+  // (row 16q + lane / 4, physical chunk lane & 3) with the logical chunk (lane & 3) ^ F(row), F = {0,2,3,1}[(row >> 2) & 3]
+  auto fsw = [](int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; };
+  unsigned voff[NIW];
+#pragma unroll
+  for (int i = 0; i < NIW; ++i) {
+    const int q = wave + NW * i;
+    const int row = 16 * q + (lane >> 2);
+    const int c = (lane & 3) ^ fsw(row);
+    if (q < NIX) {
+      const int tok = win_src_token(g, l, t, row, SHIFTED);
+      voff[i] = tok >= 0 ? ((unsigned)tok * (unsigned)ldx + c * 8) * 2u : 0x7FFFFFF0u;       // pad row: out of range -> zeros
+    } else {
+      const int r = row - PANGU_WTOK, hsel = r / 96, rr = r - 96 * hsel, which = rr >> 5, d = rr & 31;
+      voff[i] = ((unsigned)(which * C + (hg * HG + hsel) * 32 + d) * (unsigned)C + c * 8) * 2u;
+    }
+  }
+  auto issue = [&](int ks) {
+    unsigned char* base = ring + (ks & 1) * SLOT;
+#pragma unroll
+    for (int i = 0; i < NIW; ++i) {
+      const int q = wave + NW * i;
+      if (q < NI) {                                          // wave-uniform
+        auto dst = (__attribute__((address_space(3))) void*)(base + q * 1024);
+        if (q < NIX) __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, dst, 16, (int)voff[i], ks * 64, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, dst, 16, (int)voff[i], ks * 64, 0, 0);
+      }
+    }
+  };
+  issue(0);
+
+  int qtok[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) qtok[i] = win_src_token(g, l, t, (tile0 + i) * 16 + lq, SHIFTED);
+
+  f32x4 acc[6][3];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bqkv + (rt >> 1) * C + hd * 32 + (rt & 1) * 16 + 4 * lg);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[rt][i] = bv;
+  }
+#pragma unroll
+  for (int rt = 4; rt < 6; ++rt) {
+    const float bv = bqkv[2 * C + hd * 32 + (rt - 4) * 16 + lq];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[rt][i] = f32x4{bv, bv, bv, bv};
+  }
+
+  for (int ks = 0; ks < KS; ++ks) {
+    wait_vmcnt<0>();                                         // step ks landed (this wave's pieces)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // no fragment read of the slot re-requested below is still queued
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                            // ... for every wave; the slot of step ks-1 is free
+    asm volatile("" ::: "memory");
+    if (ks + 1 < KS) issue(ks + 1);
+    const unsigned char* slot = ring + (ks & 1) * SLOT;
+    bf16x8 fx[3], fw[6];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int row = (tile0 + i) * 16 + lq;
+      fx[i] = *reinterpret_cast<const bf16x8*>(slot + row * 64 + ((lg ^ fsw(row)) << 4));
+    }
+#pragma unroll
+    for (int rt = 0; rt < 6; ++rt) {
+      const int row = PANGU_WTOK + hsub * 96 + rt * 16 + lq;
+      fw[rt] = *reinterpret_cast<const bf16x8*>(slot + row * 64 + ((lg ^ fsw(row)) << 4));
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) acc[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[rt], fx[i], acc[rt][i], 0, 0, 0);
+#pragma unroll
+      for (int rt = 4; rt < 6; ++rt) acc[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[i], fw[rt], acc[rt][i], 0, 0, 0);
+    }
+  }
+
+  // ---- q fragments (registers), K image and V^T image of this wave's head (over the ring: every wave is done reading it)
+  BiasRow b0 = load_bias_row(bias_tile, tile0 * 16 + lq, lg);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  bf16x8 qf[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    qf[i] = __builtin_bit_cast(bf16x8, u32x4{pack2(acc[0][i][0], acc[0][i][1]), pack2(acc[0][i][2], acc[0][i][3]),
+                                             pack2(acc[1][i][0], acc[1][i][1]), pack2(acc[1][i][2], acc[1][i][3])});
+    const int n = (tile0 + i) * 16 + lq;
+    *reinterpret_cast<u32x4*>(Ks + kswz(n, lg)) = u32x4{pack2(acc[2][i][0], acc[2][i][1]), pack2(acc[2][i][2], acc[2][i][3]),
+                                                        pack2(acc[3][i][0], acc[3][i][1]), pack2(acc[3][i][2], acc[3][i][3])};
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+      *reinterpret_cast<u32x2*>(Vt + (dt * 16 + lq) * VT_LD + ((tile0 + i) * 16 + 4 * lg) * 2) =
+          u32x2{pack2(acc[4 + dt][i][0], acc[4 + dt][i][1]), pack2(acc[4 + dt][i][2], acc[4 + dt][i][3])};
+  }
+  bool zcut = false, hcut = false;
+  unsigned long long kz_bits = 0ull, kh_bits = 0ull;
+  if (SHIFTED) {
+    const int zwin = t / g.nHw, hwin = t - zwin * g.nHw;
+    zcut = zwin == g.nZw - 1;
+    hcut = hwin == g.nHw - 1;
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kn = key_of(j, lg * 4 + r);
+        if (kn >= 72) kz_bits |= 1ull << (4 * j + r);
+        if (((kn / 12) % 6) < 3) kh_bits |= 1ull << (4 * j + r);
+      }
+  }
+  __syncthreads();
+  const BiasRow b1 = load_bias_row(bias_tile, (tile0 + 1) * 16 + lq, lg);
+  attn_tile<SHIFTED>(Ks, Vt, qf[0], b0, tile0 * 16 + lq, qtok[0], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
+  b0 = load_bias_row(bias_tile, (tile0 + 2) * 16 + lq, lg);
+  attn_tile<SHIFTED>(Ks, Vt, qf[1], b1, (tile0 + 1) * 16 + lq, qtok[1], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
+  attn_tile<SHIFTED>(Ks, Vt, qf[2], b0, (tile0 + 2) * 16 + lq, qtok[2], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
+}
+
 // ---- QKV projection fused in, input rows REGISTER-resident (round 3) ---------------------------------------------------
 // window_attn_qkvx_bf16_kernel: ONE workgroup per window walks ALL heads.  In the kernel above every (window, head)
 // workgroup re-fetches the window's 144 input rows (9 of the 15 KB of each K-step); the K-loop runs at the rate the CU's
@@ -734,6 +901,32 @@ static int launch_attn_qkv(pangu_stream_t stream, const void* x, int ldx, const 
   const int grid = ((g.types + 7) / 8) * 8 * g.nLon * heads;
   // A/B knob PANGU_ATTN_QKV_MODE = <ring><bk/32>: 21 (default) ring of 2 x 32 channels, four workgroups per CU; 31 ring of 3;
   // 12 one slot of 64 channels (half the steps); 22 ring of 2 x 64 channels (two workgroups per CU)
+  // PANGU_ATTN_QKV_HG=1: HG heads of a window per workgroup (4 at C = 384, 2 at C = 192: the x slice of a K-step requested
+  // once for all of them, 45 % / 30 % fewer L2 -> LDS bytes at the same twelve waves per CU).  Built and parity-tested in
+  // round 3, NOT the default: 0.247 / 0.267 ms against 0.222 / 0.242 ms at C = 384 and 0.463 / 0.481 against 0.372 / 0.352 at
+  // C = 192 (MI355X, interleaved runs) -- one barrier per K-step now couples twelve (six) waves instead of three, and the
+  // skew it adds costs more than the bytes save: the small independent (window, head) workgroups ARE the latency cover.
+  static const int hgmode = getenv("PANGU_ATTN_QKV_HG") ? atoi(getenv("PANGU_ATTN_QKV_HG")) : 0;
+  if (hgmode && !qkv_out) {
+    hipStream_t sg = (hipStream_t)stream;
+#define PANGU_QG_LAUNCH(SH, CC, HGG)                                                                                      \
+  do {                                                                                                                    \
+    constexpr size_t slot_b = (size_t)(PANGU_WTOK + 96 * HGG) * 64, img_b = (size_t)HGG * (PANGU_WTOK * 64 + 32 * VT_LD); \
+    constexpr size_t shm_g = 2 * slot_b > img_b ? 2 * slot_b : img_b;                                                     \
+    auto kern = window_attn_qkvg_bf16_kernel<SH, CC, HGG>;                                                                \
+    PANGU_ENSURE_DYN_LDS(kern, shm_g);                                                                                    \
+    const int grid_g = ((g.types + 7) / 8) * 8 * g.nLon * (heads / HGG);                                                  \
+    hipLaunchKernelGGL(kern, dim3(grid_g), dim3(192 * HGG), shm_g, sg, (const u16*)x, ldx, (const u16*)w_qkv, b_qkv,      \
+                       (const u16*)esb, (u16*)out, lse, g, n_tok, heads);                                                 \
+  } while (0)
+    if (C == 384) {
+      if (shifted) PANGU_QG_LAUNCH(true, 384, 4); else PANGU_QG_LAUNCH(false, 384, 4);
+    } else {
+      if (shifted) PANGU_QG_LAUNCH(true, 192, 2); else PANGU_QG_LAUNCH(false, 192, 2);
+    }
+#undef PANGU_QG_LAUNCH
+    return pangu_launch_status();
+  }
   // PANGU_ATTN_QKV_X=1: the register-resident-rows kernel (one workgroup per window, all heads; ring of 3 weight slots).
   // Built and parity-tested in round 3, NOT the default: 0.384-0.396 ms against 0.347-0.370 ms of the (window, head) kernel at
   // C = 192 (MI355X, interleaved) although it moves 2.5x fewer bytes through the L2 -> LDS path -- 250 registers leave two
