@@ -24,6 +24,41 @@ _TRAIN_MLP = int(os.environ.get("PANGU_BF16_TRAIN_MLP", "1"))
 _TRAIN_QKV = int(os.environ.get("PANGU_BF16_TRAIN_QKV", "0"))
 
 
+# Weight gradients of a block on a SECOND stream (A/B knob PANGU_BF16_WGRAD_STREAM=1): they are off the backward's critical path
+# (dx chain), and neither they nor the data-gradient GEMMs saturate HBM or the matrix cores on their own (3.5-4 TB/s, MFMA-busy
+# 0.2-0.35), so letting the two kinds of launches share the chip can cover part of each other's latency.  Ordering: an event
+# after the producers on the main stream, a join (main waits for the side stream) before the block's gradients are returned;
+# operands are kept alive until the join; the two-stage weight-gradient workspace is per (device, stream).
+_WGRAD_STREAM = int(os.environ.get("PANGU_BF16_WGRAD_STREAM", "0"))
+_side_streams = {}
+
+
+class _WgradLane:
+    def __init__(self, device):
+        self.on = bool(_WGRAD_STREAM)
+        if self.on:
+            self.main = torch.cuda.current_stream(device)
+            self.side = _side_streams.get(device)
+            if self.side is None:
+                self.side = _side_streams[device] = torch.cuda.Stream(device)
+            self.keep = []
+
+    def wgrad(self, dc, a, want_bias=True):
+        if not self.on:
+            return ob.linear_wgrad(dc, a, want_bias)
+        ev = torch.cuda.Event()
+        ev.record(self.main)                    # dc, a (and the zero arena's fill) are ordered before this point
+        self.side.wait_event(ev)
+        self.keep += [dc, a]
+        with torch.cuda.stream(self.side):
+            return ob.linear_wgrad(dc, a, want_bias)
+
+    def join(self):
+        if self.on:
+            self.main.wait_stream(self.side)
+            self.keep.clear()
+
+
 def _mlp_mode(C):
     if C not in (192, 384) or _TRAIN_MLP == 0 or (_TRAIN_MLP == 2 and C != 384):
         return 0
@@ -88,6 +123,8 @@ class EarthBlockFnBF16(torch.autograd.Function):
             qkv, o, lse, y = rest[:4]
             rest = rest[4:]
         g = {k: None for k in ("n1w", "n1b", "n2w", "n2b", "m1w", "m1b", "m2w", "m2b", "esb", "a1w", "a1b", "a2w", "a2b")}
+        lane = _WgradLane(dout.device)
+        dqb_pad = None
         dx1 = dout
         if s2 != 0.0:
             mode = ctx.mlp_mode
@@ -104,9 +141,9 @@ class EarthBlockFnBF16(torch.autograd.Function):
                 dpre, h = ob.linear_gelu_bwd(dm, sh.get_t(m2w), pre)
             else:
                 dpre = ob.linear(dm, sh.get_t(m2w), None, act=ob.ACT_GELU_BWD, aux=pre)
-            g["m2w"], g["m2b"] = ob.linear_wgrad(dm, h)
+            g["m2w"], g["m2b"] = lane.wgrad(dm, h)
             del dm, h
-            g["m1w"], g["m1b"] = ob.linear_wgrad(dpre, x1)
+            g["m1w"], g["m1b"] = lane.wgrad(dpre, x1)
             if dout.is_contiguous():      # residual gradient added in the GEMM epilogue (no extra pass over N x C)
                 dx1 = ob.linear(dpre, sh.get_t(m1w), act=ob.ACT_ADD, aux=dout)
             else:
@@ -116,15 +153,14 @@ class EarthBlockFnBF16(torch.autograd.Function):
         dx = dx1
         if s1 != 0.0:
             dy, g["n1w"], g["n1b"] = ob.ln_residual_bwd(dx1, y, n1w, s1)
-            g["a2w"], g["a2b"] = ob.linear_wgrad(dy, o)
+            g["a2w"], g["a2b"] = lane.wgrad(dy, o)
             do = ob.linear(dy, sh.get_t(a2w))
             del dy
             dqkv, dqb_pad, desb = ob.window_attention_bwd(qkv, sh.get(a1b), sh.get(esb), o, lse, do, Z, H, W, heads, shifted,
                                                           desb_out=ops.grad_slot(esb))       # straight into the DP flat buffer
             del do
             g["esb"] = desb.unsqueeze(0)
-            g["a1w"], g["a1b"] = ob.linear_wgrad(dqkv, x)
-            g["a1b"] += dqb_pad
+            g["a1w"], g["a1b"] = lane.wgrad(dqkv, x)
             if dx1.is_contiguous():
                 dx = ob.linear(dqkv, sh.get_t(a1w), act=ob.ACT_ADD, aux=dx1)
             else:
@@ -132,6 +168,9 @@ class EarthBlockFnBF16(torch.autograd.Function):
                 dx += dx1
         elif not dx.is_contiguous():
             dx = dx.contiguous()
+        lane.join()
+        if dqb_pad is not None:
+            g["a1b"] += dqb_pad
         return (dx, g["n1w"], g["n1b"], g["n2w"], g["n2b"], g["m1w"], g["m1b"], g["m2w"], g["m2b"], g["esb"],
                 g["a1w"], g["a1b"], g["a2w"], g["a2b"], None, None, None, None, None)
 
