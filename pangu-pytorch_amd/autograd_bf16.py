@@ -318,7 +318,7 @@ def forward_train(model, inp, inp_surface, statistics, maps, const_h):
         cat = torch.empty((Nn, 2 * Cc), dtype=torch.bfloat16, device=dev)
         # the two halves as tensors that SHARE cat's storage without being autograd views of it (a view returned by a custom
         # Function whose base is written again -- the other half -- is refused by autograd)
-        halves = [torch.empty(0, dtype=torch.bfloat16, device=dev).set_(cat.untyped_storage(), off, (Nn, Cc), (2 * Cc, 1))
+        halves = [torch.empty(0, dtype=torch.bfloat16, device=dev).set_(cat.untyped_storage(), cat.storage_offset() + off, (Nn, Cc), (2 * Cc, 1))
                   for off in (0, Cc)]
         skip = run_layer(model.layers[0], x, 8, H4, W4, out=halves[0])
         x = DownSampleFnBF16.apply(skip, dn.linear.weight, dn.norm.weight, dn.norm.bias, (8, H4, W4), sh)

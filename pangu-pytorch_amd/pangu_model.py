@@ -187,7 +187,7 @@ class PanguModel(nn.Module):
             # whose base is written again -- the other half -- is refused)
             from . import fused
             cat = torch.empty((N, 2 * C), dtype=x.dtype, device=x.device)
-            halves = [torch.empty(0, dtype=x.dtype, device=x.device).set_(cat.untyped_storage(), off, (N, C), (2 * C, 1))
+            halves = [torch.empty(0, dtype=x.dtype, device=x.device).set_(cat.untyped_storage(), cat.storage_offset() + off, (N, C), (2 * C, 1))
                       for off in (0, C)]
             skip = self.layers[0](x, 8, 181, 360, out=halves[0])
             x = self.downsample(skip, 8, 181, 360)
