@@ -109,13 +109,13 @@ __global__ __launch_bounds__(256) void ln_residual_bwd_kernel(const T* __restric
 // bf16 fast path of the post-norm residual backward for C % 8 == 0, C <= 512 (the model's 192 / 384): 16-B loads (8 channels
 // per lane), LPR lanes per row (32 -> two rows per wave at C <= 256), gamma and the dgamma/dbeta accumulators in registers,
 // both inputs of two row groups requested together before any arithmetic, persistent grid.  Same math as row_ln_bwd.
-template <int LPR>
+template <int LPR, int UNR>
 __global__ __launch_bounds__(256) void ln_residual_bwd_bf16_v8_kernel(const u16* __restrict__ dout, int lddo,
                                                                       const u16* __restrict__ yin,
                                                                       const float* __restrict__ gamma, u16* __restrict__ dy,
                                                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                       int N, int C, float branch_scale) {
-  constexpr int RPW = 64 / LPR, UNR = 2, GROUPS = 4 * RPW;
+  constexpr int RPW = 64 / LPR, GROUPS = 4 * RPW;      // UNR row groups in flight per wave (each row is a chain of 3 cross-lane reductions)
   __shared__ float red[2 * GROUPS * (LPR * 8)];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, l = lane % LPR;
@@ -390,15 +390,19 @@ extern "C" int pangu_ln_residual_bwd_bf16(pangu_stream_t stream, const void* dou
   hipStream_t s = (hipStream_t)stream;
   dim3 g(row_grid(N)), b(256);
   if ((C & 7) == 0 && C <= 512 && (lddo & 7) == 0) {
+    static const int unr = getenv("PANGU_LN_BWD_UNR") ? atoi(getenv("PANGU_LN_BWD_UNR")) : 2;      // A/B knob: 2 or 4 row groups in flight
+#define PANGU_LNB(LPR_, UNR_)                                                                                              \
+  do {                                                                                                                    \
+    const int rpb = 4 * (64 / LPR_) * UNR_, blocks = (N + rpb - 1) / rpb;                                                 \
+    hipLaunchKernelGGL((ln_residual_bwd_bf16_v8_kernel<LPR_, UNR_>), dim3(blocks < 2048 ? blocks : 2048), b, 0, s,        \
+                       (const u16*)dout, lddo, (const u16*)y, gamma, (u16*)dy, dgamma, dbeta, N, C, branch_scale);        \
+  } while (0)
     if (C <= 256) {
-      const int blocks = (N + 15) / 16;
-      hipLaunchKernelGGL(ln_residual_bwd_bf16_v8_kernel<32>, dim3(blocks < 2048 ? blocks : 2048), b, 0, s, (const u16*)dout,
-                         lddo, (const u16*)y, gamma, (u16*)dy, dgamma, dbeta, N, C, branch_scale);
+      if (unr == 4) PANGU_LNB(32, 4); else PANGU_LNB(32, 2);
     } else {
-      const int blocks = (N + 7) / 8;
-      hipLaunchKernelGGL(ln_residual_bwd_bf16_v8_kernel<64>, dim3(blocks < 2048 ? blocks : 2048), b, 0, s, (const u16*)dout,
-                         lddo, (const u16*)y, gamma, (u16*)dy, dgamma, dbeta, N, C, branch_scale);
+      if (unr == 4) PANGU_LNB(64, 4); else PANGU_LNB(64, 2);
     }
+#undef PANGU_LNB
     return pangu_launch_status();
   }
   PANGU_NV_DISPATCH(C, ln_residual_bwd_kernel, u16, (const u16*)dout, lddo, (const u16*)y, gamma, (u16*)dy, dgamma, dbeta, N,
