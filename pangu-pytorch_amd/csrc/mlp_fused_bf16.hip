@@ -63,6 +63,15 @@ constexpr float LN_EPS = 1e-5f;
 #ifndef PANGU_MLP_IGLP
 #define PANGU_MLP_IGLP 4        // VALU instructions placed behind each MFMA of a step (0 = leave it to the scheduler)
 #endif
+#ifndef PANGU_MLP_NT_X
+#define PANGU_MLP_NT_X 0        // cache-policy bits of the once-read activation loads (2 = nt: keep the weight image in L2): A/B in profiles/r03 notes
+#endif
+#ifndef PANGU_MLP_NT_OUT
+#define PANGU_MLP_NT_OUT 0      // ... of the result / side-output stores
+#endif
+#ifndef PANGU_MLP_NT_SIDE
+#define PANGU_MLP_NT_SIDE 0     // ... of the training side outputs (pre, m)
+#endif
 #ifndef PANGU_MLP_PRE_VARIANT
 #define PANGU_MLP_PRE_VARIANT 0 // training variant, how the pre-activation leaves: 0 = 16-B pieces via v_permlane32_swap, 1 = the same with s_nop padding (hazard probe), 2 = 8-B pieces, no exchange
 #endif
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_ln_residual_bf16_kernel(
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
       xf[ks][tt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                                                  x_rsrc, (int)((row * (unsigned)ldx + 16 * ks + 8 * lh) * 2u), 0, 0));
+                                                  x_rsrc, (int)((row * (unsigned)ldx + 16 * ks + 8 * lh) * 2u), 0, PANGU_MLP_NT_X));
   }
   // ---- b1 and the epilogue's per-channel vectors -> LDS (fp32): as global loads in the epilogue (144 per lane, each
   // waited for at its use) they cost a quarter of the kernel
@@ -230,7 +239,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_ln_residual_bf16_kernel(
 #if PANGU_MLP_PRE_VARIANT == 1
         asm volatile("s_nop 7" : "+v"(v));
 #endif
-        __builtin_amdgcn_raw_buffer_store_b128(v, p_rsrc, (int)pre_off, tt * pre_tile + (chunk * 32 + 16 * qp) * 2, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v, p_rsrc, (int)pre_off, tt * pre_tile + (chunk * 32 + 16 * qp) * 2, PANGU_MLP_NT_SIDE);
         // Write-after-read hazard the compiler does not cover (ROCm 7.2, gfx950): a 16-B buffer store reads its data
         // registers over several cycles, and hipcc pads a following VALU write of those registers (s_nop) only when the
         // store's soffset is an immediate; with soffset in an SGPR (the steady-state loop here) the GELU's first
@@ -488,7 +497,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_ln_residual_bf16_kernel(
         const int f = lane + 64 * it, row = f / CPR, chk = f - row * CPR;
         const u32x4 v = *reinterpret_cast<const u32x4*>(patch + row * PLD + chk * 16);
         const unsigned off = tok0 + row < M ? ((unsigned)(tok0 + row) * (unsigned)ldm + chk * 8) * 2u : 0xFFFFFFFFu;
-        __builtin_amdgcn_raw_buffer_store_b128(v, m_rsrc, (int)off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v, m_rsrc, (int)off, 0, PANGU_MLP_NT_SIDE);
       }
     }
     // LayerNorm statistics: four independent partial sums (a single dependent add chain stalls the lone wave on every add)
@@ -531,7 +540,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_ln_residual_bf16_kernel(
       const int f = lane + 64 * it, row = f / CPR, chk = f - row * CPR;
       const u32x4 v = *reinterpret_cast<const u32x4*>(patch + row * PLD + chk * 16);
       const unsigned off = tok0 + row < M ? ((unsigned)(tok0 + row) * (unsigned)ldo + chk * 8) * 2u : 0xFFFFFFFFu;
-      __builtin_amdgcn_raw_buffer_store_b128(v, o_rsrc, (int)off, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(v, o_rsrc, (int)off, 0, PANGU_MLP_NT_OUT);
     }
   }
 #ifdef PANGU_MLP_STAMP
