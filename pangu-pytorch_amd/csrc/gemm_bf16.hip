@@ -19,6 +19,10 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef PANGU_GELU_BWD_H_PATCH
+#define PANGU_GELU_BWD_H_PATCH 1      // the GELU-backward epilogue's h output leaves through the LDS patch as whole 16-B row segments (0: 8-B
+                                      // pieces straight from the MFMA layout; measured 0.57 vs 0.67 ms at C = 192, 0.36 vs 0.41 at C = 384)
+#endif
 constexpr int BBM = 128;
 constexpr int BBK = 64;
 
@@ -95,6 +99,7 @@ __device__ __forceinline__ void bf16_epilogue(f32x4 (&acc)[4][2 * TN], unsigned 
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
+    [[maybe_unused]] u32x2 hp[2 * TN];                                      // PANGU_GELU_BWD_H_PATCH: h of this row group, until the patch rows are free
 #pragma unroll
     for (int j = 0; j < 2 * TN; ++j) {
       const int col = wave_n0 + j * 16 + lg * 4;
@@ -120,8 +125,12 @@ __device__ __forceinline__ void bf16_epilogue(f32x4 (&acc)[4][2 * TN], unsigned 
           hh[c] = x[c] * phi_c;
           v[c] *= phi_c + x[c] * 0.3989422804014327f * __expf(-0.5f * x[c] * x[c]);
         }
+#if PANGU_GELU_BWD_H_PATCH
+        hp[j] = u32x2{pack2(hh[0], hh[1]), pack2(hh[2], hh[3])};
+#else
         const unsigned ho = col < N ? ((unsigned)(wave_m0 + i * 16 + lc) * (unsigned)N + (unsigned)col) * 2u : 0xFFFFFFFFu;
         __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(hh[0], hh[1]), pack2(hh[2], hh[3])}, h_rsrc, (int)ho, 0, 0);
+#endif
       }
       if (ACT == PANGU_ACT_ADD) {
         const u32x2 xp = *reinterpret_cast<const u32x2*>(slot);
@@ -151,6 +160,24 @@ __device__ __forceinline__ void bf16_epilogue(f32x4 (&acc)[4][2 * TN], unsigned 
         __builtin_amdgcn_raw_buffer_store_b128(v, c_rsrc, (int)off, 0, 2);
       }
     }
+#if PANGU_GELU_BWD_H_PATCH
+    if (ACT == PANGU_ACT_GELU_BWD_H) {                     // h through the same patch rows: whole 16-B row segments instead of 8-B pieces
+#pragma unroll
+      for (int j = 0; j < 2 * TN; ++j)
+        *reinterpret_cast<u32x2*>(ep + (i * 16 + lc) * EP_LD + (j * 16 + lg * 4) * 2) = hp[j];
+#pragma unroll
+      for (int it = 0; it < (16 * CPR + 63) / 64; ++it) {
+        const int f = lane + 64 * it;
+        const int row = i * 16 + f / CPR, ch = f % CPR;
+        const int col = wave_n0 + ch * 8;
+        if (f < 16 * CPR) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(ep + row * EP_LD + ch * 16);
+          const unsigned off = col < N ? ((unsigned)(wave_m0 + row) * (unsigned)N + (unsigned)col) * 2u : 0xFFFFFFFFu;
+          __builtin_amdgcn_raw_buffer_store_b128(v, h_rsrc, (int)off, 0, 0);
+        }
+      }
+    }
+#endif
   }
 }
 
@@ -420,6 +447,12 @@ extern "C" int pangu_linear_gelu_bwd_bf16(pangu_stream_t stream, const void* A, 
   const u16* a = (const u16*)A;
   const u16* w = (const u16*)W;
   u16* x = (u16*)const_cast<void*>(pre);
+  // with h the epilogue moves three (tokens x N) tensors per tile: 128 x 128 tiles (116 VGPRs, 37 KB of patches: four workgroups
+  // per CU cover its load -> gelu' -> store chain) beat 128 x 192 (three per CU): 0.53 vs 0.57 ms at C = 192, 0.34 vs 0.36 at
+  // C = 384 (tools/bench_kernels.py mlp_train); without h the two are level.  PANGU_GELU_BWD_TN=3 / 2 forces one.
+  static const int tn_forced = getenv("PANGU_GELU_BWD_TN") ? atoi(getenv("PANGU_GELU_BWD_TN")) : 0;
+  const bool tn2 = tn_forced ? tn_forced == 2 : h != nullptr;
+  if (tn2 && N % 128 == 0) return launch_bf16<2, false>(s, a, lda, w, nullptr, dpre, ldc, M, N, K, act, x, (u16*)h);
   if ((N % 192 == 0) || (N > 128 && N < 192)) return launch_bf16<3, false>(s, a, lda, w, nullptr, dpre, ldc, M, N, K, act, x, (u16*)h);
   if (N % 128 == 0) return launch_bf16<2, false>(s, a, lda, w, nullptr, dpre, ldc, M, N, K, act, x, (u16*)h);
   return launch_bf16<1, false>(s, a, lda, w, nullptr, dpre, ldc, M, N, K, act, x, (u16*)h);
@@ -446,7 +479,8 @@ extern "C" int pangu_linear_fwd_bf16(pangu_stream_t stream, const void* A, int l
   const u16* a = (const u16*)A;
   const u16* w = (const u16*)W;
   u16* x = (u16*)aux;
-  const bool wide = (N % 192 == 0) || (N > 128 && N < 192);
+  static const int tn_env = getenv("PANGU_BF16_TN") ? atoi(getenv("PANGU_BF16_TN")) : 0;      // A/B knob: 2 = 128 x 128 tiles wherever N % 128 == 0
+  const bool wide = ((N % 192 == 0) || (N > 128 && N < 192)) && !(tn_env == 2 && N % 128 == 0);
   if (out_dtype == PANGU_F32) {
     if (wide) return launch_bf16<3, true>(s, a, lda, w, bias, C, ldc, M, N, K, act, x);
     if (N % 128 == 0) return launch_bf16<2, true>(s, a, lda, w, bias, C, ldc, M, N, K, act, x);
