@@ -80,7 +80,7 @@ def earth_block(blk, x, Z, H, W, roll, out=None):
         esb_c = getattr(att, "_esb_compact", None)
         if esb_c is not None:                 # stale table (weights changed since it was folded): the expanded parameter
             p = att.earth_specific_bias
-            if getattr(att, "_esb_compact_stamp", None) != (p._version, p.data_ptr(), p.device) or esb_c.device != p.device:
+            if getattr(att, "_esb_compact_stamp", None) != ops.param_stamp(p) or esb_c.device != p.device:
                 att._esb_compact = esb_c = None
         cp = esb_c is not None
         esb = esb_c if cp else att.earth_specific_bias[0]

@@ -8,11 +8,8 @@ from . import ops, ops_bf16 as ob
 
 
 def _stamp(p):
-    """What identifies the CONTENT of a parameter as far as it can be observed cheaply: in-place updates through the
-    parameter bump `_version` (optimizer steps, `copy_` under no_grad); `param.data = w` (the reference's own import idiom,
-    models/onnx2torch.py:37-52) swaps the storage, i.e. `data_ptr()`.  In-place edits made THROUGH `param.data`
-    (`p.data.copy_(..)`, `p.data.add_(..)`) change neither: after such an edit call `model.invalidate_shadows()`."""
-    return (p._version, p.data_ptr(), tuple(p.shape), p.device)
+    """ops.param_stamp: (optimizer epoch, _version, data_ptr, shape, device)."""
+    return ops.param_stamp(p)
 
 
 class WeightShadow:

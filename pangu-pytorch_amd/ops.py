@@ -95,6 +95,37 @@ def _rows(t, name):
 
 _zero_arena = None        # [flat fp32 zeros, used elements]: see zero_arena
 
+# Derived copies of parameters (bf16 weight shadows, packed weight images, compact bias tables) are keyed by a STAMP of the
+# parameter they were made from.  `_version` alone is not enough: torch's fused optimizers (Adam(fused=True), the form
+# train.make_optimizer uses) update the parameters through one multi-tensor kernel that does NOT bump `_version` (measured on
+# torch 2.10: 0 before and after three steps), so a shadow keyed by it would stay at the first step's weights for the whole run.
+# Every torch optimizer step therefore advances a process-wide epoch that is part of every stamp (conservative: any optimizer
+# stepping anything re-makes every derived copy once).
+_weights_epoch = [0]
+
+
+def bump_weights_epoch(*_):
+    """Invalidate every derived copy of every parameter (registered below as a global optimizer post-step hook; call it
+    yourself after updating weights by other means than a torch optimizer or an op that bumps `_version`)."""
+    _weights_epoch[0] += 1
+
+
+def param_stamp(p):
+    """What identifies the CONTENT of a parameter as far as it can be observed cheaply: optimizer steps advance the epoch,
+    in-place updates through the parameter bump `_version` (`copy_` under no_grad), `param.data = w` (the reference's own import
+    idiom, models/onnx2torch.py:37-52) swaps the storage, i.e. `data_ptr()`.  In-place edits made THROUGH `param.data`
+    (`p.data.copy_(..)`) change none of them: call `model.invalidate_shadows()` or `ops.bump_weights_epoch()` after such an edit."""
+    return (_weights_epoch[0], p._version, p.data_ptr(), tuple(p.shape), p.device)
+
+
+def _install_epoch_hook():
+    import torch.optim.optimizer as _o
+    if getattr(_o, "_pangu_epoch_hook", None) is None and hasattr(_o, "register_optimizer_step_post_hook"):
+        _o._pangu_epoch_hook = _o.register_optimizer_step_post_hook(bump_weights_epoch)
+
+
+_install_epoch_hook()
+
 # Gradient slots (dist.FlatGradSync): parameter storage address -> the fp32 view of the flat gradient buffer that will hold
 # that parameter's gradient.  Backward kernels that WRITE (not accumulate) a parameter gradient -- the Earth-specific bias
 # tables, 94 % of the 1.107 GB -- store straight into the slot, so the flat buffer is filled without a copy pass.

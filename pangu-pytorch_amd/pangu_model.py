@@ -11,14 +11,14 @@ from collections import OrderedDict
 import torch
 from torch import nn
 
+from . import ops
 from .layers import (DownSample, EarthSpecificLayer, PatchEmbedding_pretrain, PatchRecovery_pretrain, UpSample,
                      _trunc_normal_)
 
 
 def compact_bias_stamp(p):
-    """What a compact bias table was derived from: an optimizer step / in-place edit bumps `_version`, `p.data = w` swaps
-    the storage.  fused.earth_block compares it at the point of use (a block called directly after a weight update)."""
-    return (p._version, p.data_ptr(), p.device)
+    """What a compact bias table was derived from (ops.param_stamp: optimizer epoch, `_version`, storage, shape, device)."""
+    return ops.param_stamp(p)
 
 
 class PanguModel(nn.Module):

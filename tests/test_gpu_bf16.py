@@ -529,6 +529,34 @@ def test_full_training_step_bf16(P):
     assert med < 0.1, med
 
 
+def test_bf16_shadows_follow_fused_adam(P):
+    """The bf16 weight shadows (and packed / transposed images) must track the fp32 master weights across optimizer steps.
+    torch's Adam(fused=True) -- train.make_optimizer's form -- does not bump `_version`, so the stamp carries an optimizer epoch
+    (ops.param_stamp): after a training step with a LARGE learning rate the forward must be bit-identical to a forward on
+    freshly rebuilt shadows, the stored shadow must equal the updated weight's bf16 image, and the output must have moved."""
+    from pangu_pytorch_amd import train
+    m = P.PanguModel(device="cuda").cuda().eval()            # eval: DropPath off, the three forwards are comparable
+    m.load_state_dict(synth.fill_state_dict(cases.model_param_shapes(), "cuda"))
+    m.set_compute_dtype(BF)
+    inp, inp_s, stats, maps, const_h = cases.model_inputs("cuda")
+    tgt, tgt_s = cases.model_targets("cuda")
+    opt = torch.optim.Adam([p for p in m.parameters()], lr=1e-3, fused=True)
+    w = m.layers[0].blocks[0].attention.linear1.weight
+    w0 = w.detach().clone()
+    with torch.no_grad():
+        before = m(inp, inp_s, stats, maps, const_h)[0].clone()
+    for _ in range(2):
+        train.train_step(m, opt, (inp, inp_s, tgt, tgt_s), stats, maps, const_h)
+    assert not torch.equal(w.detach(), w0)
+    with torch.no_grad():
+        after = m(inp, inp_s, stats, maps, const_h)[0].clone()
+        assert torch.equal(m._shadow.get(w), w.detach().to(BF))
+        m.invalidate_shadows()
+        fresh = m(inp, inp_s, stats, maps, const_h)[0]
+    assert torch.equal(after, fresh)
+    assert not torch.equal(after, before)
+
+
 def test_full_backward_smooth_bf16_vs_reference(P, golden_dir):
     """bf16 whole-model forward + backward under the smooth loss sum(out * cotangent) / numel against the REFERENCE's fp32
     autograd (tests/golden/model_bwd_smooth.npz): every one of the 223 gradient tensors, WORST tensor bounded -- gradient

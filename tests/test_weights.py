@@ -113,3 +113,20 @@ def test_compact_bias_table_roundtrip_and_refusal():
     bad[0, 2, 1, 17, 5] += 1e-3                   # one of several entries sharing an index
     assert weights.compact_bias_table(bad) is None
     assert weights.compact_bias_table(torch.randn(1, 7, 3, 144, 144, generator=g)) is None
+
+
+def test_param_stamp_changes_on_any_optimizer_step():
+    """ops.param_stamp carries a process-wide optimizer epoch: torch's fused optimizers update parameters without bumping
+    `_version`, so the derived copies (bf16 shadows, compact bias tables) are invalidated by the global post-step hook."""
+    import torch
+    from pangu_pytorch_amd import ops
+    p = torch.nn.Parameter(torch.zeros(3))
+    other = torch.nn.Parameter(torch.ones(2))
+    s0 = ops.param_stamp(p)
+    assert ops.param_stamp(p) == s0
+    other.grad = torch.ones(2)
+    torch.optim.SGD([other], lr=0.1).step()
+    s1 = ops.param_stamp(p)
+    assert s1 != s0 and s1[1:] == s0[1:]                 # only the epoch moved: p itself was not touched
+    ops.bump_weights_epoch()
+    assert ops.param_stamp(p) != s1
