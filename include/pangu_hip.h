@@ -287,6 +287,17 @@ int pangu_upsample_ln_bwd_bf16(pangu_stream_t stream, const void* dout, const vo
 int pangu_patch_recover_gather_bwd_bf16(pangu_stream_t stream, const float* d_output, const float* d_output_surface,
                                         void* dy_upper, void* dy_surface, int LAT, int LON);
 
+/* bf16 weight shadows: every bf16 derived copy of the fp32 master weights re-made by ONE launch (the bf16 paths of
+ * PanguModel compute on bf16 images of the reference's fp32 parameters -- pangu_model.py:9-48 -- which go stale at every
+ * optimizer step, finetune_fully.py:121 / pangu_sample.py:75).  `jobs`: device memory, (n_jobs + 1) rows of 8 int64:
+ *   [0] src0 (float*)  [1] src1 (float*, gather)  [2] dst (bf16*)  [3] idx (int32*, gather)  [4] n0  [5] n1  [6] mode
+ *   [7] first block of the job; row n_jobs is a sentinel whose [7] = total_blocks.
+ *   mode 0: dst[i] = bf16(src0[i]), i < n0 (4096 elements per block; src0 / dst 16-B aligned)
+ *   mode 1: dst[c][r] = bf16(src0[r][c]), r < n0, c < n1 (one 64 x 64 tile per block)
+ *   mode 2: e = idx[i]; dst[i] = bf16(e < n0 ? src0[e] : src1[e - n0]), i < n1 (4096 elements per block)
+ * Rounding: to nearest even, as torch's float32 -> bfloat16 cast. */
+int pangu_shadow_refresh_bf16(pangu_stream_t stream, const void* jobs, int n_jobs, long long total_blocks);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,7 @@ SIGNATURES = {
     "pangu_patch_embed_gather_bf16": [_P] * 11 + [_I, _I],
     "pangu_linear_wgrad_bf16": [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I],
     "pangu_linear_wgrad_bf16_ws": [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _P, _c.c_longlong],
+    "pangu_shadow_refresh_bf16": [_P, _P, _I, _c.c_longlong],
     "pangu_window_attn_bwd_bf16": [_P] * 10 + [_I] * 6,
     "pangu_ln_residual_bwd_bf16": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _F],
     "pangu_downsample_ln_bwd_bf16": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I],

@@ -140,6 +140,18 @@ def _mlp_pack_layout(w1, w2):
     return torch.stack([w1img.reshape(nch, 32 * C), w2img.reshape(nch, 32 * C)], 0).contiguous()
 
 
+_mlp_pack_index32 = {}    # (C, device) -> the same index as int32 (the job table of pangu_shadow_refresh_bf16 gathers through it)
+
+
+def mlp_pack_index32(C, device):
+    """int32 form of the pack index (built by the first pack_mlp_weights call of that (C, device))."""
+    key = (C, device)
+    i32 = _mlp_pack_index32.get(key)
+    if i32 is None:
+        i32 = _mlp_pack_index32[key] = _mlp_pack_index[key].to(torch.int32)
+    return i32
+
+
 def pack_mlp_weights(w1, w2):
     """Chunk image of an Mlp's weights for `mlp_ln_residual` (layout: csrc/mlp_fused_bf16.hip header).  w1 (4C, C), w2 (C, 4C),
     any float dtype, C in (192, 384) -> bf16 (2, 4C/32, 32*C): plane 0 = per 32 hidden units the W1 rows (16-B chunks XOR-swizzled

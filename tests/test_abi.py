@@ -54,6 +54,9 @@ def test_argument_validation_without_gpu():
     assert lib.pangu_window_attn_bwd(None, P8, P8, P8, P8, P8, P8, P8, P8, P8, 8, 181, big_w, 192, 6, 0) == -5
     assert lib.pangu_window_attn_bwd_bf16(None, P8, P8, P8, P8, P8, P8, P8, P8, P8, 8, 181, 2 * big_w, 192, 6, 0) == -5
     assert lib.pangu_error_string(-5) is not None
+    assert lib.pangu_shadow_refresh_bf16(None, None, 3, 10) == -2
+    assert lib.pangu_shadow_refresh_bf16(None, P8, 0, 10) == -1
+    assert lib.pangu_shadow_refresh_bf16(None, P8, 3, 1 << 31) == -1           # more blocks than a grid dimension holds
 
 
 @pytest.fixture(scope="module")

@@ -550,7 +550,17 @@ def test_bf16_shadows_follow_fused_adam(P):
     assert not torch.equal(w.detach(), w0)
     with torch.no_grad():
         after = m(inp, inp_s, stats, maps, const_h)[0].clone()
-        assert torch.equal(m._shadow.get(w), w.detach().to(BF))
+        sh = m._shadow
+        assert sh.table is not None and len(sh.table[1]) > 100         # the one-launch refresh ran (pangu_shadow_refresh_bf16)
+        blk = m.layers[1].blocks[1]
+        assert torch.equal(sh.get(w), w.detach().to(BF))
+        esb = blk.attention.earth_specific_bias
+        assert torch.equal(sh.get(esb), esb.detach()[0].to(BF))
+        for p in (blk.attention.linear1.weight, blk.linear.linear2.weight):
+            assert torch.equal(sh.get_t(p), p.detach().t().to(BF).contiguous())
+        w1, w2 = blk.linear.linear1.weight, blk.linear.linear2.weight
+        from pangu_pytorch_amd import ops_bf16 as ob
+        assert torch.equal(sh.get_mlp(w1, w2), ob.pack_mlp_weights(w1.detach(), w2.detach()))
         m.invalidate_shadows()
         fresh = m(inp, inp_s, stats, maps, const_h)[0]
     assert torch.equal(after, fresh)
