@@ -298,6 +298,20 @@ int pangu_patch_recover_gather_bwd_bf16(pangu_stream_t stream, const float* d_ou
  * Rounding: to nearest even, as torch's float32 -> bfloat16 cast. */
 int pangu_shadow_refresh_bf16(pangu_stream_t stream, const void* jobs, int n_jobs, long long total_blocks);
 
+/* Training loss of the reference (models/pangu_sample.py:61-67, weights era5_data/config.py:45-46) in one pass per direction:
+ *   loss = mean(|out - target| * w_upper[var]) + 0.25 * mean(|out_surface - target_surface| * w_surface[var])
+ * out / target: [B][Vu][plane_u] fp32 (plane_u = levels * H * W), out_surface / target_surface: [B][Vs][plane_s]; w_upper [Vu],
+ * w_surface [Vs] device fp32.  fwd: `partial` = scratch of pangu_weighted_l1_loss_blocks(..) floats; loss[0] = the loss,
+ * loss[1] / loss[2] = the two means.  bwd: grad = device scalar (d loss); d_out = sign(out - target) * ((grad / n) * w[var])
+ * in the order torch's autograd multiplies (surface: grad * 0.25 first), sign(0) = 0. */
+long long pangu_weighted_l1_loss_blocks(int B, int Vu, long long plane_u, int Vs, long long plane_s);
+int pangu_weighted_l1_loss_fwd(pangu_stream_t stream, const float* out, const float* target, const float* out_surface,
+                               const float* target_surface, const float* w_upper, const float* w_surface, float* partial,
+                               float* loss, int B, int Vu, long long plane_u, int Vs, long long plane_s);
+int pangu_weighted_l1_loss_bwd(pangu_stream_t stream, const float* out, const float* target, const float* out_surface,
+                               const float* target_surface, const float* w_upper, const float* w_surface, const float* grad,
+                               float* d_out, float* d_out_surface, int B, int Vu, long long plane_u, int Vs, long long plane_s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,9 @@ SIGNATURES = {
     "pangu_linear_wgrad_bf16": [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I],
     "pangu_linear_wgrad_bf16_ws": [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _P, _c.c_longlong],
     "pangu_shadow_refresh_bf16": [_P, _P, _I, _c.c_longlong],
+    "pangu_weighted_l1_loss_blocks": [_I, _I, _c.c_longlong, _I, _c.c_longlong],
+    "pangu_weighted_l1_loss_fwd": [_P] * 9 + [_I, _I, _c.c_longlong, _I, _c.c_longlong],
+    "pangu_weighted_l1_loss_bwd": [_P] * 10 + [_I, _I, _c.c_longlong, _I, _c.c_longlong],
     "pangu_window_attn_bwd_bf16": [_P] * 10 + [_I] * 6,
     "pangu_ln_residual_bwd_bf16": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _F],
     "pangu_downsample_ln_bwd_bf16": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I],
@@ -64,7 +67,7 @@ SIGNATURES = {
     "pangu_patch_recover_scatter": [_P, _P, _P, _P, _P, _I, _I],
     "pangu_patch_recover_scatter_denorm": [_P] * 11 + [_I, _I],
 }
-_RESTYPES = {"pangu_error_string": _c.c_char_p}
+_RESTYPES = {"pangu_error_string": _c.c_char_p, "pangu_weighted_l1_loss_blocks": _c.c_longlong}
 
 _lib = None
 

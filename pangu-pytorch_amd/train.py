@@ -31,12 +31,71 @@ def _weights_on(device, dtype):
     return w
 
 
-def weighted_l1_loss(output, output_surface, target, target_surface):
-    """reference models/pangu_sample.py:61-67: mean(|o-t| * w_upper) + 0.25 * mean(|o_s-t_s| * w_surface)."""
+def _weighted_l1_loss_torch(output, output_surface, target, target_surface):
     wu, ws = _weights_on(output.device, output.dtype)
     loss_surface = torch.mean(torch.abs(output_surface - target_surface) * ws)
     loss_upper = torch.mean(torch.abs(output - target) * wu)
     return loss_upper + loss_surface * 0.25
+
+
+class WeightedL1LossFn(torch.autograd.Function):
+    """The loss and its gradient as one HIP pass each (csrc/loss.hip): the torch expression reads / writes the 286 MB fields
+    fourteen times per step (0.9 ms); the forward here reads them once, the backward once more and writes the two gradients."""
+
+    @staticmethod
+    def forward(ctx, output, output_surface, target, target_surface):
+        from . import _lib
+        from .ops import _stream
+        lib = _lib.load()
+        wu, ws = _weights_on(output.device, torch.float32)
+        B, Vu = output.shape[0], output.shape[1]
+        Vs = output_surface.shape[1]
+        geom = (B, Vu, output[0, 0].numel(), Vs, output_surface[0, 0].numel())
+        nblk = lib.pangu_weighted_l1_loss_blocks(*geom)
+        if nblk <= 0:
+            raise RuntimeError(f"weighted_l1_loss: unsupported shapes {tuple(output.shape)} {tuple(output_surface.shape)}")
+        partial = torch.empty((nblk,), dtype=torch.float32, device=output.device)
+        loss = torch.empty((3,), dtype=torch.float32, device=output.device)
+        _lib.check(lib.pangu_weighted_l1_loss_fwd(_stream(), output.data_ptr(), target.data_ptr(), output_surface.data_ptr(),
+                                                  target_surface.data_ptr(), wu.data_ptr(), ws.data_ptr(), partial.data_ptr(),
+                                                  loss.data_ptr(), *geom), "weighted_l1_loss_fwd")
+        ctx.save_for_backward(output, output_surface, target, target_surface)
+        ctx.geom = geom
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        from .ops import _stream
+        output, output_surface, target, target_surface = ctx.saved_tensors
+        wu, ws = _weights_on(output.device, torch.float32)
+        d_o, d_os = torch.empty_like(output), torch.empty_like(output_surface)
+        g = g.to(torch.float32).contiguous()
+        _lib.check(_lib.load().pangu_weighted_l1_loss_bwd(
+            _stream(), output.data_ptr(), target.data_ptr(), output_surface.data_ptr(), target_surface.data_ptr(),
+            wu.data_ptr(), ws.data_ptr(), g.data_ptr(), d_o.data_ptr(), d_os.data_ptr(), *ctx.geom), "weighted_l1_loss_bwd")
+        return d_o, d_os, None, None
+
+
+_HIP_LOSS = __import__("os").environ.get("PANGU_HIP_LOSS", "1") != "0"      # A/B knob: 0 = the torch expression on every device
+
+
+def _hip_loss_ok(output, output_surface, target, target_surface):
+    ts = (output, output_surface, target, target_surface)
+    return (_HIP_LOSS and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.device == output.device for t in ts)
+            and output.dim() == 5 and output_surface.dim() == 4 and output.shape == target.shape
+            and output_surface.shape == target_surface.shape and output.shape[0] == output_surface.shape[0]
+            and output.shape[1] == len(UPPER_WEIGHTS) and output_surface.shape[1] == len(SURFACE_WEIGHTS)
+            and not target.requires_grad and not target_surface.requires_grad)
+
+
+def weighted_l1_loss(output, output_surface, target, target_surface):
+    """reference models/pangu_sample.py:61-67: mean(|o-t| * w_upper) + 0.25 * mean(|o_s-t_s| * w_surface).  Contiguous fp32
+    fields on a HIP device take the two-pass HIP form (WeightedL1LossFn); anything else (other dtypes, CPU tensors of the
+    host-side tests, targets that need gradients) is the reference's own torch expression."""
+    if _hip_loss_ok(output, output_surface, target, target_surface):
+        return WeightedL1LossFn.apply(output, output_surface, target, target_surface)
+    return _weighted_l1_loss_torch(output, output_surface, target, target_surface)
 
 
 def make_optimizer(model, lr=5e-6, weight_decay=3e-6):

@@ -129,3 +129,28 @@ def test_model_compact_bias_mode(P):
         m.use_compact_bias(False)
         ref2, _ = m(inp, inp_s, stats, maps, const_h)
         assert torch.equal(out2, ref2) and not torch.equal(out2, out)
+
+
+@pytest.mark.parametrize("shape", [(1, 13, 721, 1440), (2, 3, 37, 24), (1, 2, 5, 7)])
+def test_weighted_l1_loss_hip_vs_oracle(P, shape):
+    """The two-pass HIP loss (csrc/loss.hip) against the oracle's restatement of reference pangu_sample.py:61-67 on the CPU
+    (value, fp64 accumulation: 1e-6 relative) and against torch autograd of the same expression on the device (the gradient is
+    sign(o - t) times a per-variable constant built in autograd's multiplication order: bit-identical).  Shapes: the model's
+    fields, a per-GPU batch of 2, and planes whose length is not a multiple of 4 (scalar path)."""
+    from pangu_pytorch_amd import train
+    B, L, H, W = shape
+    o = synth.uniform((B, 5, L, H, W), synth.name_seed("loss_o"), device="cuda").requires_grad_(True)
+    t = synth.uniform((B, 5, L, H, W), synth.name_seed("loss_t"), device="cuda")
+    os_ = synth.uniform((B, 4, H, W), synth.name_seed("loss_os"), device="cuda").requires_grad_(True)
+    ts = synth.uniform((B, 4, H, W), synth.name_seed("loss_ts"), device="cuda")
+    with torch.no_grad():
+        t[0, 1, 0, 0, :3] = o[0, 1, 0, 0, :3]                 # exact ties: sign(0) = 0
+    assert train._hip_loss_ok(o, os_, t, ts)
+    loss = train.weighted_l1_loss(o, os_, t, ts)
+    (loss * 1.7).backward()
+    ref = O.train_loss(o.detach().cpu().double(), os_.detach().cpu().double(), t.cpu().double(), ts.cpu().double())
+    assert abs(loss.item() - ref.item()) <= 1e-6 * abs(ref.item())
+    o2, os2 = o.detach().clone().requires_grad_(True), os_.detach().clone().requires_grad_(True)
+    (train._weighted_l1_loss_torch(o2, os2, t, ts) * 1.7).backward()
+    assert torch.equal(o.grad, o2.grad) and torch.equal(os_.grad, os2.grad)
+    assert float(o.grad[0, 1, 0, 0, :3].abs().max()) == 0.0
