@@ -208,6 +208,208 @@ __global__ __launch_bounds__(256) void ln_residual_bwd_bf16_v8_kernel(const u16*
   }
 }
 
+// ---- bf16 fast paths of the two resampling LayerNorm backwards (round 3; forward twins in rowops_bf16.hip): 16-B accesses, gamma
+// and the dgamma / dbeta accumulators in registers, several rows in flight per wave, persistent grid.  Same math as row_ln_bwd.
+__device__ inline void unpack8(const u32x4 v, float* f) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    f[2 * c] = __builtin_bit_cast(float, v[c] << 16);
+    f[2 * c + 1] = __builtin_bit_cast(float, v[c] & 0xFFFF0000u);
+  }
+}
+
+// Down-sampling backward: one wave per row of 4C channels, 16 channels of ONE source token per lane (C % 16 == 0, C <= 256)
+template <int UNR>
+__global__ __launch_bounds__(256) void downsample_ln_bwd_bf16_v16_kernel(const u16* __restrict__ dout, const u16* __restrict__ x,
+                                                                         int ldx, const float* __restrict__ gamma,
+                                                                         u16* __restrict__ dx, float* __restrict__ dgamma,
+                                                                         float* __restrict__ dbeta, int Z, int H, int W, int C) {
+  __shared__ float red[2 * 4 * 1024];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lpq = C >> 4;
+  const bool act = lane < 4 * lpq;
+  const int quad = act ? lane / lpq : 0, c0 = (lane - quad * lpq) * 16;
+  const int H2 = (H + 1) / 2, W2 = W / 2, C4 = 4 * C, N2 = Z * H2 * W2;
+  float gm[16], dg[16], db[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    gm[c] = act ? gamma[lane * 16 + c] : 0.f;
+    dg[c] = 0.f;
+    db[c] = 0.f;
+  }
+  const float inv_c = 1.0f / C4;
+  for (int base = (blockIdx.x * 4 + wave) * UNR; base < N2; base += gridDim.x * 4 * UNR) {
+    u32x4 ya[UNR], yb[UNR], ga[UNR], gb[UNR];
+    long long src[UNR];                                  // element offset of this lane's 16 channels in dx, -1 = padded row / idle
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int row = base + u;
+      ya[u] = u32x4{0u, 0u, 0u, 0u};
+      yb[u] = ya[u]; ga[u] = ya[u]; gb[u] = ya[u];
+      src[u] = -1;
+      if (act && row < N2) {
+        const int w2 = row % W2, h2 = (row / W2) % H2, z = row / (W2 * H2);
+        const int h = 2 * h2 + (quad >> 1), w = 2 * w2 + (quad & 1);
+        const u16* gp = dout + (size_t)row * C4 + lane * 16;
+        ga[u] = *reinterpret_cast<const u32x4*>(gp);
+        gb[u] = *reinterpret_cast<const u32x4*>(gp + 8);
+        if (h < H) {
+          const size_t tok = (size_t)(z * H + h) * W + w;
+          const u16* p = x + tok * ldx + c0;
+          ya[u] = *reinterpret_cast<const u32x4*>(p);
+          yb[u] = *reinterpret_cast<const u32x4*>(p + 8);
+          src[u] = (long long)(tok * C + c0);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      float y[16], g[16];
+      unpack8(ya[u], y); unpack8(yb[u], y + 8);
+      unpack8(ga[u], g); unpack8(gb[u], g + 8);
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; c += 4) s += (y[c] + y[c + 1]) + (y[c + 2] + y[c + 3]);
+      const float mean = wave_sum(s) * inv_c;
+      float q = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) { const float d = y[c] - mean; q += d * d; }
+      if (!act) q = 0.f;
+      const float rstd = rsqrtf(wave_sum(q) * inv_c + LN_EPS);
+      float gg[16], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        y[c] = act ? (y[c] - mean) * rstd : 0.f;         // xhat (a padded source token holds zeros, i.e. xhat = -mean * rstd: it is part of the row)
+        gg[c] = g[c] * gm[c];
+        dg[c] += g[c] * y[c];
+        db[c] += g[c];
+        s1 += gg[c];
+        s2 += gg[c] * y[c];
+      }
+      const float m1 = wave_sum(s1) * inv_c, m2 = wave_sum(s2) * inv_c;
+      if (src[u] >= 0) {
+        u32x4 o0, o1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          o0[c] = pack_bf16x2((gg[2 * c] - m1 - y[2 * c] * m2) * rstd, (gg[2 * c + 1] - m1 - y[2 * c + 1] * m2) * rstd);
+          o1[c] = pack_bf16x2((gg[8 + 2 * c] - m1 - y[8 + 2 * c] * m2) * rstd, (gg[9 + 2 * c] - m1 - y[9 + 2 * c] * m2) * rstd);
+        }
+        *reinterpret_cast<u32x4*>(dx + src[u]) = o0;
+        *reinterpret_cast<u32x4*>(dx + src[u] + 8) = o1;
+      }
+    }
+  }
+  // per-lane parameter gradients -> [4 waves][4C] through LDS, one atomic per channel and workgroup
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    red[wave * 1024 + lane * 16 + c] = dg[c];
+    red[4096 + wave * 1024 + lane * 16 + c] = db[c];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C4; c += 256) {
+    atomicAdd(&dgamma[c], (red[c] + red[1024 + c]) + (red[2048 + c] + red[3072 + c]));
+    atomicAdd(&dbeta[c], (red[4096 + c] + red[5120 + c]) + (red[6144 + c] + red[7168 + c]));
+  }
+}
+
+// Up-sampling backward: LPR = 32 lanes per fine row of Co <= 256 channels, two rows per wave, UNR row pairs in flight.  The
+// iteration space includes the cropped fine rows h >= H (reference layers.py:488-489): their quarter of dy receives zeros.
+template <int UNR>
+__global__ __launch_bounds__(256) void upsample_ln_bwd_bf16_v8_kernel(const u16* __restrict__ dout, const u16* __restrict__ yin,
+                                                                      const float* __restrict__ gamma, u16* __restrict__ dy,
+                                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                      int Z, int H2, int W2, int H, int Co) {
+  constexpr int LPR = 32, RPW = 2, GROUPS = 8, CW = LPR * 8;
+  __shared__ float red[2 * GROUPS * CW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, l = lane % LPR;
+  const bool act = l * 8 < Co;
+  const int Wf = 2 * W2, Hf = 2 * H2, Nall = Z * Hf * Wf;
+  float gm[8], dg[8], db[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    gm[c] = act ? gamma[l * 8 + c] : 0.f;
+    dg[c] = 0.f;
+    db[c] = 0.f;
+  }
+  const float inv_c = 1.0f / Co;
+  for (int base = (blockIdx.x * 4 + wave) * RPW * UNR; base < Nall; base += gridDim.x * 4 * RPW * UNR) {
+    u32x4 yv[UNR], gv[UNR];
+    long long src[UNR];
+    bool real[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int r = base + u * RPW + sub;
+      yv[u] = u32x4{0u, 0u, 0u, 0u};
+      gv[u] = yv[u];
+      src[u] = -1;
+      real[u] = false;
+      if (act && r < Nall) {
+        const int w = r % Wf, h = (r / Wf) % Hf, z = r / (Wf * Hf);
+        src[u] = (long long)(((size_t)(z * H2 + (h >> 1)) * W2 + (w >> 1)) * (4 * Co) + ((h & 1) * 2 + (w & 1)) * Co + l * 8);
+        real[u] = h < H;
+        if (real[u]) {
+          yv[u] = *reinterpret_cast<const u32x4*>(yin + src[u]);
+          gv[u] = *reinterpret_cast<const u32x4*>(dout + (((size_t)z * H + h) * Wf + w) * Co + l * 8);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      float y[8], g[8];
+      unpack8(yv[u], y);
+      unpack8(gv[u], g);
+      const float s = group_sum<LPR>(((y[0] + y[1]) + (y[2] + y[3])) + ((y[4] + y[5]) + (y[6] + y[7])));
+      const float mean = s * inv_c;
+      float q = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { const float d = y[c] - mean; q += d * d; }
+      if (!act) q = 0.f;
+      const float rstd = rsqrtf(group_sum<LPR>(q) * inv_c + LN_EPS);
+      float gg[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        y[c] = (act && real[u]) ? (y[c] - mean) * rstd : 0.f;
+        gg[c] = g[c] * gm[c];
+        dg[c] += g[c] * y[c];
+        db[c] += g[c];
+        s1 += gg[c];
+        s2 += gg[c] * y[c];
+      }
+      const float m1 = group_sum<LPR>(s1) * inv_c, m2 = group_sum<LPR>(s2) * inv_c;
+      if (src[u] >= 0) {
+        u32x4 o = {0u, 0u, 0u, 0u};
+        if (real[u]) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            o[c] = pack_bf16x2((gg[2 * c] - m1 - y[2 * c] * m2) * rstd, (gg[2 * c + 1] - m1 - y[2 * c + 1] * m2) * rstd);
+        }
+        *reinterpret_cast<u32x4*>(dy + src[u]) = o;
+      }
+    }
+  }
+  const int grp = wave * RPW + sub;
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      red[grp * CW + l * 8 + c] = dg[c];
+      red[(GROUPS + grp) * CW + l * 8 + c] = db[c];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < Co; c += 256) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int gq = 0; gq < GROUPS; ++gq) {
+      a += red[gq * CW + c];
+      b += red[(GROUPS + gq) * CW + c];
+    }
+    atomicAdd(&dgamma[c], a);
+    atomicAdd(&dbeta[c], b);
+  }
+}
+
 template <int NV, typename T>
 __global__ __launch_bounds__(256) void downsample_ln_bwd_kernel(const T* __restrict__ dout,
                                                                 const T* __restrict__ x, int ldx,
@@ -417,6 +619,13 @@ extern "C" int pangu_downsample_ln_bwd_bf16(pangu_stream_t stream, const void* d
   if (Z <= 0 || H <= 0 || W <= 0 || (W & 1) || (C & 3) || 4 * C > 1024 || ldx < C || (ldx & 3)) return PANGU_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   dim3 g(row_grid(Z * ((H + 1) / 2) * (W / 2))), b(256);
+  static const bool fast = !(getenv("PANGU_RESAMPLE_FAST") && atoi(getenv("PANGU_RESAMPLE_FAST")) == 0);      // A/B knob
+  if (fast && (C & 15) == 0 && C <= 256 && (ldx & 7) == 0) {
+    const int rows = Z * ((H + 1) / 2) * (W / 2), blocks = (rows + 7) / 8;
+    hipLaunchKernelGGL(downsample_ln_bwd_bf16_v16_kernel<2>, dim3(blocks < 2048 ? blocks : 2048), b, 0, s, (const u16*)dout,
+                       (const u16*)x, ldx, gamma, (u16*)dx, dgamma, dbeta, Z, H, W, C);
+    return pangu_launch_status();
+  }
   PANGU_NV_DISPATCH(4 * C, downsample_ln_bwd_kernel, u16, (const u16*)dout, (const u16*)x, ldx, gamma, (u16*)dx, dgamma,
                     dbeta, Z, H, W, C);
   return pangu_launch_status();
@@ -428,6 +637,13 @@ extern "C" int pangu_upsample_ln_bwd_bf16(pangu_stream_t stream, const void* dou
   if (Z <= 0 || H2 <= 0 || W2 <= 0 || H <= 0 || H > 2 * H2 || (Co & 3) || Co > 1024) return PANGU_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   dim3 g(row_grid(Z * 2 * H2 * 2 * W2)), b(256);
+  static const bool fast = !(getenv("PANGU_RESAMPLE_FAST") && atoi(getenv("PANGU_RESAMPLE_FAST")) == 0);      // A/B knob
+  if (fast && (Co & 7) == 0 && Co <= 256) {
+    const int rows = Z * 2 * H2 * 2 * W2, blocks = (rows + 15) / 16;
+    hipLaunchKernelGGL(upsample_ln_bwd_bf16_v8_kernel<2>, dim3(blocks < 2048 ? blocks : 2048), b, 0, s, (const u16*)dout,
+                       (const u16*)y, gamma, (u16*)dy, dgamma, dbeta, Z, H2, W2, H, Co);
+    return pangu_launch_status();
+  }
   PANGU_NV_DISPATCH(Co, upsample_ln_bwd_kernel, u16, (const u16*)dout, (const u16*)y, gamma, (u16*)dy, dgamma, dbeta, Z, H2,
                     W2, H, Co);
   return pangu_launch_status();

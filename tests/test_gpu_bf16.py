@@ -325,6 +325,49 @@ def test_ln_residual_bf16(P, C):
     assert rel_err(got, ref) < ROUND
 
 
+@pytest.mark.parametrize("arm", ["fast", "generic"])
+def test_resample_ln_backward_bf16(P, arm):
+    """Backward of the down- / up-sampling LayerNorms (reference layers.py:441-454, :480-495) in bf16 against torch autograd of the
+    fp32 expression on the same bf16-rounded inputs: the 16-B fast kernels (round 3) and the generic ones (PANGU_RESAMPLE_FAST=0 is
+    read once per process, so the generic arm runs in a child process)."""
+    if arm == "generic":                 # the same checks (the [fast] id) in a child process that dispatches to the generic kernels
+        import subprocess, sys
+        env = dict(os.environ, PANGU_RESAMPLE_FAST="0")
+        r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k", "test_resample_ln_backward_bf16 and fast"],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:]
+        return
+    from pangu_pytorch_amd import ops_bf16 as ob
+    Z, H, W, C = 8, 181, 24, 192
+    H2, W2 = 91, 12
+    x = synth.uniform((Z * H * W, C), 61).to(BF)
+    g = synth.uniform((4 * C,), 62, 0.1, 1.0)
+    dout = synth.uniform((Z * H2 * W2, 4 * C), 63).to(BF)
+    xf = x.float().requires_grad_(True)
+    gf = g.clone().requires_grad_(True)
+    bf_ = torch.zeros(4 * C, requires_grad=True)
+    xr = torch.nn.functional.pad(xf.view(Z, H, W, C), (0, 0, 0, 0, 0, 1)).view(Z, H2, 2, W2, 2, C)
+    out = torch.nn.functional.layer_norm(xr.permute(0, 1, 3, 2, 4, 5).reshape(-1, 4 * C), (4 * C,), gf, bf_)
+    out.backward(dout.float())
+    dx, dg, db = ob.downsample_ln_bwd(dout.cuda(), x.cuda(), g.cuda(), Z, H, W)
+    assert rel_err(dx, xf.grad) < ROUND and rel_err(dg, gf.grad) < 1e-3 and rel_err(db, bf_.grad) < 1e-3
+    Co = 192
+    y = synth.uniform((Z * H2 * W2, 4 * Co), 64).to(BF)
+    g = synth.uniform((Co,), 65, 0.1, 1.0)
+    dout = synth.uniform((Z * H * 2 * W2, Co), 66).to(BF)
+    yf = y.float().requires_grad_(True)
+    gf = g.clone().requires_grad_(True)
+    bf_ = torch.zeros(Co, requires_grad=True)
+    yr = yf.view(Z, H2, W2, 2, 2, Co).permute(0, 1, 3, 2, 4, 5).reshape(Z, 2 * H2, 2 * W2, Co)[:, :H]
+    out = torch.nn.functional.layer_norm(yr.reshape(-1, Co), (Co,), gf, bf_)
+    out.backward(dout.float())
+    dy, dg, db = ob.upsample_ln_bwd(dout.cuda(), y.cuda(), g.cuda(), Z, H2, W2, H)
+    assert rel_err(dy, yf.grad) < ROUND and rel_err(dg, gf.grad) < 1e-3 and rel_err(db, bf_.grad) < 1e-3
+    # the cropped fine rows (h = 181 of 182) receive exactly zero
+    dyv = dy.float().view(Z, H2, W2, 2, 2, Co)
+    assert float(dyv[:, H2 - 1, :, 1].abs().max()) == 0.0
+
+
 def test_downsample_upsample_embed_bf16(P):
     from pangu_pytorch_amd import ops_bf16 as ob
     Z, H, W, C = 8, 181, 24, 192
