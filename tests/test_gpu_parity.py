@@ -232,6 +232,27 @@ def test_patch_embed_gather_and_recover_small(P):
     assert torch.equal(o.cpu(), ro) and torch.equal(os_.cpu(), rs)
 
 
+@pytest.mark.parametrize("LAT,LON", [(41, 280), (721, 1440)])
+def test_patch_recover_gather_bwd_is_the_scatter_adjoint(P, LAT, LON):
+    """Backward of the patch-recovery un-patchify (reference layers.py:522-543): pure data movement, so the gathered gradient
+    must equal the inverse permutation of the field gradients bit for bit (fp32) / after one bf16 rounding (bf16), with zeros in
+    the cropped positions (level 14, latitudes >= LAT); ragged sizes and the model's."""
+    from pangu_pytorch_amd import ops_bf16 as ob
+    H4, W4 = (LAT + 3) // 4, LON // 4
+    d_o = synth.uniform((5, 13, LAT, LON), synth.name_seed("gb_o"))
+    d_os = synth.uniform((4, LAT, LON), synth.name_seed("gb_os"))
+    full = torch.zeros(5, 14, 4 * H4, LON)
+    full[:, :13, :LAT] = d_o
+    ref_u = full.view(5, 7, 2, H4, 4, W4, 4).permute(1, 3, 5, 0, 2, 4, 6).reshape(7 * H4 * W4, 160)
+    fs = torch.zeros(4, 4 * H4, LON)
+    fs[:, :LAT] = d_os
+    ref_s = fs.view(4, H4, 4, W4, 4).permute(1, 3, 0, 2, 4).reshape(H4 * W4, 64)
+    dy_u, dy_s = P.ops.patch_recover_gather_bwd(d_o.cuda(), d_os.cuda())
+    assert torch.equal(dy_u.cpu(), ref_u) and torch.equal(dy_s.cpu(), ref_s)
+    by_u, by_s = ob.patch_recover_gather_bwd(d_o.cuda(), d_os.cuda())
+    assert torch.equal(by_u.cpu(), ref_u.to(torch.bfloat16)) and torch.equal(by_s.cpu(), ref_s.to(torch.bfloat16))
+
+
 # ---------------------------------------------------------------- block level vs reference golden + oracle
 def _load_block(P, C, roll):
     st = cases.STAGES[C]
