@@ -635,7 +635,7 @@ extern "C" int pangu_downsample_ln_bwd_bf16(pangu_stream_t stream, const void* d
   if (Z <= 0 || H <= 0 || W <= 0 || (W & 1) || (C & 3) || 4 * C > 1024 || ldx < C || (ldx & 3)) return PANGU_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   dim3 g(row_grid(Z * ((H + 1) / 2) * (W / 2))), b(256);
-  static const bool fast = !(getenv("PANGU_RESAMPLE_FAST") && atoi(getenv("PANGU_RESAMPLE_FAST")) == 0);      // A/B knob
+  static const bool fast = ((getenv("PANGU_RESAMPLE_FAST") ? atoi(getenv("PANGU_RESAMPLE_FAST")) : 3) & 2) != 0;      // A/B knob
   if (fast && (C & 15) == 0 && C <= 256 && (ldx & 7) == 0) {
     const int rows = Z * ((H + 1) / 2) * (W / 2), blocks = (rows + 7) / 8;
     hipLaunchKernelGGL(downsample_ln_bwd_bf16_v16_kernel<2>, dim3(blocks < 2048 ? blocks : 2048), b, 0, s, (const u16*)dout,
@@ -653,7 +653,7 @@ extern "C" int pangu_upsample_ln_bwd_bf16(pangu_stream_t stream, const void* dou
   if (Z <= 0 || H2 <= 0 || W2 <= 0 || H <= 0 || H > 2 * H2 || (Co & 3) || Co > 1024) return PANGU_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   dim3 g(row_grid(Z * 2 * H2 * 2 * W2)), b(256);
-  static const bool fast = !(getenv("PANGU_RESAMPLE_FAST") && atoi(getenv("PANGU_RESAMPLE_FAST")) == 0);      // A/B knob
+  static const bool fast = ((getenv("PANGU_RESAMPLE_FAST") ? atoi(getenv("PANGU_RESAMPLE_FAST")) : 3) & 2) != 0;      // A/B knob
   if (fast && (Co & 7) == 0 && Co <= 256) {
     const int rows = Z * 2 * H2 * 2 * W2, blocks = (rows + 15) / 16;
     hipLaunchKernelGGL(upsample_ln_bwd_bf16_v8_kernel<2>, dim3(blocks < 2048 ? blocks : 2048), b, 0, s, (const u16*)dout,

@@ -26,6 +26,7 @@ class WeightShadow:
     traffic, ~0.3 ms) instead of ~240 small torch launches (1.6 ms of GPU time, 10 ms of host time per training step)."""
 
     def __init__(self):
+        ops.require_epoch_hook()
         self.cache = {}          # key -> (stamp, tensor)
         self.jobs = {}           # key -> (mode, params, dst, idx, n0, n1, blocks, signature of the params)
         self.table = None        # (device int64 job table, keys in table order, total blocks)

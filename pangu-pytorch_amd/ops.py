@@ -122,9 +122,18 @@ def _install_epoch_hook():
     import torch.optim.optimizer as _o
     if getattr(_o, "_pangu_epoch_hook", None) is None and hasattr(_o, "register_optimizer_step_post_hook"):
         _o._pangu_epoch_hook = _o.register_optimizer_step_post_hook(bump_weights_epoch)
+    return getattr(_o, "_pangu_epoch_hook", None) is not None
 
 
-_install_epoch_hook()
+_epoch_hook_installed = _install_epoch_hook()
+
+
+def require_epoch_hook():
+    """Called where derived copies of parameters are first made: without the global optimizer hook (torch < 2.0) a fused
+    optimizer step would leave them stale silently -- refuse instead."""
+    if not _epoch_hook_installed:
+        raise RuntimeError("torch.optim.optimizer.register_optimizer_step_post_hook is missing (torch >= 2.0 required): the bf16 "
+                           "weight shadows could not be invalidated after optimizer steps")
 
 # Gradient slots (dist.FlatGradSync): parameter storage address -> the fp32 view of the flat gradient buffer that will hold
 # that parameter's gradient.  Backward kernels that WRITE (not accumulate) a parameter gradient -- the Earth-specific bias
