@@ -208,6 +208,120 @@ __global__ __launch_bounds__(256) void ln_residual_bwd_bf16_v8_kernel(const u16*
   }
 }
 
+// The same kernel with 16 channels (two 16-B loads per tensor) per lane and 32 lanes per row: C = 384 rows take 24 of the 32
+// lanes, TWO rows per wave instead of one row on 48 of 64 lanes -- half the instructions per row (the C = 384 launches of the
+// 8-channel form ran at 3.9 TB/s against 5.3 at C = 192, where it already had two rows per wave).  C % 16 == 0, 256 < C <= 512.
+template <int UNR>
+__global__ __launch_bounds__(256) void ln_residual_bwd_bf16_v16_kernel(const u16* __restrict__ dout, int lddo,
+                                                                       const u16* __restrict__ yin,
+                                                                       const float* __restrict__ gamma, u16* __restrict__ dy,
+                                                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                       int N, int C, float branch_scale) {
+  constexpr int LPR = 32, RPW = 2, GROUPS = 8, CW = LPR * 16;
+  __shared__ float red[2 * GROUPS * CW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, l = lane % LPR;
+  const bool act = l * 16 < C;
+  float gm[16], dg[16], db[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    gm[c] = act ? gamma[l * 16 + c] : 0.f;
+    dg[c] = 0.f;
+    db[c] = 0.f;
+  }
+  const float inv_c = 1.0f / C;
+  const int rows_per_block = 4 * RPW * UNR;
+  for (int base = blockIdx.x * rows_per_block + wave * RPW * UNR; base < N; base += gridDim.x * rows_per_block) {
+    u32x4 ya[UNR], yb[UNR], ga[UNR], gb[UNR];
+    bool ok[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int row = base + u * RPW + sub;
+      ok[u] = act && row < N;
+      ya[u] = u32x4{0u, 0u, 0u, 0u};
+      yb[u] = ya[u]; ga[u] = ya[u]; gb[u] = ya[u];
+      if (ok[u]) {
+        const u16* yp = yin + (size_t)row * C + l * 16;
+        const u16* gp = dout + (size_t)row * lddo + l * 16;
+        ya[u] = *reinterpret_cast<const u32x4*>(yp);
+        yb[u] = *reinterpret_cast<const u32x4*>(yp + 8);
+        ga[u] = *reinterpret_cast<const u32x4*>(gp);
+        gb[u] = *reinterpret_cast<const u32x4*>(gp + 8);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      float y[16], g[16];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        y[2 * c] = __builtin_bit_cast(float, ya[u][c] << 16);
+        y[2 * c + 1] = __builtin_bit_cast(float, ya[u][c] & 0xFFFF0000u);
+        y[8 + 2 * c] = __builtin_bit_cast(float, yb[u][c] << 16);
+        y[9 + 2 * c] = __builtin_bit_cast(float, yb[u][c] & 0xFFFF0000u);
+        g[2 * c] = __builtin_bit_cast(float, ga[u][c] << 16) * branch_scale;
+        g[2 * c + 1] = __builtin_bit_cast(float, ga[u][c] & 0xFFFF0000u) * branch_scale;
+        g[8 + 2 * c] = __builtin_bit_cast(float, gb[u][c] << 16) * branch_scale;
+        g[9 + 2 * c] = __builtin_bit_cast(float, gb[u][c] & 0xFFFF0000u) * branch_scale;
+      }
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; c += 4) s += (y[c] + y[c + 1]) + (y[c + 2] + y[c + 3]);
+      s = group_sum<LPR>(s);
+      const float mean = s * inv_c;
+      float q = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) { const float d = y[c] - mean; q += d * d; }
+      if (!act) q = 0.f;
+      q = group_sum<LPR>(q);
+      const float rstd = rsqrtf(q * inv_c + LN_EPS);
+      float gg[16], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        y[c] = act ? (y[c] - mean) * rstd : 0.f;        // xhat
+        gg[c] = g[c] * gm[c];
+        dg[c] += g[c] * y[c];
+        db[c] += g[c];
+        s1 += gg[c];
+        s2 += gg[c] * y[c];
+      }
+      s1 = group_sum<LPR>(s1);
+      s2 = group_sum<LPR>(s2);
+      const float m1 = s1 * inv_c, m2 = s2 * inv_c;
+      if (ok[u]) {
+        u32x4 o0, o1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          o0[c] = pack_bf16x2((gg[2 * c] - m1 - y[2 * c] * m2) * rstd, (gg[2 * c + 1] - m1 - y[2 * c + 1] * m2) * rstd);
+          o1[c] = pack_bf16x2((gg[8 + 2 * c] - m1 - y[8 + 2 * c] * m2) * rstd, (gg[9 + 2 * c] - m1 - y[9 + 2 * c] * m2) * rstd);
+        }
+        const int row = base + u * RPW + sub;
+        u16* op = dy + (size_t)row * C + l * 16;
+        *reinterpret_cast<u32x4*>(op) = o0;
+        *reinterpret_cast<u32x4*>(op + 8) = o1;
+      }
+    }
+  }
+  const int grp = wave * RPW + sub;
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      red[grp * CW + l * 16 + c] = dg[c];
+      red[(GROUPS + grp) * CW + l * 16 + c] = db[c];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int gq = 0; gq < GROUPS; ++gq) {
+      a += red[gq * CW + c];
+      b += red[(GROUPS + gq) * CW + c];
+    }
+    atomicAdd(&dgamma[c], a);
+    atomicAdd(&dbeta[c], b);
+  }
+}
+
 // ---- bf16 fast paths of the two resampling LayerNorm backwards (round 3; forward twins in rowops_bf16.hip): 16-B accesses, gamma
 // and the dgamma / dbeta accumulators in registers, several rows in flight per wave, persistent grid.  Same math as row_ln_bwd.
 __device__ inline void unpack8(const u32x4 v, float* f) {
@@ -615,8 +729,13 @@ extern "C" int pangu_ln_residual_bwd_bf16(pangu_stream_t stream, const void* dou
     hipLaunchKernelGGL((ln_residual_bwd_bf16_v8_kernel<LPR_, UNR_>), dim3(blocks < 2048 ? blocks : 2048), b, 0, s,        \
                        (const u16*)dout, lddo, (const u16*)y, gamma, (u16*)dy, dgamma, dbeta, N, C, branch_scale);        \
   } while (0)
+    static const bool v16 = !(getenv("PANGU_LN_BWD_V16") && atoi(getenv("PANGU_LN_BWD_V16")) == 0);      // A/B knob
     if (C <= 256) {
       if (unr == 4) PANGU_LNB(32, 4); else PANGU_LNB(32, 2);
+    } else if (v16 && (C & 15) == 0 && (lddo & 7) == 0) {
+      const int blocks = (N + 15) / 16;
+      hipLaunchKernelGGL(ln_residual_bwd_bf16_v16_kernel<2>, dim3(blocks < 2048 ? blocks : 2048), b, 0, s, (const u16*)dout, lddo,
+                         (const u16*)y, gamma, (u16*)dy, dgamma, dbeta, N, C, branch_scale);
     } else {
       if (unr == 4) PANGU_LNB(64, 4); else PANGU_LNB(64, 2);
     }
