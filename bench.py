@@ -154,7 +154,7 @@ def main():
                          "forward once (45 s on a 256-core host, minutes on 8 cores); auto = full on hosts with >= 32 cores")
     ap.add_argument("--no-bf16", action="store_true", help="skip the secondary bf16 forward measurement")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary DDP training-step measurement")
-    ap.add_argument("--train-steps", type=int, default=3)
+    ap.add_argument("--train-steps", type=int, default=6)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -338,7 +338,8 @@ def main():
                 model.set_compute_dtype(dt)
                 torch.manual_seed(1234 + rank)            # DropPath draws (host RNG)
                 torch.cuda.reset_peak_memory_stats()
-                train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=grad_sync if sync else None)
+                for _ in range(2):                        # untimed: builds the weight shadows / Adam state, then one steady-state step
+                    train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=grad_sync if sync else None)
                 lsync()
                 del exposed[:]
                 t1 = time.perf_counter()
