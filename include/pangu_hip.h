@@ -312,6 +312,16 @@ int pangu_weighted_l1_loss_bwd(pangu_stream_t stream, const float* out, const fl
                                const float* target_surface, const float* w_upper, const float* w_surface, const float* grad,
                                float* d_out, float* d_out_surface, int B, int Vu, long long plane_u, int Vs, long long plane_s);
 
+/* Adam over a whole list of tensors in ONE launch (reference finetune_fully.py:121 torch.optim.Adam, stepped at
+ * models/pangu_sample.py:75): p, grad, exp_avg, exp_avg_sq fp32, updated in place with the arithmetic of torch's fused Adam
+ * (L2 weight decay added to the gradient, bias corrections, eps outside the root; doubles where that code uses doubles) -- bit
+ * identical to torch.optim.Adam(fused=True).  `jobs`: device memory, (n_jobs + 1) rows of 8 int64:
+ *   [0] param  [1] grad  [2] exp_avg  [3] exp_avg_sq  [4] bf16 image of the updated param to write as well, or 0  [5] n
+ *   [6] 0 = the call's bias corrections, else float bits of (1 - beta1^step) | float bits of sqrt(1 - beta2^step) << 32 (tensors
+ *   at different step counts)   [7] first block (4096 elements per block); row n_jobs: sentinel, [7] = total_blocks. */
+int pangu_adam_step_multi(pangu_stream_t stream, const void* jobs, int n_jobs, long long total_blocks, double lr, double beta1,
+                          double beta2, double weight_decay, double eps, float bias_correction1, float bias_correction2_sqrt);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,7 @@ SIGNATURES = {
     "pangu_linear_wgrad_bf16": [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I],
     "pangu_linear_wgrad_bf16_ws": [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _P, _c.c_longlong],
     "pangu_shadow_refresh_bf16": [_P, _P, _I, _c.c_longlong],
+    "pangu_adam_step_multi": [_P, _P, _I, _c.c_longlong] + [_c.c_double] * 5 + [_F, _F],
     "pangu_weighted_l1_loss_blocks": [_I, _I, _c.c_longlong, _I, _c.c_longlong],
     "pangu_weighted_l1_loss_fwd": [_P] * 9 + [_I, _I, _c.c_longlong, _I, _c.c_longlong],
     "pangu_weighted_l1_loss_bwd": [_P] * 10 + [_I, _I, _c.c_longlong, _I, _c.c_longlong],

@@ -154,3 +154,33 @@ def test_weighted_l1_loss_hip_vs_oracle(P, shape):
     (train._weighted_l1_loss_torch(o2, os2, t, ts) * 1.7).backward()
     assert torch.equal(o.grad, o2.grad) and torch.equal(os_.grad, os2.grad)
     assert float(o.grad[0, 1, 0, 0, :3].abs().max()) == 0.0
+
+
+def test_hip_adam_matches_torch_fused_adam(P):
+    """train.HipAdam (csrc/adam.hip, one launch for every tensor) against torch.optim.Adam(fused=True) -- the optimiser of reference
+    finetune_fully.py:121 -- over four steps with weight decay, tensors of ragged sizes (the 4-element vector path and its scalar
+    tail), a tensor that joins late (different step counts: per-row bias corrections) and a non-default group.  The kernel follows
+    ATen's adam_math operation by operation, so parameters and both moments must agree to the last bit."""
+    from pangu_pytorch_amd import train
+    torch.manual_seed(0)
+    shapes = [(1037,), (64, 96), (3, 5, 7), (4096 * 3 + 1,), (2,)]
+    pa = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    kw = dict(lr=3e-3, weight_decay=3e-2, betas=(0.9, 0.98), eps=1e-8)
+    oa = train.HipAdam([{"params": pa[:3]}, {"params": pa[3:], "lr": 1e-2, "weight_decay": 0.0}], **kw)
+    ob_ = torch.optim.Adam([{"params": pb[:3]}, {"params": pb[3:], "lr": 1e-2, "weight_decay": 0.0}], fused=True, **kw)
+    for step in range(4):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if i == 1 and step == 0:
+                a.grad = b.grad = None                    # joins at step 1: its step count stays one behind
+                continue
+            g = torch.randn_like(a) * (10.0 ** (i - 2))
+            a.grad, b.grad = g.clone(), g.clone()
+        oa.step()
+        ob_.step()
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            assert torch.equal(a.detach(), b.detach()), (step, i, float((a - b).abs().max()))
+            if a in oa.state and oa.state[a]:
+                assert torch.equal(oa.state[a]["exp_avg"], ob_.state[b]["exp_avg"]), (step, i)
+                assert torch.equal(oa.state[a]["exp_avg_sq"], ob_.state[b]["exp_avg_sq"]), (step, i)
+    assert oa.state[pa[1]]["step"] == 3 and oa.state[pa[0]]["step"] == 4
