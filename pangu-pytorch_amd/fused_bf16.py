@@ -29,13 +29,28 @@ class WeightShadow:
         ops.require_epoch_hook()
         self.cache = {}          # key -> (stamp, tensor)
         self.jobs = {}           # key -> (mode, params, dst, idx, n0, n1, blocks, signature of the params)
-        self.table = None        # (device int64 job table, keys in table order, total blocks)
+        self.table = None        # (device int64 job table, keys in table order, total blocks, keys left out)
         self.bulk_epoch = ops._weights_epoch[0]
+        self.fresh = {}          # key -> epoch at which an optimizer wrote that copy itself (train.HipAdam): skipped by the next refresh
 
     def clear(self):
         self.cache.clear()
         self.jobs.clear()
+        self.fresh.clear()
         self.table = None
+
+    def plain_image(self, p):
+        """The recorded plain bf16 cast of parameter `p` (None when there is none or it no longer matches `p`): an optimizer that
+        updates `p` may write this image in the same pass (train.HipAdam) and call `mark_fresh(p)`."""
+        j = self.jobs.get(id(p))
+        if j is None or j[0] != 0 or self._sig(j[1]) != j[7] or self.cache.get(id(p), (None, None))[1] is not j[2]:
+            return None
+        return j[2]
+
+    def mark_fresh(self, p):
+        """`plain_image(p)` was just re-written from the updated `p` by the optimizer step in progress (epoch = the current one;
+        the post-step hook advances it): the refresh of the NEXT epoch -- and only that one -- leaves it out."""
+        self.fresh[id(p)] = ops._weights_epoch[0]
 
     @staticmethod
     def _sig(params):
@@ -72,19 +87,27 @@ class WeightShadow:
         if not self.jobs:
             return
         from . import _lib
-        if self.table is None:
+        # copies an optimizer wrote itself during the ONE step since the last epoch (exactly one: any other optimizer step in
+        # between could have touched the parameter again)
+        ep = ops._weights_epoch[0]
+        skip = frozenset(k for k, e in self.fresh.items() if e == ep - 1 and k in self.jobs)
+        self.fresh.clear()
+        if self.table is None or self.table[3] != skip:
             rows, keys, first = [], [], 0
             for key, (mode, params, dst, idx, n0, n1, blocks, _) in self.jobs.items():
+                if key in skip:
+                    continue
                 rows.append([params[0].data_ptr(), params[1].data_ptr() if len(params) > 1 else 0, dst.data_ptr(),
                              idx.data_ptr() if idx is not None else 0, n0, n1, mode, first])
                 keys.append(key)
                 first += blocks
             rows.append([0, 0, 0, 0, 0, 0, 0, first])
             dev = next(iter(self.jobs.values()))[2].device
-            self.table = (torch.tensor(rows, dtype=torch.int64).to(dev), keys, first)
-        table, keys, total = self.table
-        _lib.check(_lib.load().pangu_shadow_refresh_bf16(ob._stream(), table.data_ptr(), len(keys), total), "shadow_refresh_bf16")
-        for key in keys:
+            self.table = (torch.tensor(rows, dtype=torch.int64).to(dev), keys, first, skip)
+        table, keys, total, _ = self.table
+        if keys:
+            _lib.check(_lib.load().pangu_shadow_refresh_bf16(ob._stream(), table.data_ptr(), len(keys), total), "shadow_refresh_bf16")
+        for key in list(keys) + list(skip):
             self.cache[key] = (tuple(_stamp(p) for p in self.jobs[key][1]), self.jobs[key][2])
 
     def _lookup(self, key, params, make, mode=None, idx=None):

@@ -105,9 +105,13 @@ class HipAdam(torch.optim.Optimizer):
     torch.optim.Adam's (`step`, `exp_avg`, `exp_avg_sq`; lr / betas / eps / weight_decay per group), so schedulers work unchanged.
     Optimizer steps advance ops' weights epoch through the global post-step hook like any torch optimizer."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, shadow_of=None):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._tables = {}        # group index -> (signature, device table, n_jobs, total blocks)
+        # shadow_of: a PanguModel whose bf16 weight shadows (fused_bf16.WeightShadow) this optimizer keeps current for the plain
+        # casts -- the Earth-specific bias tables, 94 % of the bytes: the kernel writes the bf16 image next to the updated fp32
+        # value instead of the refresh launch re-reading 1.04 GB
+        self._shadow_of = shadow_of
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -124,6 +128,8 @@ class HipAdam(torch.optim.Optimizer):
         for gi, group in enumerate(self.param_groups):
             rows, first, dev = [], 0, None
             beta1, beta2 = group["betas"]
+            ws = getattr(self._shadow_of, "_shadow", None) if self._shadow_of is not None and _ADAM_SHADOW else None
+            imaged = []
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -141,7 +147,13 @@ class HipAdam(torch.optim.Optimizer):
                 n = p.numel()
                 if n == 0:
                     continue
-                rows.append((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), 0, n, st["step"], first))
+                img = ws.plain_image(p) if ws is not None else None
+                if img is not None and (img.numel() != n or img.device != p.device):
+                    img = None
+                if img is not None:
+                    imaged.append(p)
+                rows.append((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                             img.data_ptr() if img is not None else 0, n, st["step"], first))
                 first += (n + 4095) // 4096
                 dev = p.device
             if not rows:
@@ -151,7 +163,7 @@ class HipAdam(torch.optim.Optimizer):
             # the table holds pointers (and per-tensor bias corrections only when the step counts differ): with gradients that keep
             # their addresses -- FlatGradSync's flat buffer, or the caching allocator handing the same blocks back every step -- it
             # is uploaded once; otherwise through pinned memory, asynchronously (no host sync in the training loop)
-            sig = tuple((r[0], r[1], r[5], 0 if uniform else r[6]) for r in rows)
+            sig = tuple((r[0], r[1], r[4], r[5], 0 if uniform else r[6]) for r in rows)
             hit = self._tables.get(gi)
             if hit is None or hit[0] != sig:
                 tab = []
@@ -168,10 +180,13 @@ class HipAdam(torch.optim.Optimizer):
             b1, b2 = bias(rows[0][6])
             _lib.check(lib.pangu_adam_step_multi(_stream(), hit[1].data_ptr(), hit[2], hit[3], float(group["lr"]), float(beta1),
                                                  float(beta2), float(group["weight_decay"]), float(group["eps"]), b1, b2), "adam_step_multi")
+            for p in imaged:
+                ws.mark_fresh(p)
         return loss
 
 
 _HIP_ADAM = __import__("os").environ.get("PANGU_HIP_ADAM", "1") != "0"      # A/B knob: 0 = torch.optim.Adam(fused=True)
+_ADAM_SHADOW = __import__("os").environ.get("PANGU_ADAM_SHADOW", "1") != "0"      # A/B knob: 0 = HipAdam leaves every bf16 image to the refresh launch
 
 
 def make_optimizer(model, lr=5e-6, weight_decay=3e-6):
@@ -181,7 +196,7 @@ def make_optimizer(model, lr=5e-6, weight_decay=3e-6):
     params = [p for p in model.parameters() if p.requires_grad]
     on_gpu = all(p.is_cuda for p in params)
     if on_gpu and _HIP_ADAM and all(p.dtype == torch.float32 and p.is_contiguous() for p in params):
-        return HipAdam(params, lr=lr, weight_decay=weight_decay)
+        return HipAdam(params, lr=lr, weight_decay=weight_decay, shadow_of=model)
     return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, fused=on_gpu)
 
 

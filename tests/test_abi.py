@@ -54,6 +54,11 @@ def test_argument_validation_without_gpu():
     assert lib.pangu_window_attn_bwd(None, P8, P8, P8, P8, P8, P8, P8, P8, P8, 8, 181, big_w, 192, 6, 0) == -5
     assert lib.pangu_window_attn_bwd_bf16(None, P8, P8, P8, P8, P8, P8, P8, P8, P8, 8, 181, 2 * big_w, 192, 6, 0) == -5
     assert lib.pangu_error_string(-5) is not None
+    assert lib.pangu_adam_step_multi(None, None, 3, 10, 1e-3, 0.9, 0.999, 0.0, 1e-8, 0.1, 0.03) == -2
+    assert lib.pangu_adam_step_multi(None, P8, 3, 10, 1e-3, 1.0, 0.999, 0.0, 1e-8, 0.1, 0.03) == -4          # beta1 = 1
+    assert lib.pangu_weighted_l1_loss_blocks(1, 5, 13 * 721 * 1440, 4, 721 * 1440) == 5 * 1648 + 4 * 127
+    assert lib.pangu_weighted_l1_loss_fwd(None, P8, P8, P8, P8, P8, P8, None, P8, 1, 5, 100, 4, 100) == -2
+    assert lib.pangu_weighted_l1_loss_bwd(None, P8, P8, P8, P8, P8, P8, P8, P8, P8, 0, 5, 100, 4, 100) == -1
     assert lib.pangu_shadow_refresh_bf16(None, None, 3, 10) == -2
     assert lib.pangu_shadow_refresh_bf16(None, P8, 0, 10) == -1
     assert lib.pangu_shadow_refresh_bf16(None, P8, 3, 1 << 31) == -1           # more blocks than a grid dimension holds

@@ -576,7 +576,8 @@ def test_full_training_step_bf16(P):
     assert med < 0.1, med
 
 
-def test_bf16_shadows_follow_fused_adam(P):
+@pytest.mark.parametrize("optimizer", ["torch-fused", "hip"])
+def test_bf16_shadows_follow_fused_adam(P, optimizer):
     """The bf16 weight shadows (and packed / transposed images) must track the fp32 master weights across optimizer steps.
     torch's Adam(fused=True) -- train.make_optimizer's form -- does not bump `_version`, so the stamp carries an optimizer epoch
     (ops.param_stamp): after a training step with a LARGE learning rate the forward must be bit-identical to a forward on
@@ -587,7 +588,8 @@ def test_bf16_shadows_follow_fused_adam(P):
     m.set_compute_dtype(BF)
     inp, inp_s, stats, maps, const_h = cases.model_inputs("cuda")
     tgt, tgt_s = cases.model_targets("cuda")
-    opt = torch.optim.Adam([p for p in m.parameters()], lr=1e-3, fused=True)
+    opt = (torch.optim.Adam([p for p in m.parameters()], lr=1e-3, fused=True) if optimizer == "torch-fused" else
+           train.HipAdam([p for p in m.parameters()], lr=1e-3, shadow_of=m))
     w = m.layers[0].blocks[0].attention.linear1.weight
     w0 = w.detach().clone()
     with torch.no_grad():
@@ -598,7 +600,7 @@ def test_bf16_shadows_follow_fused_adam(P):
     with torch.no_grad():
         after = m(inp, inp_s, stats, maps, const_h)[0].clone()
         sh = m._shadow
-        assert sh.table is not None and len(sh.table[1]) > 100         # the one-launch refresh ran (pangu_shadow_refresh_bf16)
+        assert sh.table is not None and len(sh.table[1]) + len(sh.table[3]) > 100         # the one-launch refresh ran (pangu_shadow_refresh_bf16); [3] = images the optimizer wrote itself
         blk = m.layers[1].blocks[1]
         assert torch.equal(sh.get(w), w.detach().to(BF))
         esb = blk.attention.earth_specific_bias
@@ -608,10 +610,13 @@ def test_bf16_shadows_follow_fused_adam(P):
         w1, w2 = blk.linear.linear1.weight, blk.linear.linear2.weight
         from pangu_pytorch_amd import ops_bf16 as ob
         assert torch.equal(sh.get_mlp(w1, w2), ob.pack_mlp_weights(w1.detach(), w2.detach()))
+        from_adam = len(sh.table[3])
         m.invalidate_shadows()
         fresh = m(inp, inp_s, stats, maps, const_h)[0]
     assert torch.equal(after, fresh)
     assert not torch.equal(after, before)
+    if optimizer == "hip":            # the Earth-specific bias images (and the other plain casts) came from the Adam launch itself
+        assert from_adam >= 16
 
 
 def test_full_backward_smooth_bf16_vs_reference(P, golden_dir):
