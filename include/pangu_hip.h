@@ -316,7 +316,7 @@ int pangu_weighted_l1_loss_bwd(pangu_stream_t stream, const float* out, const fl
  * models/pangu_sample.py:75): p, grad, exp_avg, exp_avg_sq fp32, updated in place with the arithmetic of torch's fused Adam
  * (L2 weight decay added to the gradient, bias corrections, eps outside the root; doubles where that code uses doubles) -- bit
  * identical to torch.optim.Adam(fused=True).  `jobs`: device memory, (n_jobs + 1) rows of 8 int64:
- *   [0] param  [1] grad  [2] exp_avg  [3] exp_avg_sq  [4] bf16 image of the updated param to write as well, or 0  [5] n
+ *   [0] param  [1] grad (0 = an all-zero gradient that is never read)  [2] exp_avg  [3] exp_avg_sq  [4] bf16 image of the updated param to write as well, or 0  [5] n
  *   [6] 0 = the call's bias corrections, else float bits of (1 - beta1^step) | float bits of sqrt(1 - beta2^step) << 32 (tensors
  *   at different step counts)   [7] first block (4096 elements per block); row n_jobs: sentinel, [7] = total_blocks. */
 int pangu_adam_step_multi(pangu_stream_t stream, const void* jobs, int n_jobs, long long total_blocks, double lr, double beta1,

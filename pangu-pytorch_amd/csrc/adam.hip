@@ -8,7 +8,7 @@
 // term, both moment updates, the step size and the denominator are evaluated in double and rounded to float where that code assigns
 // to its float variables -- so the result is bit-identical to torch.optim.Adam(fused=True) (tests/test_gpu_extras.py).
 //
-// Job table: (n_jobs + 1) rows of 8 int64: [0] param [1] grad [2] exp_avg [3] exp_avg_sq (float*)  [4] bf16 image of the updated
+// Job table: (n_jobs + 1) rows of 8 int64: [0] param [1] grad (0 = a zero gradient, never read) [2] exp_avg [3] exp_avg_sq (float*)  [4] bf16 image of the updated
 // param or 0  [5] n  [6] 0 = use the launch's bias corrections (every tensor at the same step count: the table then only changes
 // when a pointer does), else float bits of bias_correction1 | float bits of sqrt(bias_correction2) << 32  [7] first block; the last
 // row is a sentinel whose [7] = total blocks.  4096 elements per block.
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const long long* __rest
     const long long i = base + k * 1024 + threadIdx.x * 4;
     if (vec && i + 4 <= n) {
       f32x4 p = *reinterpret_cast<const f32x4*>(P + i);
-      const f32x4 g = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(G + i));
+      const f32x4 g = G ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(G + i)) : f32x4{0.f, 0.f, 0.f, 0.f};
       f32x4 m = *reinterpret_cast<const f32x4*>(M + i);
       f32x4 v = *reinterpret_cast<const f32x4*>(V + i);
 #pragma unroll
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const long long* __rest
     } else {
       for (long long j = i; j < n && j < i + 4; ++j) {
         float pe = P[j], me = M[j], ve = V[j];
-        adam_one(pe, G[j], me, ve, lr, beta1, beta2, weight_decay, eps, bc1, bc2s);
+        adam_one(pe, G ? G[j] : 0.f, me, ve, lr, beta1, beta2, weight_decay, eps, bc1, bc2s);
         P[j] = pe; M[j] = me; V[j] = ve;
         if (S) S[j] = __builtin_bit_cast(u16, (__bf16)pe);
       }

@@ -114,7 +114,10 @@ class HipAdam(torch.optim.Optimizer):
         self._shadow_of = shadow_of
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, missing_as_zero=False):
+        """missing_as_zero: parameters without a gradient are stepped with a ZERO gradient (moments decay, weight decay applies)
+        instead of being skipped -- what the reference's DropPath-dropped branches get (the branch is computed and multiplied by
+        zero there) -- without materialising the zeros."""
         import math
         import struct
 
@@ -131,12 +134,13 @@ class HipAdam(torch.optim.Optimizer):
             ws = getattr(self._shadow_of, "_shadow", None) if self._shadow_of is not None and _ADAM_SHADOW else None
             imaged = []
             for p in group["params"]:
-                if p.grad is None:
+                if p.grad is None and not (missing_as_zero and p.requires_grad):
                     continue
                 g = p.grad
-                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and g.dtype == torch.float32 and g.device == p.device):
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and
+                        (g is None or (g.dtype == torch.float32 and g.device == p.device))):
                     raise RuntimeError("HipAdam: parameters and gradients must be contiguous float32 tensors on one HIP device")
-                if not g.is_contiguous():
+                if g is not None and not g.is_contiguous():
                     g = p.grad = g.contiguous()
                 st = self.state[p]
                 if not st:
@@ -152,7 +156,7 @@ class HipAdam(torch.optim.Optimizer):
                     img = None
                 if img is not None:
                     imaged.append(p)
-                rows.append((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                rows.append((p.data_ptr(), g.data_ptr() if g is not None else 0, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                              img.data_ptr() if img is not None else 0, n, st["step"], first))
                 first += (n + 4095) // 4096
                 dev = p.device
@@ -213,12 +217,15 @@ def train_step(model, optimizer, batch, statistics, maps, const_h, stats_last=No
     loss.backward()
     if grad_sync is not None:
         grad_sync()
-    else:
+        optimizer.step()
+    elif isinstance(optimizer, HipAdam):
         # a DropPath-dropped branch is not computed here, so its parameters come back without a gradient; the reference
         # computes the branch, multiplies by zero and hands Adam ZERO gradients (moments decay, weight decay applies)
+        optimizer.step(missing_as_zero=True)
+    else:
         for group in optimizer.param_groups:
             for p in group["params"]:
                 if p.requires_grad and p.grad is None:
                     p.grad = torch.zeros_like(p)
-    optimizer.step()
+        optimizer.step()
     return loss.detach()

@@ -184,3 +184,27 @@ def test_hip_adam_matches_torch_fused_adam(P):
                 assert torch.equal(oa.state[a]["exp_avg"], ob_.state[b]["exp_avg"]), (step, i)
                 assert torch.equal(oa.state[a]["exp_avg_sq"], ob_.state[b]["exp_avg_sq"]), (step, i)
     assert oa.state[pa[1]]["step"] == 3 and oa.state[pa[0]]["step"] == 4
+
+
+def test_hip_adam_missing_gradient_as_zero(P):
+    """train_step's DropPath rule (a dropped branch's parameters get ZERO gradients, as in the reference where the branch is
+    computed and multiplied by zero): HipAdam.step(missing_as_zero=True) with no gradient tensor at all == torch's fused Adam fed
+    explicit zeros, bit for bit (moments decay, weight decay still applies)."""
+    from pangu_pytorch_amd import train
+    torch.manual_seed(1)
+    pa = [torch.nn.Parameter(torch.randn(n, device="cuda")) for n in (5000, 777)]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    kw = dict(lr=1e-2, weight_decay=1e-2)
+    oa, ob_ = train.HipAdam(pa, **kw), torch.optim.Adam(pb, fused=True, **kw)
+    for step in range(3):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if i == 1 and step == 1:
+                a.grad, b.grad = None, torch.zeros_like(b)
+            else:
+                g = torch.randn_like(a)
+                a.grad, b.grad = g.clone(), g.clone()
+        oa.step(missing_as_zero=True)
+        ob_.step()
+        for a, b in zip(pa, pb):
+            assert torch.equal(a.detach(), b.detach())
+            assert torch.equal(oa.state[a]["exp_avg_sq"], ob_.state[b]["exp_avg_sq"])
