@@ -101,6 +101,8 @@ class EarthBlockFn(torch.autograd.Function):
                 dx += dx1
         elif not dx.is_contiguous():
             dx = dx.contiguous()
+        ops.fill_dropped_grads(g, {"n1w": n1w, "n1b": n1w, "n2w": n2w, "n2b": n2w, "m1w": m1w, "m1b": m1w[:, 0], "m2w": m2w, "m2b": n2w,
+                                   "esb": esb, "a1w": a1w, "a1b": a1b, "a2w": a2w, "a2b": n1w})
         return (dx, g["n1w"], g["n1b"], g["n2w"], g["n2b"], g["m1w"], g["m1b"], g["m2w"], g["m2b"], g["esb"],
                 g["a1w"], g["a1b"], g["a2w"], g["a2b"], None, None, None, None)
 

@@ -93,6 +93,29 @@ def _rows(t, name):
     return t.data_ptr(), t.stride(0)
 
 
+# What a block's backward returns for the parameters of a DropPath-dropped branch (the branch is not computed here; in the
+# reference it is computed and multiplied by zero, layers.py:250-251, so autograd hands the optimizer ZERO gradients there):
+# "none" (default: train.train_step / HipAdam.step(missing_as_zero=True) give those parameters the zero-gradient step without
+# materialising zeros) or "zeros" (explicit zero tensors: exact reference semantics under ANY optimizer / foreign training loop).
+_dropped_grads = "none"
+
+
+def set_dropped_branch_grads(mode):
+    global _dropped_grads
+    if mode not in ("none", "zeros"):
+        raise ValueError("set_dropped_branch_grads: 'none' or 'zeros'")
+    _dropped_grads = mode
+
+
+def fill_dropped_grads(g, like):
+    """g: name -> gradient or None; like: name -> parameter of that shape.  Under the "zeros" policy every None becomes zeros."""
+    if _dropped_grads == "zeros":
+        for k, p in like.items():
+            if g.get(k) is None:
+                g[k] = torch.zeros_like(p)
+    return g
+
+
 _zero_arena = None        # [flat fp32 zeros, used elements]: see zero_arena
 
 # Derived copies of parameters (bf16 weight shadows, packed weight images, compact bias tables) are keyed by a STAMP of the

@@ -319,6 +319,48 @@ def test_block_droppath_branches(P, s1, s2):
             assert rel_err(q.grad, want) < TIGHT, k
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_dropped_branch_gradient_policy(P, dt):
+    """What a block returns for the parameters of a DropPath-dropped branch: None by default (train.train_step gives them the
+    reference's zero-gradient optimizer step without materialising zeros) and explicit zero tensors under
+    ops.set_dropped_branch_grads("zeros") -- the reference's autograd result (layers.py:250-251: branch computed, multiplied by
+    zero) for foreign training loops with any optimizer."""
+    C, roll, W = 192, False, 12
+    st = cases.STAGES[C]
+    blk = P.layers.EarthSpecificBlock(C, 0.2, st["heads"], device="cuda").cuda().train()
+    pre = cases.block_prefix(C, roll)
+    blk.load_state_dict({k: synth.synth_param(pre + k, s, "cuda") for k, s in cases.block_param_shapes(C).items()})
+    mlp_names = ("linear.linear1.weight", "linear.linear1.bias", "linear.linear2.weight", "linear.linear2.bias", "norm2.weight", "norm2.bias")
+    try:
+        for policy in ("none", "zeros"):
+            P.ops.set_dropped_branch_grads(policy)
+            blk.zero_grad(set_to_none=True)
+            seq = iter([1.25, 0.0])                       # attention branch kept, MLP branch dropped
+            blk.drop_path.sample_scale = lambda training: next(seq)
+            x = cases.block_input(C, W, "cuda")
+            if dt == "bf16":
+                from pangu_pytorch_amd import autograd_bf16, fused_bf16
+                att = blk.attention
+                s1, s2 = blk.drop_path.sample_scale(True), blk.drop_path.sample_scale(True)
+                y = autograd_bf16.EarthBlockFnBF16.apply(
+                    x[0].to(torch.bfloat16).requires_grad_(True), blk.norm1.weight, blk.norm1.bias, blk.norm2.weight, blk.norm2.bias,
+                    blk.linear.linear1.weight, blk.linear.linear1.bias, blk.linear.linear2.weight, blk.linear.linear2.bias,
+                    att.earth_specific_bias, att.linear1.weight, att.linear1.bias, att.linear2.weight, att.linear2.bias,
+                    (st["Z"], st["H"], W, att.head_number, roll), s1, s2, fused_bf16.WeightShadow(), None)
+            else:
+                y = blk(x.requires_grad_(True), st["Z"], st["H"], W, roll)
+            (y.float() * cases.cotangent("dp", y.shape, "cuda")).sum().backward()
+            named = dict(blk.named_parameters())
+            for k in mlp_names:
+                if policy == "none":
+                    assert named[k].grad is None, k
+                else:
+                    assert named[k].grad is not None and named[k].grad.shape == named[k].shape and float(named[k].grad.abs().max()) == 0.0, k
+            assert named["attention.linear1.weight"].grad is not None and float(named["attention.linear1.weight"].grad.abs().max()) > 0
+    finally:
+        P.ops.set_dropped_branch_grads("none")
+
+
 def test_block_backward_batch_of_two(P):
     """A batch of two through the autograd path == the two samples run one by one: outputs per sample, input gradients
     per sample, parameter gradients summed (the per-sample slicing is a view / one unbind, never a SelectBackward)."""
