@@ -147,6 +147,8 @@ class HipAdam(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if torch.is_tensor(st["step"]):          # a state_dict written by torch.optim.Adam keeps `step` as a tensor
+                    st["step"] = int(st["step"].item())
                 st["step"] += 1
                 n = p.numel()
                 if n == 0:

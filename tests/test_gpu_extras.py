@@ -184,6 +184,17 @@ def test_hip_adam_matches_torch_fused_adam(P):
                 assert torch.equal(oa.state[a]["exp_avg"], ob_.state[b]["exp_avg"]), (step, i)
                 assert torch.equal(oa.state[a]["exp_avg_sq"], ob_.state[b]["exp_avg_sq"]), (step, i)
     assert oa.state[pa[1]]["step"] == 3 and oa.state[pa[0]]["step"] == 4
+    # a checkpoint written by torch's Adam (reference pangu_sample.py:95 saves optimizer.state_dict()) resumes under HipAdam
+    oc = train.HipAdam([{"params": pa[:3]}, {"params": pa[3:], "lr": 1e-2, "weight_decay": 0.0}], **kw)
+    import copy
+    oc.load_state_dict(copy.deepcopy(ob_.state_dict()))      # as after torch.save / torch.load (state_dict() itself aliases the live tensors)
+    for a, b in zip(pa, pb):
+        g = torch.randn_like(a)
+        a.grad, b.grad = g.clone(), g.clone()
+    oc.step()
+    ob_.step()
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        assert torch.equal(a.detach(), b.detach()), i
 
 
 def test_hip_adam_missing_gradient_as_zero(P):
