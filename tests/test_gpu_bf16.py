@@ -619,6 +619,31 @@ def test_bf16_shadows_follow_fused_adam(P, optimizer):
         assert from_adam >= 16
 
 
+def test_bf16_training_trajectory_tracks_fp32(P):
+    """Twelve optimisation steps (train.train_step: forward, reference loss, backward, HipAdam; DropPath on with the same host RNG
+    seed, lr 2e-4 so that the weights really move) on one fixed batch, once in fp32 and once in bf16: the two loss trajectories stay
+    within 1e-2 of each other at every step and fall by > 25 %.  The end-to-end check that the bf16 step trains on CURRENT weights:
+    with stale weight shadows (round-3 bug) the bf16 losses stop following the fp32 ones after the first step."""
+    import bench
+    from pangu_pytorch_amd import train
+    traj = {}
+    for dt in (torch.float32, BF):
+        torch.manual_seed(0)
+        m = P.PanguModel(device="cuda").cuda().train()
+        m.set_compute_dtype(dt)
+        inp, inp_s, stats, maps, const_h = bench.synthetic_inputs(torch.device("cuda"), 1000)
+        tgt, tgt_s, *_ = bench.synthetic_inputs(torch.device("cuda"), 2000)
+        opt = train.HipAdam([p for p in m.parameters()], lr=2e-4, weight_decay=3e-6, shadow_of=m)
+        torch.manual_seed(7)
+        traj[dt] = [float(train.train_step(m, opt, (inp, inp_s, tgt, tgt_s), stats, maps, const_h)) for _ in range(12)]
+        del m, opt
+        torch.cuda.empty_cache()
+    a, b = traj[torch.float32], traj[BF]
+    print("fp32", ["%.4f" % v for v in a], "bf16", ["%.4f" % v for v in b])
+    assert max(abs(x - y) for x, y in zip(a, b)) < 1e-2
+    assert a[-1] < 0.75 * a[0] and b[-1] < 0.75 * b[0]
+
+
 def test_full_backward_smooth_bf16_vs_reference(P, golden_dir):
     """bf16 whole-model forward + backward under the smooth loss sum(out * cotangent) / numel against the REFERENCE's fp32
     autograd (tests/golden/model_bwd_smooth.npz): every one of the 223 gradient tensors, WORST tensor bounded -- gradient
