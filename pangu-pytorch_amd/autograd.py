@@ -92,8 +92,8 @@ class EarthBlockFn(torch.autograd.Function):
                                                            desb_out=ops.grad_slot(esb))      # straight into the DP flat buffer
             del do
             g["esb"] = desb.unsqueeze(0)
-            g["a1w"], g["a1b"] = ops.linear_wgrad(dqkv, x)
-            g["a1b"] += dqb_pad
+            # linear1's bias gradient = column sums of dqkv + the pad-slot term already in dqb_pad: the kernel adds into that buffer
+            g["a1w"], g["a1b"] = ops.linear_wgrad(dqkv, x, db_into=dqb_pad)
             if dx1.is_contiguous():
                 dx = ops.linear(dqkv, _wt(a1w), act=ops.ACT_ADD, aux=dx1)
             else:

@@ -43,15 +43,15 @@ class _WgradLane:
                 self.side = _side_streams[device] = torch.cuda.Stream(device)
             self.keep = []
 
-    def wgrad(self, dc, a, want_bias=True):
+    def wgrad(self, dc, a, want_bias=True, db_into=None):
         if not self.on:
-            return ob.linear_wgrad(dc, a, want_bias)
+            return ob.linear_wgrad(dc, a, want_bias, db_into)
         ev = torch.cuda.Event()
         ev.record(self.main)                    # dc, a (and the zero arena's fill) are ordered before this point
         self.side.wait_event(ev)
         self.keep += [dc, a]
         with torch.cuda.stream(self.side):
-            return ob.linear_wgrad(dc, a, want_bias)
+            return ob.linear_wgrad(dc, a, want_bias, db_into)
 
     def join(self):
         if self.on:
@@ -160,7 +160,12 @@ class EarthBlockFnBF16(torch.autograd.Function):
                                                           desb_out=ops.grad_slot(esb))       # straight into the DP flat buffer
             del do
             g["esb"] = desb.unsqueeze(0)
-            g["a1w"], g["a1b"] = lane.wgrad(dqkv, x)
+            # linear1's bias gradient = column sums of dqkv (real tokens) + the pad-slot term the attention backward already
+            # accumulated into dqb_pad: the weight-gradient kernel adds its sums into that buffer
+            fuse_db = dqb_pad is not None and dqb_pad.is_contiguous() and not lane.on
+            g["a1w"], g["a1b"] = lane.wgrad(dqkv, x, db_into=dqb_pad if fuse_db else None)
+            if fuse_db:
+                dqb_pad = None
             if dx1.is_contiguous():
                 dx = ob.linear(dqkv, sh.get_t(a1w), act=ob.ACT_ADD, aux=dx1)
             else:

@@ -336,8 +336,9 @@ def wgrad_workspace(device):
     return ws
 
 
-def linear_wgrad(dc, a, want_bias=True):
-    """dW[N,K] = dc[M,N]^T @ a[M,K], db[N] = colsum(dc), ADDED into zero-initialised buffers; the token slabs' partial tiles
+def linear_wgrad(dc, a, want_bias=True, db_into=None):
+    """dW[N,K] = dc[M,N]^T @ a[M,K], db[N] = colsum(dc), ADDED into zero-initialised buffers (db_into: add the column sums into this
+    fp32 (N,) buffer, which already holds a partial bias gradient, instead); the token slabs' partial tiles
     travel through a per-(device, stream) scratch buffer (96 MB, allocated on first use; the few fp32 shapes whose slabs need 108 MB keep the atomic tail, measured level) and one reduce launch instead of fp32 atomics."""
     lib = _lib.load()
     ws = wgrad_workspace(dc.device)
@@ -345,9 +346,10 @@ def linear_wgrad(dc, a, want_bias=True):
     ap, lda = _rows(a, "wgrad.a")
     M, N = dc.shape
     K = a.shape[1]
-    buf = _zeros((N * K + (N if want_bias else 0),), dc.device)   # one fill launch (none inside a zero_arena)
+    own_db = want_bias and db_into is None
+    buf = _zeros((N * K + (N if own_db else 0),), dc.device)   # one fill launch (none inside a zero_arena)
     dw = buf[:N * K].view(N, K)
-    db = buf[N * K:] if want_bias else None
+    db = (buf[N * K:] if own_db else db_into) if want_bias else None
     esz = dc.element_size()
     for m0, m1 in (_row_chunks(M, esz * lddc, esz * lda) or [(0, M)]):      # the kernel ADDS into dw / db
         with _timed("wgrad", 2.0 * (m1 - m0) * N * K):

@@ -295,7 +295,7 @@ _WGRAD_WS_BYTES = ops._WGRAD_WS_BYTES
 _wgrad_workspace = ops.wgrad_workspace      # one scratch buffer per device for both dtypes
 
 
-def linear_wgrad(dc, a, want_bias=True):
+def linear_wgrad(dc, a, want_bias=True, db_into=None):
     """dW[N,K] (fp32) = dc[M,N]^T @ a[M,K], db[N] = colsum(dc); bf16 operands (row-strided views allowed).  The partial tiles of
     the token slabs travel through a per-device scratch buffer (96 MB, allocated on first use; one per device: do not run weight gradients of one device on two streams at once; the few fp32 shapes whose slabs need 108 MB keep the atomic tail, measured level) instead of fp32 atomics."""
     lib = _lib.load()
@@ -304,9 +304,12 @@ def linear_wgrad(dc, a, want_bias=True):
     ap, lda = _rows(a, "wgrad.a")
     M, N = dc.shape
     K = a.shape[1]
-    buf = _zeros((N * K + (N if want_bias else 0),), dc.device)   # one fill launch (none inside a zero_arena)
+    # db_into: an fp32 (N,) buffer that already holds a partial bias gradient (the attention backward's pad-slot term): the column
+    # sums are ADDED to it (the kernels accumulate atomically anyway) instead of a separate buffer + a torch add afterwards
+    own_db = want_bias and db_into is None
+    buf = _zeros((N * K + (N if own_db else 0),), dc.device)   # one fill launch (none inside a zero_arena)
     dw = buf[:N * K].view(N, K)
-    db = buf[N * K:] if want_bias else None
+    db = (buf[N * K:] if own_db else db_into) if want_bias else None
     for m0, m1 in (_row_chunks(M, 2 * lddc, 2 * lda) or [(0, M)]):      # the kernel ADDS into dw / db
         with _timed("wgrad_bf16", 2.0 * (m1 - m0) * N * K):
             _lib.check(lib.pangu_linear_wgrad_bf16_ws(_stream(), dp + m0 * lddc * 2, lddc, ap + m0 * lda * 2, lda, dw.data_ptr(),
