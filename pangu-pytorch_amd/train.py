@@ -161,6 +161,8 @@ class HipAdam(torch.optim.Optimizer):
                 rows.append((p.data_ptr(), g.data_ptr() if g is not None else 0, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                              img.data_ptr() if img is not None else 0, n, st["step"], first))
                 first += (n + 4095) // 4096
+                if dev is not None and p.device != dev:
+                    raise RuntimeError("HipAdam: the parameters of one group must live on one device")
                 dev = p.device
             if not rows:
                 continue
