@@ -21,6 +21,9 @@ typedef short bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16;
 
+#ifndef PANGU_ATTN_OUT_WIDE
+#define PANGU_ATTN_OUT_WIDE 1      // 16-B output stores after a v_permlane16_swap exchange (0: two 8-B stores per lane)
+#endif
 constexpr int VT_LD = 336;      // bytes per V^T row (144 keys * 2 B + pad; 336 = 80 mod 256: conflict-free b128 fragment reads)
 
 __device__ inline u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
@@ -151,14 +154,30 @@ __device__ __forceinline__ void attn_tile(const unsigned char* Ks, const unsigne
       else o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o1, 0, 0, 0);
     }
   }
-  // lane holds O^T[d = 16dt + 4lg + r][query = qn]
+  // lane holds O^T[d = 16dt + 4lg + r][query = qn]: the token's 64-B head row is spread over the four 16-lane rows of the wave as
+  // 8-B pieces (o0: d = 4lg.., o1: d = 16 + 4lg..).  v_permlane16_swap exchanges the odd rows of the o0 registers with the even
+  // rows of the o1 registers (all four lanes of a token sit at the same lane-in-row), after which lane row lg holds EIGHT
+  // consecutive d -- rows 0..3: d = 0, 16, 8, 24 .. +7 -- and the row leaves as ONE 16-B store per lane instead of two 8-B stores
+  // (half the store instructions, whole 64-B segments per instruction: the epilogue is store-issue-bound, not byte-bound)
+  const float inv = 1.0f / sum;
+#if PANGU_ATTN_OUT_WIDE
+  {
+    const auto r0 = __builtin_amdgcn_permlane16_swap(pack2(o0[0] * inv, o0[1] * inv), pack2(o1[0] * inv, o1[1] * inv), false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(pack2(o0[2] * inv, o0[3] * inv), pack2(o1[2] * inv, o1[3] * inv), false, false);
+    if (qtok >= 0) {
+      u16* dst = out + (size_t)qtok * C + hd * 32 + ((lg & 1) << 4) + ((lg >> 1) << 3);
+      *reinterpret_cast<u32x4*>(dst) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+      if (lse && lg == 0) lse[(size_t)qtok * heads + hd] = mx + __logf(sum);
+    }
+  }
+#else
   if (qtok >= 0) {
-    const float inv = 1.0f / sum;
     u16* dst = out + (size_t)qtok * C + hd * 32 + lg * 4;
     *reinterpret_cast<u32x2*>(dst) = u32x2{pack2(o0[0] * inv, o0[1] * inv), pack2(o0[2] * inv, o0[3] * inv)};
     *reinterpret_cast<u32x2*>(dst + 16) = u32x2{pack2(o1[0] * inv, o1[1] * inv), pack2(o1[2] * inv, o1[3] * inv)};
     if (lse && lg == 0) lse[(size_t)qtok * heads + hd] = mx + __logf(sum);
   }
+#endif
 }
 
 // Latency structure: a workgroup is short (27 KB in, 9 KB out, 99 MFMAs), so its life is a chain of memory round trips

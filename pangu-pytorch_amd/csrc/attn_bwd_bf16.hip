@@ -23,6 +23,17 @@ constexpr int TIMG = 32 * T_LD;
 
 __device__ inline u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
 __device__ inline unsigned pack2(float a, float b) { return pack_bf16x2(a, b); }
+
+#ifndef PANGU_ATTN_BWD_WIDE
+#define PANGU_ATTN_BWD_WIDE 1      // 16-B gradient stores after a v_permlane16_swap exchange (0: two 8-B stores per row and lane)
+#endif
+// x0 / x1: this lane's four values of d = 4lg.. / 16 + 4lg.. of one token -> the 16-B piece d = {0, 16, 8, 24}[lg] .. +7 of that token
+// (all 64 lanes must be active: the swap exchanges whole 16-lane rows)
+__device__ inline u32x4 wide16(const f32x4 x0, const f32x4 x1) {
+  const auto r0 = __builtin_amdgcn_permlane16_swap(pack2(x0[0], x0[1]), pack2(x1[0], x1[1]), false, false);
+  const auto r1 = __builtin_amdgcn_permlane16_swap(pack2(x0[2], x0[3]), pack2(x1[2], x1[3]), false, false);
+  return u32x4{r0[0], r1[0], r0[1], r1[1]};
+}
 __device__ inline float bflo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ inline float bfhi(unsigned u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
 __device__ inline float bf1(u16 h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
@@ -359,6 +370,7 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_bf16_kernel(
   const int t = pair / heads, hd = pair - t * heads;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 15, lg = lane >> 4;
+  const int wide_doff = ((lg & 1) << 4) | ((lg >> 1) << 3);      // first d of this lane's 16-B piece after wide16()
   const int C3 = 3 * C;
   const float scale = 0.17677669529663687f;
   constexpr float K_LOG2E = 1.4426950408889634f;
@@ -532,6 +544,18 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_bf16_kernel(
       // lane: dK^T / dV^T [d = 16dt + 4lg + r][key kn]
       const int ktok = *ldsp<int>(L0 + L_ROW + 1152 + kn * 4);
       dk0 *= scale; dk1 *= scale;
+#if PANGU_ATTN_BWD_WIDE
+      {
+        // the token's 64-B head row sits in the wave as 8-B pieces over the four 16-lane rows (x0: d = 4lg.., x1: d = 16 + 4lg..):
+        // v_permlane16_swap (odd rows of x0 <-> even rows of x1) leaves EIGHT consecutive d per lane -- rows 0..3: d = 0, 16, 8, 24
+        // -- so each gradient row leaves as one 16-B store per lane instead of two 8-B stores (attn_bf16.hip, attn_tile)
+        const unsigned dst = ktok >= 0 ? ((unsigned)ktok * (unsigned)C3 + (unsigned)(hd * 32 + wide_doff)) * 2u : OOB;
+        __builtin_amdgcn_raw_buffer_store_b128(wide16(dk0, dk1), dq_rsrc, (int)dst, 2 * C, 0);
+        asm volatile("s_nop 1" ::: "memory");        // store-data WAR hazard hipcc leaves open with an SGPR soffset (mlp_fused_bf16.hip)
+        __builtin_amdgcn_raw_buffer_store_b128(wide16(dv0, dv1), dq_rsrc, (int)dst, 4 * C, 0);
+        asm volatile("s_nop 1" ::: "memory");
+      }
+#else
       {
         const unsigned dst = ktok >= 0 ? ((unsigned)ktok * (unsigned)C3 + (unsigned)(hd * 32 + lg * 4)) * 2u : OOB;
         __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(dk0[0], dk0[1]), pack2(dk0[2], dk0[3])}, dq_rsrc, (int)dst, 2 * C, 0);
@@ -539,6 +563,7 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_bf16_kernel(
         __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(dv0[0], dv0[1]), pack2(dv0[2], dv0[3])}, dq_rsrc, (int)dst, 4 * C, 0);
         __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(dv1[0], dv1[1]), pack2(dv1[2], dv1[3])}, dq_rsrc, (int)dst, 4 * C + 32, 0);
       }
+#endif
       // zero-pad keys all carry linear1.bias: their gradients are summed (lanes of a pad key, then LDS, then ONE
       // global atomic per value at the end) instead of 64 same-address global atomics per pad key and window
       if (__any(ktok < 0)) {
@@ -579,6 +604,13 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_bf16_kernel(
         dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k_hi, dsf, dq1, 0, 0, 0);
       }
       const int qtok = *ldsp<int>(L0 + L_ROW + 1152 + kn * 4);
+#if PANGU_ATTN_BWD_WIDE
+      {                       // lane: dQ^T[d = 16dt + 4lg + r][query 16 wave + lq] -> eight consecutive d per lane, one 16-B store
+        const unsigned dst = qtok >= 0 ? ((unsigned)qtok * (unsigned)C3 + (unsigned)(hd * 32 + wide_doff)) * 2u : OOB;
+        dq0 *= scale; dq1 *= scale;
+        __builtin_amdgcn_raw_buffer_store_b128(wide16(dq0, dq1), dq_rsrc, (int)dst, 0, 0);
+      }
+#else
       {                       // lane: dQ^T[d = 16dt + 4lg + r][query 16 wave + lq]
         const unsigned dst = qtok >= 0 ? ((unsigned)qtok * (unsigned)C3 + (unsigned)(hd * 32 + lg * 4)) * 2u : OOB;
         __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(dq0[0] * scale, dq0[1] * scale), pack2(dq0[2] * scale, dq0[3] * scale)},
@@ -586,6 +618,7 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_bf16_kernel(
         __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(dq1[0] * scale, dq1[1] * scale), pack2(dq1[2] * scale, dq1[3] * scale)},
                                               dq_rsrc, (int)dst, 32, 0);
       }
+#endif
     }
     BWD_STAMP(s4);
     __syncthreads();                              // every wave is done with the images and dS of window l
