@@ -105,6 +105,18 @@ int pangu_window_attn_fwd_compact(pangu_stream_t stream, const float* qkv, const
                                   const float* esb_compact, float* out, float* lse, int Z, int H, int W, int C,
                                   int heads, int shifted);
 
+/* EarthAttention3D.forward's own calling convention (reference layers.py:360-421, the part between linear1 and linear2) for
+ * callers that use the module OUTSIDE EarthSpecificBlock: the tensor is already partitioned and the mask is explicit.
+ *   qkv  [n_lon*types*144][3C]  linear1 output of the window slots in (lon window, type, slot) order (every slot an ordinary
+ *                               token: nothing is a pad here), channel = which*C + head*32 + d
+ *   esb  [types][heads][144][144]
+ *   mask NULL (layers.py:404-405) or fp32 [n_lon][types][144][144] with mask_lon_stride = types*144*144, or one
+ *        [types][144][144] table shared by all longitude windows with mask_lon_stride = 0 (layers.py:401-402)
+ *   out  [n_lon*types*144][C]   channel = head*32 + d (layers.py:413-415)
+ * Not on the hot path (plain VALU kernel, one (window, head) per workgroup). */
+int pangu_attn_windows_fwd(pangu_stream_t stream, const float* qkv, const float* esb, const float* mask,
+                           long long mask_lon_stride, float* out, int n_lon, int types, int heads, int C);
+
 /* Backward of pangu_window_attn_fwd.  One workgroup per (window type, head) walks the nLon longitude windows
  * and keeps the bias gradient d_esb[t][head] = sum_l dS in registers (no atomics, written once).
  *   out, lse: the forward's outputs;  dout [N][C]: gradient w.r.t. out

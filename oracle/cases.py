@@ -38,6 +38,12 @@ def block_input(C, W, device="cpu"):
     return synth.uniform((1, N, C), synth.name_seed(f"block_input_{C}_{W}"), device=device)
 
 
+def attention_window_input(C, nLon, device="cpu"):
+    """A partitioned tensor (nLon, types, 144, C) for EarthAttention3D.forward taken on its own: EVERY slot non-zero (also the
+    slots that hold the block's zero-pad rows when the module runs inside a block)."""
+    return synth.uniform((nLon, STAGES[C]["types"], 144, C), synth.name_seed(f"attn_windows_{C}_{nLon}"), device=device)
+
+
 def cotangent(name, shape, device="cpu"):
     """Fixed upstream gradient so that loss = sum(out * cotangent)."""
     return synth.uniform(shape, synth.name_seed("cot_" + name), device=device)

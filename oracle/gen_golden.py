@@ -1,6 +1,6 @@
 """Generate golden vectors by running the REFERENCE itself (build container only; needs /root/reference).
 
-TEST INFRASTRUCTURE. Usage:  python oracle/gen_golden.py [index] [blocks] [layers] [model] [model_bwd] [model_bwd_smooth] [extras] [rollout2] [keys_table] [refinit]
+TEST INFRASTRUCTURE. Usage:  python oracle/gen_golden.py [index] [blocks] [layers] [model] [model_bwd] [model_bwd_smooth] [extras] [rollout2] [keys_table] [refinit] [attn_windows]
 Outputs small fixtures (fingerprints: samples + sums, index tensors, packed masks) under tests/golden/.
 Inputs and parameters are closed-form (oracle/synth.py), so tests regenerate them bit-identically.
 """
@@ -99,6 +99,24 @@ def gen_blocks(L, M):
                 d.update(cases.summarize(p.grad, tag + ".d_" + k))
             print(tag, "ref fwd+bwd %.1fs" % (time.time() - t))
             save(tag + ".npz", d)
+
+
+def gen_attn_windows(L, M):
+    """EarthAttention3D.forward(x_window, mask) on its own (layers.py:360-421), both stages, mask None and mask = gen_mask."""
+    d = {}
+    for C in (192, 384):
+        st = cases.STAGES[C]
+        Z, H, W = st["Z"], st["H"], 24
+        blk = L.EarthSpecificBlock(C, 0.0, st["heads"], device="cpu").eval()
+        for roll in (False, True):
+            load_params(blk, cases.block_prefix(C, roll))
+            xw = cases.attention_window_input(C, W // 12)
+            mask = blk.gen_mask(torch.zeros(1, Z, H + 5, W, C)) if roll else None
+            with torch.no_grad():
+                y = blk.attention(xw, mask)
+            assert y.shape == xw.shape
+            d.update(cases.summarize(y, f"attn_windows_{C}_{int(roll)}.out"))
+    save("attn_windows.npz", d)
 
 
 def gen_layers(L, M):
@@ -357,3 +375,5 @@ if __name__ == "__main__":
         gen_rollout(L, M, steps=2)
     if "refinit" in what:
         gen_refinit(L, M)
+    if "attn_windows" in what:
+        gen_attn_windows(L, M)

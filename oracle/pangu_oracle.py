@@ -172,6 +172,23 @@ def window_attention(x, w1, b1, w2, b2, bias, Z, H, W, heads, shifted, lon_chunk
     return o @ w2.t() + b2
 
 
+def attention_windows(xw, w1, b1, w2, b2, bias, mask=None):
+    """EarthAttention3D.forward on an already PARTITIONED tensor (reference layers.py:360-421): xw (nLon, types, 144, C) ->
+    (nLon, types, 144, C).  Every slot is an ordinary token here (the block's zero-pad rows arrive as zeros, :192, but nothing
+    in this function knows): linear1 (:365), heads split with channel = which*C + head*32 + d (:368-371), q*scale (:374),
+    q k^T (:378) + bias broadcast over the longitude windows (:395) + optional mask (nLon, types, 144, 144) broadcast over
+    heads (:401-402), softmax (:403/405), P v (:409), heads merged (:413-415), linear2 (:418)."""
+    nLon, types, n, C = xw.shape
+    heads = C // HEAD_DIM
+    qkv = (xw @ w1.t() + b1).view(nLon, types, n, 3, heads, HEAD_DIM).permute(3, 0, 1, 4, 2, 5)
+    q, k, v = qkv[0] * HEAD_DIM ** -0.5, qkv[1], qkv[2]                    # (nLon,types,heads,144,32)
+    s = q @ k.transpose(-2, -1) + bias[0].unsqueeze(0)
+    if mask is not None:
+        s = s + mask.view(nLon, types, 1, n, n)
+    o = (torch.softmax(s, dim=-1) @ v).permute(0, 1, 3, 2, 4).reshape(nLon, types, n, C)
+    return o @ w2.t() + b2
+
+
 def mlp(x, w1, b1, w2, b2):
     return F.gelu(x @ w1.t() + b1) @ w2.t() + b2          # exact-erf GELU (layers.py:261)
 

@@ -95,8 +95,10 @@ def earth_block(blk, x, Z, H, W, roll, out=None):
             x1 = ops.ln_residual(y, x2, blk.norm1.weight, blk.norm1.bias, branch_scale=s1)
     else:
         x1 = x2
+    # out may be the 2-D (N, C) row-strided half of the skip-concat buffer that PanguModel._forward_f32 hands to the LAST block
+    # of layer 0 / 3 on the autograd path; a partially frozen fine-tune (nothing upstream of this block trains) lands here
+    o2 = None if out is None else (out if out.dim() == 2 else _tok2d(out))
     if s2 != 0.0:
-        o2 = _tok2d(out) if out is not None else None
         if _FUSE_LN and C in (192, 384):
             h = ops.linear(x1, blk.linear.linear1.weight, blk.linear.linear1.bias, act=ops.ACT_GELU)
             x2o = ops.linear_ln_residual(h, blk.linear.linear2.weight, blk.linear.linear2.bias, x1, blk.norm2.weight,
@@ -107,9 +109,11 @@ def earth_block(blk, x, Z, H, W, roll, out=None):
     else:
         x2o = x1
         if out is not None:
-            _tok2d(out).copy_(x1)
-            x2o = _tok2d(out)
-    return out if out is not None else x2o.view(B, N, C)
+            o2.copy_(x1)
+            x2o = o2
+    if out is not None:
+        return out.unsqueeze(0) if out.dim() == 2 else out
+    return x2o.view(B, N, C)
 
 
 def patch_embed(m, inp, inp_surface, statistics, maps, const_h):

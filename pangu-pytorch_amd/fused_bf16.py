@@ -31,7 +31,7 @@ class WeightShadow:
         self.jobs = {}           # key -> (mode, params, dst, idx, n0, n1, blocks, signature of the params)
         self.table = None        # (device int64 job table, keys in table order, total blocks, keys left out)
         self.bulk_epoch = ops._weights_epoch[0]
-        self.fresh = {}          # key -> epoch at which an optimizer wrote that copy itself (train.HipAdam): skipped by the next refresh
+        self.fresh = {}          # key -> (epoch, param _version, param address) when an optimizer wrote that copy itself (train.HipAdam): skipped by the next refresh
 
     def clear(self):
         self.cache.clear()
@@ -50,7 +50,10 @@ class WeightShadow:
     def mark_fresh(self, p):
         """`plain_image(p)` was just re-written from the updated `p` by the optimizer step in progress (epoch = the current one;
         the post-step hook advances it): the refresh of the NEXT epoch -- and only that one -- leaves it out."""
-        self.fresh[id(p)] = ops._weights_epoch[0]
+        # (the parameter's `_version` and address at this moment: HipAdam's raw-pointer kernel bumps neither, so an in-place edit
+        # before the next forward -- load_state_dict(best), an EMA swap, a weight clamp -- is what changes them, and the image
+        # written here is then stale like every other copy)
+        self.fresh[id(p)] = (ops._weights_epoch[0], p._version, p.data_ptr())
 
     @staticmethod
     def _sig(params):
@@ -90,7 +93,8 @@ class WeightShadow:
         # copies an optimizer wrote itself during the ONE step since the last epoch (exactly one: any other optimizer step in
         # between could have touched the parameter again)
         ep = ops._weights_epoch[0]
-        skip = frozenset(k for k, e in self.fresh.items() if e == ep - 1 and k in self.jobs)
+        skip = frozenset(k for k, (e, ver, ptr) in self.fresh.items()
+                         if e == ep - 1 and k in self.jobs and self.jobs[k][1][0]._version == ver and self.jobs[k][1][0].data_ptr() == ptr)
         self.fresh.clear()
         if self.table is None or self.table[3] != skip:
             rows, keys, first = [], [], 0
@@ -106,7 +110,7 @@ class WeightShadow:
             self.table = (torch.tensor(rows, dtype=torch.int64).to(dev), keys, first, skip)
         table, keys, total, _ = self.table
         if keys:
-            _lib.check(_lib.load().pangu_shadow_refresh_bf16(ob._stream(), table.data_ptr(), len(keys), total), "shadow_refresh_bf16")
+            _lib.check(_lib.load().pangu_shadow_refresh_bf16(ob._stream(table), table.data_ptr(), len(keys), total), "shadow_refresh_bf16")
         for key in list(keys) + list(skip):
             self.cache[key] = (tuple(_stamp(p) for p in self.jobs[key][1]), self.jobs[key][2])
 

@@ -44,6 +44,34 @@ class DropPath(nn.Module):
         return f"drop_prob={self.drop_prob:.3f}"
 
 
+_ALLOWED_MODULE_TYPES = set()      # filled on first use (assert_plain_tree)
+
+
+def assert_plain_tree(root, what):
+    """The kernels read the parameters of the nn.Linear / nn.Conv1d / nn.LayerNorm children directly and never call their
+    `forward` (nor, on the bf16 path, the forward of ANY sub-module of the model): a wrapper that replaces such a child (LoRA /
+    peft `lora.Linear`, parametrizations, quantisation stubs -- reference finetune/lora_tune.py:124-135 wraps `linear1`) or a
+    forward (pre-)hook on a sub-module would be ignored silently and e.g. train nothing.  Refuse instead: every sub-module of
+    `root` must be one of this file's classes or the plain torch.nn class, without forward hooks (hooks on `root` itself run)."""
+    allowed = _ALLOWED_MODULE_TYPES
+    if not allowed:
+        allowed.update({nn.Linear, nn.Conv1d, nn.LayerNorm, nn.GELU, nn.Dropout, nn.Identity, nn.Sequential, DropPath,
+                        PatchEmbedding_pretrain, Mlp, EarthAttention3D, EarthSpecificBlock, EarthSpecificLayer, DownSample, UpSample,
+                        PatchRecovery_pretrain})
+    for m in root.modules():
+        if (m._forward_hooks or m._forward_pre_hooks or type(m) not in allowed) and m is not root:
+            break
+    else:
+        return
+    name = next(n for n, q in root.named_modules() if q is m)
+    if type(m) in allowed:
+        raise RuntimeError(f"{what} (MI355X build): sub-module '{name}' carries forward hooks, but its forward is never called "
+                           "(the HIP kernels read the parameters directly): the hook would be ignored")
+    raise RuntimeError(f"{what} (MI355X build): sub-module '{name}' is {type(m).__module__}.{type(m).__name__}, not the plain "
+                       "module the kernels read their parameters from; a wrapper's own arithmetic (LoRA adapters, "
+                       "parametrizations) would be bypassed and e.g. train nothing")
+
+
 class PatchEmbedding_pretrain(nn.Module):
     """reference layers.py:12-93."""
 
@@ -73,7 +101,8 @@ class Mlp(nn.Module):
 
 
 class EarthAttention3D(nn.Module):
-    """reference layers.py:272-421.  Parameters only; the arithmetic is the fused window-attention kernel."""
+    """reference layers.py:272-421.  Inside a block the arithmetic is the fused window-attention kernel (the block never calls
+    this module's forward); `forward(x_window, mask)` keeps the module usable on its own."""
 
     def __init__(self, dim, heads, dropout_rate, window_size, device=None):
         super().__init__()
@@ -90,6 +119,28 @@ class EarthAttention3D(nn.Module):
         self.earth_specific_bias = nn.Parameter(torch.zeros(1, self.type_of_windows, heads, wtok, wtok, device=device))
         _trunc_normal_(self.earth_specific_bias, std=0.02)
         self._construct_index()
+
+    def forward(self, x, mask):
+        """reference layers.py:360-421, the module's own calling convention: x (nLon, types, 144, C) ALREADY partitioned into
+        windows (as EarthSpecificBlock.forward :216-221 hands it over), mask None or (nLon, types, 144, 144) (gen_mask, :153-181)
+        -> (nLon, types, 144, C).  EarthSpecificBlock does not come through here -- its kernels fold the partition into their
+        addressing -- this is for callers that use the module on its own: linear1 and linear2 on the GEMM kernel, the core on
+        `pangu_attn_windows_fwd` (explicit mask tensor, every slot an ordinary token).  Inference only: under autograd train
+        the block (its backward is fused); a call that would need a gradient raises."""
+        from . import ops
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("EarthAttention3D.forward(x_window, mask) is inference-only in the MI355X build: call it under "
+                                      "torch.no_grad(); training goes through EarthSpecificBlock (fused backward kernels)")
+        if x.dim() != 4 or x.shape[1] != self.type_of_windows or x.shape[2] != 144 or x.shape[3] != self.dim:
+            raise RuntimeError(f"EarthAttention3D: expected (nLon, {self.type_of_windows}, 144, {self.dim}) windows, got {tuple(x.shape)}")
+        n_lon = x.shape[0]
+        xw = x.to(torch.float32).contiguous().view(-1, self.dim)
+        with torch.cuda.device(x.device):
+            qkv = ops.linear(xw, self.linear1.weight, self.linear1.bias)
+            m = None if mask is None else mask.to(device=x.device, dtype=torch.float32).contiguous()
+            o = ops.attention_windows(qkv, self.earth_specific_bias[0], m, n_lon, self.type_of_windows, self.head_number)
+            y = ops.linear(o, self.linear2.weight, self.linear2.bias)
+        return y.view(x.shape)
 
     def _construct_index(self):
         """reference layers.py:319-357: `self.position_index`, int64 (20736,) in [0, 3312) -- a plain attribute there too
@@ -116,6 +167,7 @@ class EarthSpecificBlock(nn.Module):
         self.type_of_windows = self.attention.type_of_windows
 
     def forward(self, x, Z, H, W, roll, out=None):
+        assert_plain_tree(self, "EarthSpecificBlock")
         return fused.earth_block(self, x, Z, H, W, roll, out=out)
 
     def gen_mask(self, x):

@@ -71,8 +71,33 @@ class _timed:
 
 
 
-def _stream():
+def _stream(t):
+    """The stream a launch on `t`'s device goes to: torch's current stream of the CURRENT device -- which must be `t`'s.
+    A tensor on cuda:1 launched while the current device is cuda:0 would put device-1 pointers on a device-0 stream (silent
+    peer access over xGMI, or a fault): refused here, once per launch.  PanguModel.forward enters `torch.cuda.device(input.device)`
+    itself and autograd runs a backward under the device of its forward, so only hand-made calls of single ops can trip this."""
+    dev = t.device if isinstance(t, torch.Tensor) else torch.device(t)
+    if dev.type != "cuda":
+        raise RuntimeError(f"the Pangu HIP path needs tensors on an MI355X device (got {dev}); there is no CPU fallback")
+    cur = torch.cuda.current_device()
+    if dev.index is not None and dev.index != cur:
+        raise RuntimeError(f"Pangu HIP op called with tensors on {dev} while the current device is cuda:{cur}: wrap the call in "
+                           f"`with torch.cuda.device({dev.index}):` (PanguModel.forward does this for its own launches)")
     return torch.cuda.current_stream().cuda_stream
+
+
+def same_device(*tensors):
+    """All tensors on one HIP device (None entries skipped), else RuntimeError -- the model-level check behind `_stream`'s
+    first-tensor guard."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"Pangu HIP path: tensors on different devices ({dev} and {t.device})")
+    return dev
 
 
 def _chk(t, name):
@@ -256,7 +281,7 @@ def window_index(Z, H, W, shifted, device):
     lib = _lib.load()
     Hp = H + 5
     out = torch.empty((W // 12, (Z // 2) * (Hp // 6), 144), dtype=torch.int32, device=device)
-    _lib.check(lib.pangu_window_index_export(_stream(), out.data_ptr(), Z, H, W, int(shifted)), "window_index_export")
+    _lib.check(lib.pangu_window_index_export(_stream(device), out.data_ptr(), Z, H, W, int(shifted)), "window_index_export")
     return out
 
 
@@ -264,7 +289,7 @@ def window_mask(Z, H, W, device):
     lib = _lib.load()
     Hp = H + 5
     out = torch.empty(((Z // 2) * (Hp // 6), 144, 144), dtype=torch.float32, device=device)
-    _lib.check(lib.pangu_window_mask_export(_stream(), out.data_ptr(), Z, H, W), "window_mask_export")
+    _lib.check(lib.pangu_window_mask_export(_stream(device), out.data_ptr(), Z, H, W), "window_mask_export")
     return out
 
 
@@ -292,7 +317,7 @@ def linear(a, weight, bias=None, act=ACT_NONE, out=None, aux=None):
     split = _F32_SPLIT and K % 8 == 0 and act != ACT_ADD
     fn = lib.pangu_linear_fwd_f32x3 if split else lib.pangu_linear_fwd
     with _timed("linear_x3" if split else "linear", 2.0 * M * N * K):
-        _lib.check(fn(_stream(), ap, lda, wp, bp, op, ldc, M, N, K, act,
+        _lib.check(fn(_stream(a), ap, lda, wp, bp, op, ldc, M, N, K, act,
                       _chk(aux, "linear.aux") if aux is not None else None), "linear_fwd")
     return out
 
@@ -316,7 +341,7 @@ def linear_ln_residual(a, weight, bias, shortcut, gamma, beta, out=None, branch_
         return out
     with _timed("linear_ln", 2.0 * M * N * K):      # its own bucket: not the plain GEMM kernel of bench.py's roofline
         _lib.check(lib.pangu_linear_ln_residual_fwd(
-            _stream(), ap, lda, _chk(weight, "linear_ln.weight"), _chk(bias, "linear_ln.bias") if bias is not None else None,
+            _stream(a), ap, lda, _chk(weight, "linear_ln.weight"), _chk(bias, "linear_ln.bias") if bias is not None else None,
             sp, lds, _chk(gamma, "gamma"), _chk(beta, "beta"), op, ldo, M, N, K, float(branch_scale)), "linear_ln_residual_fwd")
     return out
 
@@ -353,7 +378,7 @@ def linear_wgrad(dc, a, want_bias=True, db_into=None):
     esz = dc.element_size()
     for m0, m1 in (_row_chunks(M, esz * lddc, esz * lda) or [(0, M)]):      # the kernel ADDS into dw / db
         with _timed("wgrad", 2.0 * (m1 - m0) * N * K):
-            _lib.check(lib.pangu_linear_wgrad_ws(_stream(), dp + m0 * lddc * esz, lddc, ap + m0 * lda * esz, lda, dw.data_ptr(),
+            _lib.check(lib.pangu_linear_wgrad_ws(_stream(dc), dp + m0 * lddc * esz, lddc, ap + m0 * lda * esz, lda, dw.data_ptr(),
                                                  db.data_ptr() if want_bias else None, m1 - m0, N, K, ws.data_ptr(),
                                                  _WGRAD_WS_BYTES), "linear_wgrad")
     return dw, db
@@ -376,9 +401,30 @@ def window_attention(qkv, qkv_bias, esb, Z, H, W, heads, shifted, want_lse=False
     Np = (Z // 2) * ((H + 5) // 6) * (W // 12) * 144          # padded token count: the core's FLOPs (4*Np*144*C)
     with _timed("attn", 4.0 * Np * 144 * C):
         fn = lib.pangu_window_attn_fwd_compact if compact else lib.pangu_window_attn_fwd
-        _lib.check(fn(_stream(), _chk(qkv, "qkv"), _chk(qkv_bias, "qkv_bias"), _chk(esb, "esb"), out.data_ptr(),
+        _lib.check(fn(_stream(qkv), _chk(qkv, "qkv"), _chk(qkv_bias, "qkv_bias"), _chk(esb, "esb"), out.data_ptr(),
                       lse.data_ptr() if want_lse else None, Z, H, W, C, heads, int(shifted)), "window_attn_fwd")
     return (out, lse) if want_lse else out
+
+
+def attention_windows(qkv, esb, mask, n_lon, types, heads):
+    """EarthAttention3D's core on a PARTITIONED tensor (reference layers.py:368-415): qkv (n_lon*types*144, 3C) in window-slot
+    order, esb (types, heads, 144, 144), mask None | (n_lon, types, 144, 144) | (types, 144, 144) fp32 -> (n_lon*types*144, C)."""
+    lib = _lib.load()
+    M, C3 = qkv.shape
+    C = C3 // 3
+    if M != n_lon * types * 144 or tuple(esb.shape) != (types, heads, 144, 144):
+        raise RuntimeError(f"attention_windows: qkv {tuple(qkv.shape)}, esb {tuple(esb.shape)} vs {n_lon} x {types} windows")
+    stride = 0
+    if mask is not None:
+        if tuple(mask.shape) == (n_lon, types, 144, 144):
+            stride = types * 144 * 144
+        elif tuple(mask.shape) != (types, 144, 144):
+            raise RuntimeError(f"attention_windows: mask {tuple(mask.shape)} is neither ({n_lon}, {types}, 144, 144) nor ({types}, 144, 144)")
+    out = torch.empty((M, C), dtype=torch.float32, device=qkv.device)
+    _lib.check(lib.pangu_attn_windows_fwd(_stream(qkv), _chk(qkv, "qkv"), _chk(esb, "esb"),
+                                          _chk(mask, "mask") if mask is not None else None, stride, out.data_ptr(), n_lon, types,
+                                          heads, C), "attn_windows_fwd")
+    return out
 
 
 def window_attention_bwd(qkv, qkv_bias, esb, out, lse, dout, Z, H, W, heads, shifted, desb_out=None):
@@ -392,7 +438,7 @@ def window_attention_bwd(qkv, qkv_bias, esb, out, lse, dout, Z, H, W, heads, shi
     desb = torch.empty_like(esb) if desb_out is None else desb_out.view(esb.shape)
     Np = (Z // 2) * ((H + 5) // 6) * (W // 12) * 144
     with _timed("attn_bwd", 14.0 * Np * 144 * C):
-        _lib.check(lib.pangu_window_attn_bwd(_stream(), _chk(qkv, "qkv"), _chk(qkv_bias, "qkv_bias"), _chk(esb, "esb"),
+        _lib.check(lib.pangu_window_attn_bwd(_stream(qkv), _chk(qkv, "qkv"), _chk(qkv_bias, "qkv_bias"), _chk(esb, "esb"),
                                              _chk(out, "out"), _chk(lse, "lse"), _chk(dout, "dout"), dqkv.data_ptr(),
                                              dqb.data_ptr(), desb.data_ptr(), Z, H, W, C, heads, int(shifted)),
                    "window_attn_bwd")
@@ -406,7 +452,7 @@ def ln_residual_bwd(dout, y, gamma, branch_scale=1.0):
     dp, lddo = _rows(dout, "ln_bwd.dout")
     dy = torch.empty_like(y)
     dg, db = _zeros((2, C), y.device).unbind(0)
-    _lib.check(lib.pangu_ln_residual_bwd(_stream(), dp, lddo, _chk(y, "ln_bwd.y"), _chk(gamma, "gamma"), dy.data_ptr(),
+    _lib.check(lib.pangu_ln_residual_bwd(_stream(dout), dp, lddo, _chk(y, "ln_bwd.y"), _chk(gamma, "gamma"), dy.data_ptr(),
                                          dg.data_ptr(), db.data_ptr(), N, C, float(branch_scale)), "ln_residual_bwd")
     return dy, dg, db
 
@@ -417,7 +463,7 @@ def downsample_ln_bwd(dout, x, gamma, Z, H, W):
     C = x.shape[1]
     dx = torch.empty((Z * H * W, C), dtype=torch.float32, device=x.device)
     dg, db = _zeros((2, 4 * C), x.device).unbind(0)
-    _lib.check(lib.pangu_downsample_ln_bwd(_stream(), _chk(dout, "dout"), xp, ldx, _chk(gamma, "gamma"), dx.data_ptr(),
+    _lib.check(lib.pangu_downsample_ln_bwd(_stream(dout), _chk(dout, "dout"), xp, ldx, _chk(gamma, "gamma"), dx.data_ptr(),
                                            dg.data_ptr(), db.data_ptr(), Z, H, W, C), "downsample_ln_bwd")
     return dx, dg, db
 
@@ -427,7 +473,7 @@ def upsample_ln_bwd(dout, y, gamma, Z, H2, W2, H):
     Co = y.shape[1] // 4
     dy = torch.empty_like(y)
     dg, db = _zeros((2, Co), y.device).unbind(0)
-    _lib.check(lib.pangu_upsample_ln_bwd(_stream(), _chk(dout, "dout"), _chk(y, "y"), _chk(gamma, "gamma"),
+    _lib.check(lib.pangu_upsample_ln_bwd(_stream(dout), _chk(dout, "dout"), _chk(y, "y"), _chk(gamma, "gamma"),
                                          dy.data_ptr(), dg.data_ptr(), db.data_ptr(), Z, H2, W2, H, Co),
                "upsample_ln_bwd")
     return dy, dg, db
@@ -439,7 +485,7 @@ def patch_recover_gather_bwd(d_out, d_out_s):
     H4, W4 = (LAT + 3) // 4, LON // 4
     dy_u = torch.empty((7 * H4 * W4, 160), dtype=torch.float32, device=d_out.device)
     dy_s = torch.empty((H4 * W4, 64), dtype=torch.float32, device=d_out.device)
-    _lib.check(lib.pangu_patch_recover_gather_bwd(_stream(), _chk(d_out, "d_output"), _chk(d_out_s, "d_output_surface"),
+    _lib.check(lib.pangu_patch_recover_gather_bwd(_stream(d_out), _chk(d_out, "d_output"), _chk(d_out_s, "d_output_surface"),
                                                   dy_u.data_ptr(), dy_s.data_ptr(), LAT, LON),
                "patch_recover_gather_bwd")
     return dy_u, dy_s
@@ -453,7 +499,7 @@ def ln_residual(y, shortcut, gamma, beta, out=None, branch_scale=1.0, want_stats
         out = torch.empty((N, C), dtype=torch.float32, device=y.device)
     op, ldo = _rows(out, "ln_residual.out")
     stats = torch.empty((N, 2), dtype=torch.float32, device=y.device) if want_stats else None
-    _lib.check(lib.pangu_ln_residual_fwd(_stream(), _chk(y, "ln_residual.y"), sp, lds, _chk(gamma, "gamma"),
+    _lib.check(lib.pangu_ln_residual_fwd(_stream(y), _chk(y, "ln_residual.y"), sp, lds, _chk(gamma, "gamma"),
                                          _chk(beta, "beta"), op, ldo, stats.data_ptr() if want_stats else None, N, C,
                                          float(branch_scale)), "ln_residual_fwd")
     return (out, stats) if want_stats else out
@@ -466,7 +512,7 @@ def downsample_ln(x, gamma, beta, Z, H, W, want_stats=False):
     rows = Z * ((H + 1) // 2) * (W // 2)
     out = torch.empty((rows, 4 * C), dtype=torch.float32, device=x.device)
     stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device) if want_stats else None
-    _lib.check(lib.pangu_downsample_ln_fwd(_stream(), xp, ldx, _chk(gamma, "gamma"), _chk(beta, "beta"), out.data_ptr(),
+    _lib.check(lib.pangu_downsample_ln_fwd(_stream(x), xp, ldx, _chk(gamma, "gamma"), _chk(beta, "beta"), out.data_ptr(),
                                            stats.data_ptr() if want_stats else None, Z, H, W, C), "downsample_ln_fwd")
     return (out, stats) if want_stats else out
 
@@ -477,7 +523,7 @@ def upsample_ln(y, gamma, beta, Z, H2, W2, H, want_stats=False):
     rows = Z * H * 2 * W2
     out = torch.empty((rows, Co), dtype=torch.float32, device=y.device)
     stats = torch.empty((rows, 2), dtype=torch.float32, device=y.device) if want_stats else None
-    _lib.check(lib.pangu_upsample_ln_fwd(_stream(), _chk(y, "upsample.y"), _chk(gamma, "gamma"), _chk(beta, "beta"),
+    _lib.check(lib.pangu_upsample_ln_fwd(_stream(y), _chk(y, "upsample.y"), _chk(gamma, "gamma"), _chk(beta, "beta"),
                                          out.data_ptr(), stats.data_ptr() if want_stats else None, Z, H2, W2, H, Co),
                "upsample_ln_fwd")
     return (out, stats) if want_stats else out
@@ -490,7 +536,7 @@ def patch_embed_gather(inp, inp_surface, s_mean, s_std, u_mean, u_std, maps, con
     H4, W4 = (LAT + 3) // 4, LON // 4
     a_s = torch.empty((H4 * W4, 112), dtype=torch.float32, device=inp.device)
     a_u = torch.empty((7 * H4 * W4, 192), dtype=torch.float32, device=inp.device)
-    _lib.check(lib.pangu_patch_embed_gather(_stream(), _chk(inp, "input"), _chk(inp_surface, "input_surface"),
+    _lib.check(lib.pangu_patch_embed_gather(_stream(inp), _chk(inp, "input"), _chk(inp_surface, "input_surface"),
                                             _chk(s_mean, "surface_mean"), _chk(s_std, "surface_std"),
                                             _chk(u_mean, "upper_mean"), _chk(u_std, "upper_std"), _chk(maps, "maps"),
                                             _chk(const_h, "const_h"), a_s.data_ptr(), a_u.data_ptr(), LAT, LON),
@@ -538,9 +584,9 @@ def patch_recover_scatter(y_upper, y_surface, LAT, LON):
             raise RuntimeError(f"scatter_denorm target {tuple(pu.shape)} does not match the (5, 13, {LAT}, {LON}) fields")
         um, us, sm, ss = tgt[2]
         _lib.check(lib.pangu_patch_recover_scatter_denorm(
-            _stream(), _chk(y_upper, "y_upper"), _chk(y_surface, "y_surface"), out.data_ptr(), out_s.data_ptr(), pu.data_ptr(),
+            _stream(y_upper), _chk(y_upper, "y_upper"), _chk(y_surface, "y_surface"), out.data_ptr(), out_s.data_ptr(), pu.data_ptr(),
             ps.data_ptr(), um.data_ptr(), us.data_ptr(), sm.data_ptr(), ss.data_ptr(), LAT, LON), "patch_recover_scatter_denorm")
         return out, out_s
-    _lib.check(lib.pangu_patch_recover_scatter(_stream(), _chk(y_upper, "y_upper"), _chk(y_surface, "y_surface"),
+    _lib.check(lib.pangu_patch_recover_scatter(_stream(y_upper), _chk(y_upper, "y_upper"), _chk(y_surface, "y_surface"),
                                                out.data_ptr(), out_s.data_ptr(), LAT, LON), "patch_recover_scatter")
     return out, out_s

@@ -37,7 +37,7 @@ def linear(a, weight, bias=None, act=ACT_NONE, out=None, aux=None, out_dtype=tor
             linear(a[m0:m1], weight, bias, act, out[m0:m1], aux[m0:m1] if aux is not None else None, out_dtype)
         return out
     with _timed("linear_bf16", 2.0 * M * N * K):
-        _lib.check(lib.pangu_linear_fwd_bf16(_stream(), ap, lda, _p(weight, "weight"),
+        _lib.check(lib.pangu_linear_fwd_bf16(_stream(a), ap, lda, _p(weight, "weight"),
                                              _p(bias, "bias", torch.float32) if bias is not None else None, op, ldc, M,
                                              N, K, act, _p(aux, "aux") if aux is not None else None,
                                              BF16 if out.dtype == torch.bfloat16 else F32), "linear_fwd_bf16")
@@ -52,7 +52,7 @@ def window_attention(qkv, qkv_bias, esb, Z, H, W, heads, shifted, want_lse=False
     lse = torch.empty((N, heads), dtype=torch.float32, device=qkv.device) if want_lse else None
     Np = (Z // 2) * ((H + 5) // 6) * (W // 12) * 144
     with _timed("attn_bf16", 4.0 * Np * 144 * C):
-        _lib.check(lib.pangu_window_attn_fwd_bf16(_stream(), _p(qkv, "qkv"), _p(qkv_bias, "qkv_bias"), _p(esb, "esb"),
+        _lib.check(lib.pangu_window_attn_fwd_bf16(_stream(qkv), _p(qkv, "qkv"), _p(qkv_bias, "qkv_bias"), _p(esb, "esb"),
                                                   out.data_ptr(), lse.data_ptr() if want_lse else None, Z, H, W, C, heads,
                                                   int(shifted)), "window_attn_fwd_bf16")
     return (out, lse) if want_lse else out
@@ -71,7 +71,7 @@ def window_attention_qkv(x, w_qkv, b_qkv, esb, Z, H, W, heads, shifted, want_lse
     lse = torch.empty((N, heads), dtype=torch.float32, device=x.device) if want_lse else None
     Np = (Z // 2) * ((H + 5) // 6) * (W // 12) * 144
     with _timed("attn_qkv_bf16", 4.0 * Np * 144 * C + 6.0 * Np * C * C):
-        _lib.check(lib.pangu_window_attn_qkv_fwd_bf16(_stream(), xp, ldx, _p(w_qkv, "w_qkv"), _p(b_qkv, "b_qkv", torch.float32),
+        _lib.check(lib.pangu_window_attn_qkv_fwd_bf16(_stream(x), xp, ldx, _p(w_qkv, "w_qkv"), _p(b_qkv, "b_qkv", torch.float32),
                                                       _p(esb, "esb"), out.data_ptr(), lse.data_ptr() if want_lse else None,
                                                       Z, H, W, C, heads, int(shifted)), "window_attn_qkv_fwd_bf16")
     return (out, lse) if want_lse else out
@@ -91,7 +91,7 @@ def window_attention_qkv_train(x, w_qkv, b_qkv, esb, Z, H, W, heads, shifted):
     Np = (Z // 2) * ((H + 5) // 6) * (W // 12) * 144
     with _timed("attn_qkv_bf16", 4.0 * Np * 144 * C + 6.0 * Np * C * C):
         _lib.check(lib.pangu_window_attn_qkv_train_fwd_bf16(
-            _stream(), xp, ldx, _p(w_qkv, "w_qkv"), _p(b_qkv, "b_qkv", torch.float32), _p(esb, "esb"), out.data_ptr(),
+            _stream(x), xp, ldx, _p(w_qkv, "w_qkv"), _p(b_qkv, "b_qkv", torch.float32), _p(esb, "esb"), out.data_ptr(),
             lse.data_ptr(), qkv.data_ptr(), Z, H, W, C, heads, int(shifted)), "window_attn_qkv_train_fwd_bf16")
     return out, lse, qkv
 
@@ -114,7 +114,7 @@ def linear_ln_residual(a, weight, bias, shortcut, gamma, beta, out=None):
         return out
     with _timed("linear_ln_bf16", 2.0 * M * N * K):
         _lib.check(lib.pangu_linear_ln_residual_fwd_bf16(
-            _stream(), ap, lda, _p(weight, "weight"), _p(bias, "bias", torch.float32) if bias is not None else None,
+            _stream(a), ap, lda, _p(weight, "weight"), _p(bias, "bias", torch.float32) if bias is not None else None,
             _p(shortcut, "shortcut"), _p(gamma, "gamma", torch.float32), _p(beta, "beta", torch.float32), op, ldo, M, N, K),
             "linear_ln_residual_fwd_bf16")
     return out
@@ -191,7 +191,7 @@ def mlp_ln_residual(x, w_packed, b1, b2, gamma, beta, out=None, branch_scale=1.0
         return out
     with _timed("mlp_fused_bf16", 16.0 * M * C * C):
         _lib.check(lib.pangu_mlp_ln_residual_fwd_bf16(
-            _stream(), xp, ldx, _p(w_packed, "w_packed"), _p(b1, "b1", torch.float32), _p(b2, "b2", torch.float32),
+            _stream(x), xp, ldx, _p(w_packed, "w_packed"), _p(b1, "b1", torch.float32), _p(b2, "b2", torch.float32),
             _p(gamma, "gamma", torch.float32), _p(beta, "beta", torch.float32), op, ldo, M, C, float(branch_scale)),
             "mlp_ln_residual_fwd_bf16")
     return out
@@ -215,7 +215,7 @@ def mlp_ln_residual_train(x, w_packed, b1, b2, gamma, beta, branch_scale=1.0, wa
     pre = torch.empty((M, 4 * C), dtype=torch.bfloat16, device=x.device) if want_pre else None
     with _timed("mlp_fused_bf16", 16.0 * M * C * C):
         _lib.check(lib.pangu_mlp_ln_residual_train_fwd_bf16(
-            _stream(), xp, ldx, _p(w_packed, "w_packed"), _p(b1, "b1", torch.float32), _p(b2, "b2", torch.float32),
+            _stream(x), xp, ldx, _p(w_packed, "w_packed"), _p(b1, "b1", torch.float32), _p(b2, "b2", torch.float32),
             _p(gamma, "gamma", torch.float32), _p(beta, "beta", torch.float32), op, ldo,
             pre.data_ptr() if want_pre else None, 4 * C, m.data_ptr(), C, M, C, float(branch_scale)),
             "mlp_ln_residual_train_fwd_bf16")
@@ -236,7 +236,7 @@ def linear_gelu_bwd(dm, w2_t, pre, want_h=True):
     chunks = _row_chunks(M, 2 * lda, 2 * N)
     for m0, m1 in (chunks or [(0, M)]):
         with _timed("linear_bf16", 2.0 * (m1 - m0) * N * K):
-            _lib.check(lib.pangu_linear_gelu_bwd_bf16(_stream(), ap + m0 * lda * 2, lda, _p(w2_t, "w2_t"),
+            _lib.check(lib.pangu_linear_gelu_bwd_bf16(_stream(dm), ap + m0 * lda * 2, lda, _p(w2_t, "w2_t"),
                                                       dpre[m0:m1].data_ptr(), N, m1 - m0, N, K, _p(pre, "pre") + m0 * N * 2,
                                                       h[m0:m1].data_ptr() if want_h else None), "linear_gelu_bwd_bf16")
     return dpre, h
@@ -249,7 +249,7 @@ def ln_residual(y, shortcut, gamma, beta, out=None, branch_scale=1.0):
     if out is None:
         out = torch.empty((N, C), dtype=torch.bfloat16, device=y.device)
     op, ldo = _rows(out, "out")
-    _lib.check(lib.pangu_ln_residual_fwd_bf16(_stream(), _p(y, "y"), sp, lds, _p(gamma, "gamma", torch.float32),
+    _lib.check(lib.pangu_ln_residual_fwd_bf16(_stream(y), _p(y, "y"), sp, lds, _p(gamma, "gamma", torch.float32),
                                               _p(beta, "beta", torch.float32), op, ldo, N, C, float(branch_scale)),
                "ln_residual_fwd_bf16")
     return out
@@ -260,7 +260,7 @@ def downsample_ln(x, gamma, beta, Z, H, W):
     xp, ldx = _rows(x, "x")
     C = x.shape[1]
     out = torch.empty((Z * ((H + 1) // 2) * (W // 2), 4 * C), dtype=torch.bfloat16, device=x.device)
-    _lib.check(lib.pangu_downsample_ln_fwd_bf16(_stream(), xp, ldx, _p(gamma, "gamma", torch.float32),
+    _lib.check(lib.pangu_downsample_ln_fwd_bf16(_stream(x), xp, ldx, _p(gamma, "gamma", torch.float32),
                                                 _p(beta, "beta", torch.float32), out.data_ptr(), Z, H, W, C),
                "downsample_ln_fwd_bf16")
     return out
@@ -270,7 +270,7 @@ def upsample_ln(y, gamma, beta, Z, H2, W2, H):
     lib = _lib.load()
     Co = y.shape[1] // 4
     out = torch.empty((Z * H * 2 * W2, Co), dtype=torch.bfloat16, device=y.device)
-    _lib.check(lib.pangu_upsample_ln_fwd_bf16(_stream(), _p(y, "y"), _p(gamma, "gamma", torch.float32),
+    _lib.check(lib.pangu_upsample_ln_fwd_bf16(_stream(y), _p(y, "y"), _p(gamma, "gamma", torch.float32),
                                               _p(beta, "beta", torch.float32), out.data_ptr(), Z, H2, W2, H, Co),
                "upsample_ln_fwd_bf16")
     return out
@@ -283,7 +283,7 @@ def patch_embed_gather(inp, inp_surface, s_mean, s_std, u_mean, u_std, maps, con
     a_s = torch.empty((H4 * W4, 128), dtype=torch.bfloat16, device=inp.device)
     a_u = torch.empty((7 * H4 * W4, 192), dtype=torch.bfloat16, device=inp.device)
     f = torch.float32
-    _lib.check(lib.pangu_patch_embed_gather_bf16(_stream(), _p(inp, "input", f), _p(inp_surface, "input_surface", f),
+    _lib.check(lib.pangu_patch_embed_gather_bf16(_stream(inp), _p(inp, "input", f), _p(inp_surface, "input_surface", f),
                                                  _p(s_mean, "s_mean", f), _p(s_std, "s_std", f), _p(u_mean, "u_mean", f),
                                                  _p(u_std, "u_std", f), _p(maps, "maps", f), _p(const_h, "const_h", f),
                                                  a_s.data_ptr(), a_u.data_ptr(), LAT, LON), "patch_embed_gather_bf16")
@@ -312,7 +312,7 @@ def linear_wgrad(dc, a, want_bias=True, db_into=None):
     db = (buf[N * K:] if own_db else db_into) if want_bias else None
     for m0, m1 in (_row_chunks(M, 2 * lddc, 2 * lda) or [(0, M)]):      # the kernel ADDS into dw / db
         with _timed("wgrad_bf16", 2.0 * (m1 - m0) * N * K):
-            _lib.check(lib.pangu_linear_wgrad_bf16_ws(_stream(), dp + m0 * lddc * 2, lddc, ap + m0 * lda * 2, lda, dw.data_ptr(),
+            _lib.check(lib.pangu_linear_wgrad_bf16_ws(_stream(dc), dp + m0 * lddc * 2, lddc, ap + m0 * lda * 2, lda, dw.data_ptr(),
                                                       db.data_ptr() if want_bias else None, m1 - m0, N, K, ws.data_ptr(),
                                                       _WGRAD_WS_BYTES), "linear_wgrad_bf16")
     return dw, db
@@ -327,7 +327,7 @@ def window_attention_bwd(qkv, qkv_bias, esb, out, lse, dout, Z, H, W, heads, shi
     desb = torch.empty(esb.shape, dtype=torch.float32, device=qkv.device) if desb_out is None else desb_out.view(esb.shape)
     Np = (Z // 2) * ((H + 5) // 6) * (W // 12) * 144
     with _timed("attn_bwd_bf16", 14.0 * Np * 144 * C):
-        _lib.check(lib.pangu_window_attn_bwd_bf16(_stream(), _p(qkv, "qkv"), _p(qkv_bias, "qkv_bias"), _p(esb, "esb"),
+        _lib.check(lib.pangu_window_attn_bwd_bf16(_stream(qkv), _p(qkv, "qkv"), _p(qkv_bias, "qkv_bias"), _p(esb, "esb"),
                                                   _p(out, "out"), _p(lse, "lse", torch.float32), _p(dout, "dout"),
                                                   dqkv.data_ptr(), dqb.data_ptr(), desb.data_ptr(), Z, H, W, C, heads,
                                                   int(shifted)), "window_attn_bwd_bf16")
@@ -340,7 +340,7 @@ def ln_residual_bwd(dout, y, gamma, branch_scale=1.0):
     dp, lddo = _rows(dout, "ln_bwd.dout")
     dy = torch.empty_like(y)
     dg, db = _zeros((2, C), y.device).unbind(0)
-    _lib.check(lib.pangu_ln_residual_bwd_bf16(_stream(), dp, lddo, _p(y, "y"), _p(gamma, "gamma", torch.float32),
+    _lib.check(lib.pangu_ln_residual_bwd_bf16(_stream(dout), dp, lddo, _p(y, "y"), _p(gamma, "gamma", torch.float32),
                                               dy.data_ptr(), dg.data_ptr(), db.data_ptr(), N, C, float(branch_scale)),
                "ln_residual_bwd_bf16")
     return dy, dg, db
@@ -352,7 +352,7 @@ def downsample_ln_bwd(dout, x, gamma, Z, H, W):
     C = x.shape[1]
     dx = torch.empty((Z * H * W, C), dtype=torch.bfloat16, device=x.device)
     dg, db = _zeros((2, 4 * C), x.device).unbind(0)
-    _lib.check(lib.pangu_downsample_ln_bwd_bf16(_stream(), _p(dout, "dout"), xp, ldx, _p(gamma, "gamma", torch.float32),
+    _lib.check(lib.pangu_downsample_ln_bwd_bf16(_stream(dout), _p(dout, "dout"), xp, ldx, _p(gamma, "gamma", torch.float32),
                                                 dx.data_ptr(), dg.data_ptr(), db.data_ptr(), Z, H, W, C),
                "downsample_ln_bwd_bf16")
     return dx, dg, db
@@ -363,7 +363,7 @@ def upsample_ln_bwd(dout, y, gamma, Z, H2, W2, H):
     Co = y.shape[1] // 4
     dy = torch.empty_like(y)
     dg, db = _zeros((2, Co), y.device).unbind(0)
-    _lib.check(lib.pangu_upsample_ln_bwd_bf16(_stream(), _p(dout, "dout"), _p(y, "y"), _p(gamma, "gamma", torch.float32),
+    _lib.check(lib.pangu_upsample_ln_bwd_bf16(_stream(dout), _p(dout, "dout"), _p(y, "y"), _p(gamma, "gamma", torch.float32),
                                               dy.data_ptr(), dg.data_ptr(), db.data_ptr(), Z, H2, W2, H, Co),
                "upsample_ln_bwd_bf16")
     return dy, dg, db
@@ -375,7 +375,7 @@ def patch_recover_gather_bwd(d_out, d_out_s):
     H4, W4 = (LAT + 3) // 4, LON // 4
     dy_u = torch.empty((7 * H4 * W4, 160), dtype=torch.bfloat16, device=d_out.device)
     dy_s = torch.empty((H4 * W4, 64), dtype=torch.bfloat16, device=d_out.device)
-    _lib.check(lib.pangu_patch_recover_gather_bwd_bf16(_stream(), _p(d_out, "d_output", torch.float32),
+    _lib.check(lib.pangu_patch_recover_gather_bwd_bf16(_stream(d_out), _p(d_out, "d_output", torch.float32),
                                                        _p(d_out_s, "d_output_surface", torch.float32), dy_u.data_ptr(),
                                                        dy_s.data_ptr(), LAT, LON), "patch_recover_gather_bwd_bf16")
     return dy_u, dy_s

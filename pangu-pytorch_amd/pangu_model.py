@@ -139,6 +139,11 @@ class PanguModel(nn.Module):
             nn.init.constant_(m.bias, 0)
             nn.init.constant_(m.weight, 1.0)
 
+    def _assert_plain_children(self):
+        """See layers.assert_plain_tree: wrappers around / hooks on sub-modules would be bypassed silently -- refuse."""
+        from .layers import assert_plain_tree
+        assert_plain_tree(self, "PanguModel")
+
     def set_constants(self, statistics, maps, const_h):
         """Register default `statistics, maps, const_h` so forward can be called with two arguments."""
         dev = next(self.parameters()).device
@@ -159,6 +164,15 @@ class PanguModel(nn.Module):
         if not (input.is_cuda and input_surface.is_cuda):
             raise RuntimeError("PanguModel (MI355X build) needs its inputs on a HIP device; there is no CPU fallback "
                                f"(got {input.device})")
+        pdev = self._input_layer.conv.weight.device
+        if ops.same_device(input, input_surface) != pdev:
+            raise RuntimeError(f"PanguModel: inputs on {input.device}, parameters on {pdev}")
+        self._assert_plain_children()
+        if input.device.index != torch.cuda.current_device():
+            # an 8-GPU node driven from one process (or a caller that never called torch.cuda.set_device): every launch of this
+            # forward goes to the INPUT's device and its current stream (ops._stream refuses anything else)
+            with torch.cuda.device(input.device):
+                return self.forward(input, input_surface, statistics, maps, const_h)
         grad_path = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         want_bf16 = self.compute_dtype == torch.bfloat16 or (
             torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16)

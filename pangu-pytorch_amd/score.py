@@ -25,7 +25,7 @@ def _sums(pred, target):
     out = torch.zeros((planes, 4), dtype=torch.float32, device=pred.device)
     w = latitude_weights(H, pred.device)
     lib = _lib.load()
-    _lib.check(lib.pangu_lat_weighted_sums(_stream(), _chk(pred.contiguous(), "pred"), _chk(target.contiguous(), "target"),
+    _lib.check(lib.pangu_lat_weighted_sums(_stream(pred), _chk(pred.contiguous(), "pred"), _chk(target.contiguous(), "target"),
                                            w.data_ptr(), out.data_ptr(), planes, H, W), "lat_weighted_sums")
     return out.view(pred.shape[:-2] + (4,)), H * W
 

@@ -48,6 +48,13 @@ class WeightedL1LossFn(torch.autograd.Function):
         from .ops import _stream
         lib = _lib.load()
         wu, ws = _weights_on(output.device, torch.float32)
+        with torch.cuda.device(output.device):
+            return WeightedL1LossFn._forward(ctx, lib, wu, ws, output, output_surface, target, target_surface)
+
+    @staticmethod
+    def _forward(ctx, lib, wu, ws, output, output_surface, target, target_surface):
+        from . import _lib
+        from .ops import _stream
         B, Vu = output.shape[0], output.shape[1]
         Vs = output_surface.shape[1]
         geom = (B, Vu, output[0, 0].numel(), Vs, output_surface[0, 0].numel())
@@ -56,7 +63,7 @@ class WeightedL1LossFn(torch.autograd.Function):
             raise RuntimeError(f"weighted_l1_loss: unsupported shapes {tuple(output.shape)} {tuple(output_surface.shape)}")
         partial = torch.empty((nblk,), dtype=torch.float32, device=output.device)
         loss = torch.empty((3,), dtype=torch.float32, device=output.device)
-        _lib.check(lib.pangu_weighted_l1_loss_fwd(_stream(), output.data_ptr(), target.data_ptr(), output_surface.data_ptr(),
+        _lib.check(lib.pangu_weighted_l1_loss_fwd(_stream(output), output.data_ptr(), target.data_ptr(), output_surface.data_ptr(),
                                                   target_surface.data_ptr(), wu.data_ptr(), ws.data_ptr(), partial.data_ptr(),
                                                   loss.data_ptr(), *geom), "weighted_l1_loss_fwd")
         ctx.save_for_backward(output, output_surface, target, target_surface)
@@ -72,7 +79,7 @@ class WeightedL1LossFn(torch.autograd.Function):
         d_o, d_os = torch.empty_like(output), torch.empty_like(output_surface)
         g = g.to(torch.float32).contiguous()
         _lib.check(_lib.load().pangu_weighted_l1_loss_bwd(
-            _stream(), output.data_ptr(), target.data_ptr(), output_surface.data_ptr(), target_surface.data_ptr(),
+            _stream(output), output.data_ptr(), target.data_ptr(), output_surface.data_ptr(), target_surface.data_ptr(),
             wu.data_ptr(), ws.data_ptr(), g.data_ptr(), d_o.data_ptr(), d_os.data_ptr(), *ctx.geom), "weighted_l1_loss_bwd")
         return d_o, d_os, None, None
 
@@ -113,13 +120,27 @@ class HipAdam(torch.optim.Optimizer):
         # value instead of the refresh launch re-reading 1.04 GB
         self._shadow_of = shadow_of
 
+    # the device job tables hold raw pointers into the optimizer state: anything that can replace state tensors drops them
+    def load_state_dict(self, state_dict):
+        self._tables = {}
+        return super().load_state_dict(state_dict)
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._tables = {}
+
+    def add_param_group(self, param_group):
+        self._tables = {}
+        return super().add_param_group(param_group)
+
     @torch.no_grad()
     def step(self, closure=None, missing_as_zero=False):
         """missing_as_zero: parameters without a gradient are stepped with a ZERO gradient (moments decay, weight decay applies)
         instead of being skipped -- what the reference's DropPath-dropped branches get (the branch is computed and multiplied by
         zero there) -- without materialising the zeros."""
-        import math
         import struct
+
+        import numpy as np
 
         from . import _lib
         from .ops import _stream
@@ -166,12 +187,17 @@ class HipAdam(torch.optim.Optimizer):
                 dev = p.device
             if not rows:
                 continue
-            bias = lambda k: (1.0 - beta1 ** k, math.sqrt(1.0 - beta2 ** k))
+            if group.get("amsgrad") or group.get("maximize"):
+                raise RuntimeError("HipAdam implements torch.optim.Adam without amsgrad / maximize (a loaded state_dict asked for them)")
+            # ATen's fused Adam (FusedAdamUtils / adam_math): bias_correction2 is rounded to float BEFORE the square root
+            bias = lambda k: (1.0 - beta1 ** k, float(np.sqrt(np.float32(1.0 - beta2 ** k))))
             uniform = all(r[6] == rows[0][6] for r in rows)
             # the table holds pointers (and per-tensor bias corrections only when the step counts differ): with gradients that keep
             # their addresses -- FlatGradSync's flat buffer, or the caching allocator handing the same blocks back every step -- it
             # is uploaded once; otherwise through pinned memory, asynchronously (no host sync in the training loop)
-            sig = tuple((r[0], r[1], r[4], r[5], 0 if uniform else r[6]) for r in rows)
+            # (the moments' addresses are part of the signature: `load_state_dict` / a rollback that replaces `exp_avg` while the
+            # parameters and the flat gradient buffer stay put must not leave the kernel updating the old, freed tensors)
+            sig = tuple((r[0], r[1], r[2], r[3], r[4], r[5], 0 if uniform else r[6]) for r in rows)
             hit = self._tables.get(gi)
             if hit is None or hit[0] != sig:
                 tab = []
@@ -186,8 +212,9 @@ class HipAdam(torch.optim.Optimizer):
                 tab.append([0, 0, 0, 0, 0, 0, 0, first])
                 hit = self._tables[gi] = (sig, torch.tensor(tab, dtype=torch.int64).pin_memory().to(dev, non_blocking=True), len(rows), first)
             b1, b2 = bias(rows[0][6])
-            _lib.check(lib.pangu_adam_step_multi(_stream(), hit[1].data_ptr(), hit[2], hit[3], float(group["lr"]), float(beta1),
-                                                 float(beta2), float(group["weight_decay"]), float(group["eps"]), b1, b2), "adam_step_multi")
+            with torch.cuda.device(dev):      # the launch goes to the parameters' device whatever the caller's current device is
+                _lib.check(lib.pangu_adam_step_multi(_stream(hit[1]), hit[1].data_ptr(), hit[2], hit[3], float(group["lr"]), float(beta1),
+                                                     float(beta2), float(group["weight_decay"]), float(group["eps"]), b1, b2), "adam_step_multi")
             for p in imaged:
                 ws.mark_fresh(p)
         return loss

@@ -1,0 +1,101 @@
+"""Host-side hardening of the drop-in boundary (no GPU): the launch-device guard and the refusal of module wrappers / hooks
+that the kernels would bypass (reference finetune/lora_tune.py:124-135 wraps `linear1`; the HIP path never calls it)."""
+import pytest
+import torch
+from torch import nn
+
+import pangu_pytorch_amd as P
+from pangu_pytorch_amd import ops
+
+
+def test_stream_guard_refuses_cpu_tensor():
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops._stream(torch.zeros(4))
+
+
+def test_stream_guard_refuses_other_device(monkeypatch):
+    """A tensor on cuda:1 while the current device is cuda:0 (an 8-GPU node driven from one process) must not be launched."""
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    with pytest.raises(RuntimeError, match="current device is cuda:0"):
+        ops._stream(torch.device("cuda", 1))
+
+
+def test_same_device():
+    a, b = torch.zeros(1), torch.zeros(1, device="meta")
+    assert ops.same_device(a, None, a) == a.device
+    with pytest.raises(RuntimeError, match="different devices"):
+        ops.same_device(a, b)
+
+
+@pytest.fixture(scope="module")
+def model():
+    return P.PanguModel()
+
+
+def test_plain_tree_passes(model):
+    model._assert_plain_children()
+    h = model.register_forward_hook(lambda *a: None)         # a hook on the model itself DOES run: allowed
+    model._assert_plain_children()
+    h.remove()
+
+
+def test_forward_hook_on_child_is_refused(model):
+    lin = model.layers[1].blocks[2].linear.linear1
+    h = lin.register_forward_hook(lambda *a: None)
+    try:
+        with pytest.raises(RuntimeError, match="forward hooks"):
+            model._assert_plain_children()
+    finally:
+        h.remove()
+    h = model.layers[0].blocks[0].attention.register_forward_pre_hook(lambda *a: None)
+    try:
+        with pytest.raises(RuntimeError, match="forward hooks"):
+            model._assert_plain_children()
+    finally:
+        h.remove()
+    model._assert_plain_children()
+
+
+class _LoraLinear(nn.Module):
+    """Shape of a peft `lora.Linear`: wraps the base layer and adds a low-rank path in ITS forward."""
+
+    def __init__(self, base, r=4):
+        super().__init__()
+        self.base_layer = base
+        self.lora_A = nn.Linear(base.in_features, r, bias=False)
+        self.lora_B = nn.Linear(r, base.out_features, bias=False)
+
+    def forward(self, x):
+        return self.base_layer(x) + self.lora_B(self.lora_A(x))
+
+
+def test_lora_style_wrapper_is_refused():
+    m = P.PanguModel()
+    att = m.layers[0].blocks[1].attention
+    att.linear1 = _LoraLinear(att.linear1)
+    with pytest.raises(RuntimeError, match="LoRA"):
+        m._assert_plain_children()
+    blk = P.layers.EarthSpecificBlock(192, 0.0, 6)
+    blk.linear.linear2 = _LoraLinear(blk.linear.linear2)
+    with pytest.raises(RuntimeError, match="EarthSpecificBlock"):
+        blk(torch.zeros(1, 8 * 181 * 12, 192), 8, 181, 12, False)
+
+
+class _MyLinear(nn.Linear):
+    def forward(self, x):
+        return super().forward(x) * 2
+
+
+def test_subclassed_linear_is_refused():
+    blk = P.layers.EarthSpecificBlock(384, 0.0, 12)
+    blk.attention.linear2 = _MyLinear(384, 384)
+    with pytest.raises(RuntimeError, match="_MyLinear"):
+        P.layers.assert_plain_tree(blk, "EarthSpecificBlock")
+
+
+def test_earth_attention_forward_refuses_autograd():
+    att = P.layers.EarthAttention3D(192, 6, 0, (2, 6, 12))
+    with pytest.raises(NotImplementedError, match="inference-only"):
+        att(torch.zeros(1, 124, 144, 192), None)
+    with torch.no_grad(), pytest.raises(RuntimeError, match="windows"):
+        att(torch.zeros(1, 100, 144, 192), None)

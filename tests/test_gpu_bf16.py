@@ -672,6 +672,14 @@ def test_full_backward_smooth_bf16_vs_reference(P, golden_dir):
     print("BF16GRAD worst mass:", masses[:4], "median", masses[len(masses) // 2][0])
     assert l2s[0][0] < BF16_GRAD_SAMPLE_TOL, l2s[0]
     assert masses[0][0] < BF16_GRAD_MASS_TOL, masses[0]
+    # the wide bound above is for the one chaotic worst tensor only: the bulk is pinned tightly -- a regression in
+    # one bias table's gradient moves these (measured: median 0.11, 90th percentile 0.19, mass median 2.1e-3)
+    srt = sorted(v for v, _ in l2s)
+    print("BF16GRAD sample rel-L2 median %.3f p90 %.3f; mass median %.2e" % (srt[len(srt) // 2], srt[int(0.9 * len(srt))],
+                                                                            sorted(v for v, _ in masses)[len(masses) // 2]))
+    assert srt[len(srt) // 2] < 0.15, srt[len(srt) // 2]
+    assert srt[int(0.9 * len(srt))] < 0.30, srt[int(0.9 * len(srt))]
+    assert sorted(v for v, _ in masses)[len(masses) // 2] < 5e-3
 
 
 @pytest.mark.parametrize("C,roll", [(192, False), (192, True), (384, False), (384, True)])

@@ -165,3 +165,19 @@ def test_oracle_forward_and_loss_vs_reference(golden_dir):
     tgt, tgt_s = cases.model_targets()
     loss = O.train_loss(out, out_s, tgt, tgt_s).item()
     assert abs(loss - float(gb["model.loss"][0])) < 1e-5 * float(gb["model.loss"][0])
+
+
+@pytest.mark.parametrize("C", [192, 384])
+@pytest.mark.parametrize("roll", [False, True])
+def test_attention_windows_golden(golden_dir, C, roll):
+    """EarthAttention3D.forward(x_window, mask) on its own (reference layers.py:360-421), every slot non-zero."""
+    g = _load(golden_dir, "attn_windows.npz")
+    st = cases.STAGES[C]
+    pre = cases.block_prefix(C, roll)
+    p = cases.block_params(C, roll)
+    xw = cases.attention_window_input(C, 2)
+    mask = O.shift_mask(st["Z"], st["H"], 24).unsqueeze(0).expand(2, -1, -1, -1) if roll else None
+    y = O.attention_windows(xw, p[pre + "attention.linear1.weight"], p[pre + "attention.linear1.bias"],
+                            p[pre + "attention.linear2.weight"], p[pre + "attention.linear2.bias"],
+                            p[pre + "attention.earth_specific_bias"], mask)
+    assert cases.compare_summary(y, g, f"attn_windows_{C}_{int(roll)}.out", FP_TOL) < FP_TOL
