@@ -68,12 +68,6 @@ int pangu_window_mask_export(pangu_stream_t stream, float* out, int Z, int H, in
 int pangu_linear_fwd(pangu_stream_t stream, const float* A, int lda, const float* W, const float* bias,
                      float* C, int ldc, int M, int N, int K, int act, float* aux);
 
-/* OPT-IN fast fp32 projection: same contract as pangu_linear_fwd (fp32 in / out / accumulate), products evaluated on
- * the bf16 matrix pipe as hi*hi + hi*lo + lo*hi of on-the-fly bf16 splits (3/16 of the exact path's matrix cycles,
- * ~1e-5 instead of ~1e-7 relative error per dot product).  K % 8 == 0.  Never the default. */
-int pangu_linear_fwd_f32x3(pangu_stream_t stream, const float* A, int lda, const float* W, const float* bias,
-                           float* C, int ldc, int M, int N, int K, int act, float* aux);
-
 /* Weight/bias gradient of a projection (autograd of the calls above; the training step of reference
  * models/pangu_sample.py:71 `loss.backward()`):
  *   dW[N,K] += dC[M,N]^T @ A[M,K]      db[N] += sum_m dC[m,:]   (db may be NULL)
@@ -228,12 +222,6 @@ int pangu_window_attn_fwd_bf16(pangu_stream_t stream, const void* qkv, const voi
 int pangu_window_attn_qkv_fwd_bf16(pangu_stream_t stream, const void* x, int ldx, const void* w_qkv, const float* b_qkv,
                                    const void* esb, void* out, float* lse, int Z, int H, int W, int C, int heads,
                                    int shifted);
-/* Training forward of the same launch: additionally writes the projected qkv (n_tok x 3C bf16, dense; channel =
- * which*C + head*32 + d, reference layers.py:368-371) and lse (n_tok x heads fp32) -- exactly what pangu_window_attn_bwd_bf16
- * reads -- so the forward needs no separate QKV GEMM and the attention core does not re-read qkv from memory. */
-int pangu_window_attn_qkv_train_fwd_bf16(pangu_stream_t stream, const void* x, int ldx, const void* w_qkv, const float* b_qkv,
-                                         const void* esb, void* out, float* lse, void* qkv_out, int Z, int H, int W, int C,
-                                         int heads, int shifted);
 
 int pangu_ln_residual_fwd_bf16(pangu_stream_t stream, const void* y, const void* shortcut, int lds, const float* gamma,
                                const float* beta, void* out, int ldo, int N, int C, float branch_scale);
@@ -255,7 +243,7 @@ int pangu_mlp_ln_residual_fwd_bf16(pangu_stream_t stream, const void* x, int ldx
                                    int C, float branch_scale);
 /* Training forward of the same branch (the bf16 counterpart of reference models/pangu_sample.py:45-77's forward through
  * layers.py:251, :264-270): as above, and the two tensors the backward needs leave from the registers they live in --
- *   pre [M][4C] bf16 (row stride ldp): x W1^T + b1 BEFORE the GELU; may be NULL (recompute mode: nothing but m is kept);
+ *   pre [M][4C] bf16 (row stride ldp): x W1^T + b1 BEFORE the GELU;
  *   m   [M][C]  bf16 (row stride ldm): GELU(pre) W2^T + b2 BEFORE the LayerNorm.
  * The hidden activation h = GELU(pre) is not stored: pangu_linear_gelu_bwd_bf16 re-creates it in the backward. */
 int pangu_mlp_ln_residual_train_fwd_bf16(pangu_stream_t stream, const void* x, int ldx, const void* w_packed,

@@ -25,7 +25,6 @@ SIGNATURES = {
     "pangu_window_index_export": [_P, _P, _I, _I, _I, _I],
     "pangu_window_mask_export": [_P, _P, _I, _I, _I],
     "pangu_linear_fwd": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "pangu_linear_fwd_f32x3": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "pangu_linear_wgrad": [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I],
     "pangu_linear_wgrad_ws": [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _P, _c.c_longlong],
     "pangu_window_attn_bwd": [_P] * 10 + [_I] * 6,
@@ -37,7 +36,6 @@ SIGNATURES = {
     "pangu_linear_fwd_bf16": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I],
     "pangu_window_attn_fwd_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I],
     "pangu_window_attn_qkv_fwd_bf16": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I],
-    "pangu_window_attn_qkv_train_fwd_bf16": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I],
     "pangu_ln_residual_fwd_bf16": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _F],
     "pangu_linear_ln_residual_fwd_bf16": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
     "pangu_mlp_ln_residual_fwd_bf16": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F],

@@ -9,60 +9,17 @@ import torch
 from . import ops
 from . import ops_bf16 as ob
 
-# MLP branch of the training forward (A/B knob PANGU_BF16_TRAIN_MLP): 0 = three launches (MLP-up + GELU writing pre AND h,
-# MLP-down, LayerNorm + residual), 1 = ONE launch that keeps the hidden activation on chip and writes only what the backward
-# needs (pre, m); the backward's data-gradient GEMM re-creates h = GELU(pre) for the W2 weight gradient, 2 = the same for
-# C = 384 only, 3 = one launch writing m only and the backward RE-RUNS the MLP-up GEMM (the reference's answer to
-# activation memory, layers.py:115-119, restricted to this branch; measured in profiles/ as the recompute A/B).
+# MLP branch of the training forward (A/B knob PANGU_BF16_TRAIN_MLP): 1 (default) = ONE launch that keeps the hidden activation on
+# chip and writes only what the backward needs (pre, m); the backward's data-gradient GEMM re-creates h = GELU(pre) for the W2
+# weight gradient.  0 = three launches (MLP-up + GELU writing pre AND h, MLP-down, LayerNorm + residual): what widths other than
+# 192 / 384 and row-strided inputs take anyway.  (Recomputing the MLP-up GEMM in the backward instead of saving `pre` -- the
+# reference's answer to activation memory, layers.py:115-119 -- measured +2.7 ms per step and was removed in round 4; so were the
+# QKV-inside-attention training forward, +0.3 ms, and weight gradients on a second stream, +0.5 ms.  DESIGN.md keeps the numbers.)
 _TRAIN_MLP = int(os.environ.get("PANGU_BF16_TRAIN_MLP", "1"))
 
 
-# Attention branch of the training forward (A/B knob PANGU_BF16_TRAIN_QKV): 1 = the QKV projection inside the attention
-# launch with qkv + lse as side outputs (no QKV GEMM launch, no re-read of qkv by the attention core), 0 (default) = QKV GEMM +
-# attention.  Measured on MI355X (interleaved, profiles/r03 notes): 49.1 vs 48.8 ms per step -- writing the 0.3-0.6 GB qkv tensor
-# from the (window, head) workgroups (8-B pieces) costs what the saved re-read gains, so the two-launch form stays.
-_TRAIN_QKV = int(os.environ.get("PANGU_BF16_TRAIN_QKV", "0"))
-
-
-# Weight gradients of a block on a SECOND stream (A/B knob PANGU_BF16_WGRAD_STREAM=1): they are off the backward's critical path
-# (dx chain), and neither they nor the data-gradient GEMMs saturate HBM or the matrix cores on their own (3.5-4 TB/s, MFMA-busy
-# 0.2-0.35), so letting the two kinds of launches share the chip can cover part of each other's latency.  Ordering: an event
-# after the producers on the main stream, a join (main waits for the side stream) before the block's gradients are returned;
-# operands are kept alive until the join; the two-stage weight-gradient workspace is per (device, stream).
-_WGRAD_STREAM = int(os.environ.get("PANGU_BF16_WGRAD_STREAM", "0"))
-_side_streams = {}
-
-
-class _WgradLane:
-    def __init__(self, device):
-        self.on = bool(_WGRAD_STREAM)
-        if self.on:
-            self.main = torch.cuda.current_stream(device)
-            self.side = _side_streams.get(device)
-            if self.side is None:
-                self.side = _side_streams[device] = torch.cuda.Stream(device)
-            self.keep = []
-
-    def wgrad(self, dc, a, want_bias=True, db_into=None):
-        if not self.on:
-            return ob.linear_wgrad(dc, a, want_bias, db_into)
-        ev = torch.cuda.Event()
-        ev.record(self.main)                    # dc, a (and the zero arena's fill) are ordered before this point
-        self.side.wait_event(ev)
-        self.keep += [dc, a]
-        with torch.cuda.stream(self.side):
-            return ob.linear_wgrad(dc, a, want_bias, db_into)
-
-    def join(self):
-        if self.on:
-            self.main.wait_stream(self.side)
-            self.keep.clear()
-
-
 def _mlp_mode(C):
-    if C not in (192, 384) or _TRAIN_MLP == 0 or (_TRAIN_MLP == 2 and C != 384):
-        return 0
-    return 3 if _TRAIN_MLP == 3 else 1
+    return 1 if (C in (192, 384) and _TRAIN_MLP != 0) else 0
 
 
 class EarthBlockFnBF16(torch.autograd.Function):
@@ -77,19 +34,15 @@ class EarthBlockFnBF16(torch.autograd.Function):
         saved = [x]
         x1 = x
         if s1 != 0.0:
-            if _TRAIN_QKV and x.shape[1] in (192, 384) and x.is_contiguous():
-                o, lse, qkv = ob.window_attention_qkv_train(x, sh.get(a1w), a1b, sh.get(esb), Z, H, W, heads, shifted)
-            else:
-                qkv = ob.linear(x, sh.get(a1w), a1b)
-                o, lse = ob.window_attention(qkv, sh.get(a1b), sh.get(esb), Z, H, W, heads, shifted, want_lse=True)
+            qkv = ob.linear(x, sh.get(a1w), a1b)
+            o, lse = ob.window_attention(qkv, sh.get(a1b), sh.get(esb), Z, H, W, heads, shifted, want_lse=True)
             y = ob.linear(o, sh.get(a2w), a2b)
             x1 = ob.ln_residual(y, x, n1w, n1b, branch_scale=s1)
             saved += [qkv, o, lse, y]
         ctx.mlp_mode = mode = _mlp_mode(x.shape[1]) if x1.is_contiguous() else 0
         if s2 != 0.0 and mode:
-            x2, pre, m = ob.mlp_ln_residual_train(x1, sh.get_mlp(m1w, m2w), m1b, m2b, n2w, n2b, branch_scale=s2,
-                                                  want_pre=mode == 1, out=out)
-            saved += [x1, m] if pre is None else [x1, pre, m]
+            x2, pre, m = ob.mlp_ln_residual_train(x1, sh.get_mlp(m1w, m2w), m1b, m2b, n2w, n2b, branch_scale=s2, out=out)
+            saved += [x1, pre, m]
         elif s2 != 0.0:
             pre = torch.empty((x.shape[0], m1w.shape[0]), dtype=torch.bfloat16, device=x.device)
             h = ob.linear(x1, sh.get(m1w), m1b, act=ob.ACT_GELU, aux=pre)
@@ -123,17 +76,12 @@ class EarthBlockFnBF16(torch.autograd.Function):
             qkv, o, lse, y = rest[:4]
             rest = rest[4:]
         g = {k: None for k in ("n1w", "n1b", "n2w", "n2b", "m1w", "m1b", "m2w", "m2b", "esb", "a1w", "a1b", "a2w", "a2b")}
-        lane = _WgradLane(dout.device)
         dqb_pad = None
         dx1 = dout
         if s2 != 0.0:
             mode = ctx.mlp_mode
             if mode == 1:
                 x1, pre, m = rest
-            elif mode == 3:                # recompute: the MLP-up GEMM again (pre AND h, as the unfused forward writes them)
-                x1, m = rest
-                pre = torch.empty((x1.shape[0], m1w.shape[0]), dtype=torch.bfloat16, device=x1.device)
-                h = ob.linear(x1, sh.get(m1w), m1b, act=ob.ACT_GELU, aux=pre)
             else:
                 x1, pre, h, m = rest
             dm, g["n2w"], g["n2b"] = ob.ln_residual_bwd(dout, m, n2w, s2)
@@ -141,9 +89,9 @@ class EarthBlockFnBF16(torch.autograd.Function):
                 dpre, h = ob.linear_gelu_bwd(dm, sh.get_t(m2w), pre)
             else:
                 dpre = ob.linear(dm, sh.get_t(m2w), None, act=ob.ACT_GELU_BWD, aux=pre)
-            g["m2w"], g["m2b"] = lane.wgrad(dm, h)
+            g["m2w"], g["m2b"] = ob.linear_wgrad(dm, h)
             del dm, h
-            g["m1w"], g["m1b"] = lane.wgrad(dpre, x1)
+            g["m1w"], g["m1b"] = ob.linear_wgrad(dpre, x1)
             if dout.is_contiguous():      # residual gradient added in the GEMM epilogue (no extra pass over N x C)
                 dx1 = ob.linear(dpre, sh.get_t(m1w), act=ob.ACT_ADD, aux=dout)
             else:
@@ -153,7 +101,7 @@ class EarthBlockFnBF16(torch.autograd.Function):
         dx = dx1
         if s1 != 0.0:
             dy, g["n1w"], g["n1b"] = ob.ln_residual_bwd(dx1, y, n1w, s1)
-            g["a2w"], g["a2b"] = lane.wgrad(dy, o)
+            g["a2w"], g["a2b"] = ob.linear_wgrad(dy, o)
             do = ob.linear(dy, sh.get_t(a2w))
             del dy
             dqkv, dqb_pad, desb = ob.window_attention_bwd(qkv, sh.get(a1b), sh.get(esb), o, lse, do, Z, H, W, heads, shifted,
@@ -162,8 +110,8 @@ class EarthBlockFnBF16(torch.autograd.Function):
             g["esb"] = desb.unsqueeze(0)
             # linear1's bias gradient = column sums of dqkv (real tokens) + the pad-slot term the attention backward already
             # accumulated into dqb_pad: the weight-gradient kernel adds its sums into that buffer
-            fuse_db = dqb_pad is not None and dqb_pad.is_contiguous() and not lane.on
-            g["a1w"], g["a1b"] = lane.wgrad(dqkv, x, db_into=dqb_pad if fuse_db else None)
+            fuse_db = dqb_pad is not None and dqb_pad.is_contiguous()
+            g["a1w"], g["a1b"] = ob.linear_wgrad(dqkv, x, db_into=dqb_pad if fuse_db else None)
             if fuse_db:
                 dqb_pad = None
             if dx1.is_contiguous():
@@ -173,7 +121,6 @@ class EarthBlockFnBF16(torch.autograd.Function):
                 dx += dx1
         elif not dx.is_contiguous():
             dx = dx.contiguous()
-        lane.join()
         if dqb_pad is not None:
             g["a1b"] += dqb_pad
         ops.fill_dropped_grads(g, {"n1w": n1w, "n1b": n1w, "n2w": n2w, "n2b": n2w, "m1w": m1w, "m1b": m1b, "m2w": m2w, "m2b": n2w,

@@ -314,20 +314,14 @@ __device__ __forceinline__ unsigned long long attn_stamp() {
 }
 #endif
 
-// BK = input channels per K-step (32: 64-byte slot rows; 64: 128-byte rows, half as many steps / barriers / DMA round trips);
-// QK_RING = 1: one slot (request, wait, compute: other workgroups cover the round trip), 2 / 3: steps requested ahead.
-// SIDE (training forward): the projected q, k, v of the window's real tokens also leave as the (tokens x 3C) tensor the
-// backward kernel reads (channel = which * C + head * 32 + d, reference layers.py:368-371) -- q and k as 8-B pieces straight
-// from the accumulators (a lane's four consecutive d of one token; the four lanes of a token make a 32-B segment), v row-wise
-// out of the transposed V image once it is complete (8 x ds_read_u16 -> one 16-B store).  Saves the separate QKV GEMM's read
-// of x and the attention kernel's re-read of qkv (3 of the 8 N*C-sized passes of the unfused pair).
-template <bool SHIFTED, int C, int QK_RING, int BK, bool SIDE>
+template <bool SHIFTED, int C>
 __global__ __launch_bounds__(192, 2) void window_attn_qkv_bf16_kernel(const u16* __restrict__ x, int ldx,
                                                                       const u16* __restrict__ wqkv,
                                                                       const float* __restrict__ bqkv,
                                                                       const u16* __restrict__ esb, u16* __restrict__ out,
                                                                       float* __restrict__ lse, WinGeom g, int n_tok,
-                                                                      int heads, int n_pairs, u16* __restrict__ qkv_out) {
+                                                                      int heads, int n_pairs) {
+  constexpr int QK_RING = 2, BK = 32;        // ring of two 32-channel K-steps (the measured winner; see launch_attn_qkv)
 #ifdef PANGU_ATTN_STAMP
   const unsigned long long st0 = attn_stamp();
 #endif
@@ -366,13 +360,11 @@ __global__ __launch_bounds__(192, 2) void window_attn_qkv_bf16_kernel(const u16*
       const_cast<u16*>(x), 0, (int)(((size_t)(n_tok - 1) * ldx + C) * sizeof(u16)), 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<u16*>(wqkv), 0, 3 * C * C * (int)sizeof(u16), 0x00020000);
-  const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      qkv_out, 0, SIDE ? (int)((size_t)n_tok * 3 * C * sizeof(u16)) : 0, 0x00020000);
 
   // ---- LDS-DMA plan: instruction q covers slot rows RPI q .. RPI q + RPI - 1 (1 KB); q < NIX the x rows, then the weight rows.
   // Wave w issues q = w, w+3, ..  This lane fills (row RPI q + lane / CH, physical chunk lane % CH) with the logical chunk
-  // (lane % CH) ^ F(row): 64-byte rows F = {0,2,3,1}[(row>>2)&3], 128-byte rows F = (row>>1)&7 (conflict-free b128 reads).
-  auto fsw = [](int row) { return BK == 32 ? ((0x78 >> (((row >> 2) & 3) * 2)) & 3) : ((row >> 1) & 7); };
+  // (lane % CH) ^ F(row), F = {0,2,3,1}[(row>>2)&3] (conflict-free b128 reads of the 64-byte rows).
+  auto fsw = [](int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; };
   unsigned voff[NIW];
 #pragma unroll
   for (int i = 0; i < NIW; ++i) {
@@ -397,8 +389,7 @@ __global__ __launch_bounds__(192, 2) void window_attn_qkv_bf16_kernel(const u16*
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, dst, 16, (int)voff[i], ks * ROWB, 0, 0);
     }
   };
-  if (QK_RING >= 2) issue(0);
-  if (QK_RING >= 3) issue(1);
+  issue(0);
 
   // the first tile's bias row and the query-token indices are requested / computed under the K-loop
   const int tile0 = 3 * wave;
@@ -426,27 +417,15 @@ __global__ __launch_bounds__(192, 2) void window_attn_qkv_bf16_kernel(const u16*
   const unsigned long long st1 = attn_stamp();
 #endif
   for (int ks = 0; ks < KS; ++ks) {
-    if (QK_RING == 1) {
-      // one slot: every wave is done reading it (barrier), request step ks, wait for it, barrier, compute
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      issue(ks);
-      wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-    } else {
-      if (QK_RING >= 3 && ks + 1 < KS) wait_vmcnt<NIW>(); else wait_vmcnt<0>();   // step ks landed (ring of 3: step ks+1 may fly)
-      // every fragment read of the previous step must have RETURNED before this wave releases the barrier: behind it the
-      // other waves re-request that ring slot, and an LDS-DMA write can overtake a ds_read that is still queued (seen on
-      // MI355X as ~1 wrong workgroup in 3000 when the compiler had sunk the last reads' wait below the barrier)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();                                // ... for every wave; the slot of step ks-1 is free
-      asm volatile("" ::: "memory");
-      if (ks + QK_RING - 1 < KS) issue(ks + QK_RING - 1);
-    }
+    wait_vmcnt<0>();                                               // step ks landed
+    // every fragment read of the previous step must have RETURNED before this wave releases the barrier: behind it the
+    // other waves re-request that ring slot, and an LDS-DMA write can overtake a ds_read that is still queued (seen on
+    // MI355X as ~1 wrong workgroup in 3000 when the compiler had sunk the last reads' wait below the barrier)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                                  // ... for every wave; the slot of step ks-1 is free
+    asm volatile("" ::: "memory");
+    if (ks + 1 < KS) issue(ks + 1);
     const unsigned char* slot = ring + (ks % QK_RING) * SLOT;
 #pragma unroll
     for (int kk = 0; kk < BK / 32; ++kk) {
@@ -491,16 +470,6 @@ __global__ __launch_bounds__(192, 2) void window_attn_qkv_bf16_kernel(const u16*
     for (int dt = 0; dt < 2; ++dt)
       *reinterpret_cast<u32x2*>(Vt + (dt * 16 + lq) * VT_LD + ((tile0 + i) * 16 + 4 * lg) * 2) =
           u32x2{pack2(acc[4 + dt][i][0], acc[4 + dt][i][1]), pack2(acc[4 + dt][i][2], acc[4 + dt][i][3])};
-    if (SIDE) {                     // q, k of token qtok[i]: d = 4lg .. 4lg+3 and 16+4lg .. (the packed registers just built)
-      const u32x4 qv = __builtin_bit_cast(u32x4, qf[i]);
-      const unsigned base = qtok[i] >= 0 ? ((unsigned)qtok[i] * (unsigned)(3 * C) + hd * 32 + 4 * lg) * 2u : 0xFFFFFFFFu;
-      __builtin_amdgcn_raw_buffer_store_b64(u32x2{qv[0], qv[1]}, s_rsrc, (int)base, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b64(u32x2{qv[2], qv[3]}, s_rsrc, (int)base, 32, 0);
-      __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(acc[2][i][0], acc[2][i][1]), pack2(acc[2][i][2], acc[2][i][3])}, s_rsrc,
-                                            (int)base, C * 2, 0);
-      __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(acc[3][i][0], acc[3][i][1]), pack2(acc[3][i][2], acc[3][i][3])}, s_rsrc,
-                                            (int)base, C * 2 + 32, 0);
-    }
   }
 
   bool zcut = false, hcut = false;
@@ -522,25 +491,6 @@ __global__ __launch_bounds__(192, 2) void window_attn_qkv_bf16_kernel(const u16*
 #ifdef PANGU_ATTN_STAMP
   const unsigned long long st3 = attn_stamp();
 #endif
-  if (SIDE) {
-    // v rows out of the transposed image: thread -> (key n, 8 consecutive d): 144 x 4 pieces over 192 threads = 3 each
-#pragma unroll
-    for (int it = 0; it < 3; ++it) {
-      const int f = threadIdx.x + 192 * it, n = f >> 2, d0 = (f & 3) * 8;
-      unsigned w[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const unsigned lo = *reinterpret_cast<const u16*>(Vt + (d0 + 2 * e) * VT_LD + n * 2);
-        const unsigned hi = *reinterpret_cast<const u16*>(Vt + (d0 + 2 * e + 1) * VT_LD + n * 2);
-        w[e] = lo | (hi << 16);
-      }
-      const int tok = win_src_token(g, l, t, n, SHIFTED);
-      const unsigned off = tok >= 0 ? ((unsigned)tok * (unsigned)(3 * C) + 2 * C + hd * 32 + d0) * 2u : 0xFFFFFFFFu;
-      __builtin_amdgcn_raw_buffer_store_b128(u32x4{w[0], w[1], w[2], w[3]}, s_rsrc, (int)off, 0, 0);
-      asm volatile("s_nop 1" ::: "memory");        // store-data WAR hazard hipcc leaves open (see mlp_fused_bf16.hip)
-    }
-  }
-
   const BiasRow b1 = load_bias_row(bias_tile, (tile0 + 1) * 16 + lq, lg);
   attn_tile<SHIFTED>(Ks, Vt, qf[0], b0, tile0 * 16 + lq, qtok[0], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
   b0 = load_bias_row(bias_tile, (tile0 + 2) * 16 + lq, lg);
@@ -555,335 +505,6 @@ __global__ __launch_bounds__(192, 2) void window_attn_qkv_bf16_kernel(const u16*
 #endif
 }
 
-
-// ---- QKV projection fused in, HG heads of a window per workgroup (round 3) -----------------------------------------------
-// window_attn_qkvg_bf16_kernel: the (window, head) kernel above with HG heads of ONE window in a workgroup of 3 HG waves
-// (wave = (head of the group, token-tile triple): the per-wave code is unchanged).  What changes is the K-step's traffic:
-// the window's x slice (9 KB of a step's 15) is requested ONCE for the HG heads instead of once per head -- 33 KB instead
-// of 60 KB per step and four heads at C = 384 (HG = 4, twelve waves, one workgroup per CU), 21 instead of 30 KB per two
-// heads at C = 192 (HG = 2, two workgroups per CU): the same twelve waves per CU as before, and the K-loop runs at the
-// rate the CU's L2 -> LDS path delivers (73 GB/s per CU measured), so fewer bytes are what shortens it.
-template <bool SHIFTED, int C, int HG>
-__global__ __launch_bounds__(192 * HG, 3) void window_attn_qkvg_bf16_kernel(const u16* __restrict__ x, int ldx,
-                                                                            const u16* __restrict__ wqkv,
-                                                                            const float* __restrict__ bqkv,
-                                                                            const u16* __restrict__ esb, u16* __restrict__ out,
-                                                                            float* __restrict__ lse, WinGeom g, int n_tok,
-                                                                            int heads) {
-  constexpr int KS = C / 32;
-  constexpr int ROWS = PANGU_WTOK + 96 * HG;         // rows of one ring slot: 144 x rows, then HG x (q | k | v) weight rows
-  constexpr int SLOT = ROWS * 64;
-  constexpr int NW = 3 * HG;                         // waves
-  constexpr int NI = ROWS / 16;                      // 1-KB LDS-DMA instructions per step (16 rows of 64 B each)
-  constexpr int NIW = (NI + NW - 1) / NW;            // ... per wave (the last round is partial)
-  constexpr int NIX = PANGU_WTOK / 16;               // the first 9 instructions carry x rows
-  constexpr int IMG = PANGU_WTOK * 64 + 32 * VT_LD;  // one head's K + V^T images
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const ring = smem;                  // 2 slots; the HG image pairs reuse the memory behind the K-loop
-
-  // blocks b, b+8, .. share an XCD: the head groups of a window back to back (x leaves HBM once), then the next longitude
-  // window of the same type (its bias tiles stay in that L2)
-  const int ng = heads / HG;
-  const int b = blockIdx.x;
-  const int xcd = b & 7, local = b >> 3;
-  const int hg = local % ng, wl = local / ng;
-  const int l = wl % g.nLon;
-  const int t = (wl / g.nLon) * 8 + xcd;
-  if (t >= g.types) return;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hsub = wave / 3, wt = wave - 3 * hsub;
-  const int hd = hg * HG + hsub;
-  const int lq = lane & 15, lg = lane >> 4;
-  const int tile0 = 3 * wt;
-  unsigned char* const Ks = smem + hsub * IMG;
-  unsigned char* const Vt = Ks + PANGU_WTOK * 64;
-  const u16* bias_tile = esb + (size_t)(t * heads + hd) * PANGU_WTOK * PANGU_WTOK;
-
-  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<u16*>(x), 0, (int)(((size_t)(n_tok - 1) * ldx + C) * sizeof(u16)), 0x00020000);
-  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<u16*>(wqkv), 0, 3 * C * C * (int)sizeof(u16), 0x00020000);
-
-  // ---- LDS-DMA plan: instruction q covers slot rows 16q .. 16q+15; wave w issues q = w, w + NW, ..; this lane fills
-  // (row 16q + lane / 4, physical chunk lane & 3) with the logical chunk (lane & 3) ^ F(row), F = {0,2,3,1}[(row >> 2) & 3]
-  auto fsw = [](int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; };
-  unsigned voff[NIW];
-#pragma unroll
-  for (int i = 0; i < NIW; ++i) {
-    const int q = wave + NW * i;
-    const int row = 16 * q + (lane >> 2);
-    const int c = (lane & 3) ^ fsw(row);
-    if (q < NIX) {
-      const int tok = win_src_token(g, l, t, row, SHIFTED);
-      voff[i] = tok >= 0 ? ((unsigned)tok * (unsigned)ldx + c * 8) * 2u : 0x7FFFFFF0u;       // pad row: out of range -> zeros
-    } else {
-      const int r = row - PANGU_WTOK, hsel = r / 96, rr = r - 96 * hsel, which = rr >> 5, d = rr & 31;
-      voff[i] = ((unsigned)(which * C + (hg * HG + hsel) * 32 + d) * (unsigned)C + c * 8) * 2u;
-    }
-  }
-  auto issue = [&](int ks) {
-    unsigned char* base = ring + (ks & 1) * SLOT;
-#pragma unroll
-    for (int i = 0; i < NIW; ++i) {
-      const int q = wave + NW * i;
-      if (q < NI) {                                          // wave-uniform
-        auto dst = (__attribute__((address_space(3))) void*)(base + q * 1024);
-        if (q < NIX) __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, dst, 16, (int)voff[i], ks * 64, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, dst, 16, (int)voff[i], ks * 64, 0, 0);
-      }
-    }
-  };
-  issue(0);
-
-  int qtok[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) qtok[i] = win_src_token(g, l, t, (tile0 + i) * 16 + lq, SHIFTED);
-
-  f32x4 acc[6][3];
-#pragma unroll
-  for (int rt = 0; rt < 4; ++rt) {
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(bqkv + (rt >> 1) * C + hd * 32 + (rt & 1) * 16 + 4 * lg);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) acc[rt][i] = bv;
-  }
-#pragma unroll
-  for (int rt = 4; rt < 6; ++rt) {
-    const float bv = bqkv[2 * C + hd * 32 + (rt - 4) * 16 + lq];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) acc[rt][i] = f32x4{bv, bv, bv, bv};
-  }
-
-  for (int ks = 0; ks < KS; ++ks) {
-    wait_vmcnt<0>();                                         // step ks landed (this wave's pieces)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // no fragment read of the slot re-requested below is still queued
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();                            // ... for every wave; the slot of step ks-1 is free
-    asm volatile("" ::: "memory");
-    if (ks + 1 < KS) issue(ks + 1);
-    const unsigned char* slot = ring + (ks & 1) * SLOT;
-    bf16x8 fx[3], fw[6];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int row = (tile0 + i) * 16 + lq;
-      fx[i] = *reinterpret_cast<const bf16x8*>(slot + row * 64 + ((lg ^ fsw(row)) << 4));
-    }
-#pragma unroll
-    for (int rt = 0; rt < 6; ++rt) {
-      const int row = PANGU_WTOK + hsub * 96 + rt * 16 + lq;
-      fw[rt] = *reinterpret_cast<const bf16x8*>(slot + row * 64 + ((lg ^ fsw(row)) << 4));
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) acc[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[rt], fx[i], acc[rt][i], 0, 0, 0);
-#pragma unroll
-      for (int rt = 4; rt < 6; ++rt) acc[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[i], fw[rt], acc[rt][i], 0, 0, 0);
-    }
-  }
-
-  // ---- q fragments (registers), K image and V^T image of this wave's head (over the ring: every wave is done reading it)
-  BiasRow b0 = load_bias_row(bias_tile, tile0 * 16 + lq, lg);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  bf16x8 qf[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    qf[i] = __builtin_bit_cast(bf16x8, u32x4{pack2(acc[0][i][0], acc[0][i][1]), pack2(acc[0][i][2], acc[0][i][3]),
-                                             pack2(acc[1][i][0], acc[1][i][1]), pack2(acc[1][i][2], acc[1][i][3])});
-    const int n = (tile0 + i) * 16 + lq;
-    *reinterpret_cast<u32x4*>(Ks + kswz(n, lg)) = u32x4{pack2(acc[2][i][0], acc[2][i][1]), pack2(acc[2][i][2], acc[2][i][3]),
-                                                        pack2(acc[3][i][0], acc[3][i][1]), pack2(acc[3][i][2], acc[3][i][3])};
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-      *reinterpret_cast<u32x2*>(Vt + (dt * 16 + lq) * VT_LD + ((tile0 + i) * 16 + 4 * lg) * 2) =
-          u32x2{pack2(acc[4 + dt][i][0], acc[4 + dt][i][1]), pack2(acc[4 + dt][i][2], acc[4 + dt][i][3])};
-  }
-  bool zcut = false, hcut = false;
-  unsigned long long kz_bits = 0ull, kh_bits = 0ull;
-  if (SHIFTED) {
-    const int zwin = t / g.nHw, hwin = t - zwin * g.nHw;
-    zcut = zwin == g.nZw - 1;
-    hcut = hwin == g.nHw - 1;
-#pragma unroll
-    for (int j = 0; j < 9; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kn = key_of(j, lg * 4 + r);
-        if (kn >= 72) kz_bits |= 1ull << (4 * j + r);
-        if (((kn / 12) % 6) < 3) kh_bits |= 1ull << (4 * j + r);
-      }
-  }
-  __syncthreads();
-  const BiasRow b1 = load_bias_row(bias_tile, (tile0 + 1) * 16 + lq, lg);
-  attn_tile<SHIFTED>(Ks, Vt, qf[0], b0, tile0 * 16 + lq, qtok[0], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
-  b0 = load_bias_row(bias_tile, (tile0 + 2) * 16 + lq, lg);
-  attn_tile<SHIFTED>(Ks, Vt, qf[1], b1, (tile0 + 1) * 16 + lq, qtok[1], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
-  attn_tile<SHIFTED>(Ks, Vt, qf[2], b0, (tile0 + 2) * 16 + lq, qtok[2], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
-}
-
-// ---- QKV projection fused in, input rows REGISTER-resident (round 3) ---------------------------------------------------
-// window_attn_qkvx_bf16_kernel: ONE workgroup per window walks ALL heads.  In the kernel above every (window, head)
-// workgroup re-fetches the window's 144 input rows (9 of the 15 KB of each K-step); the K-loop runs at the rate the CU's
-// L2 -> LDS path delivers (measured 73 GB/s per CU = the guide's gather-into-LDS figure), not at the matrix rate.  Here
-//   * the window's rows are loaded ONCE, straight from global memory in MFMA-fragment shape (wave w: token tiles 3w..3w+2,
-//     C/32 fragments each: 72 registers at C = 192, 144 at C = 384), and stay in registers over the heads;
-//   * only the head's 96 weight rows travel L2 -> LDS by LDS-DMA (6 KB per 32-channel step instead of 15), as ONE stream
-//     over (head, step): the ring keeps running under the attention tiles of the previous head, so a head's first steps
-//     have landed when its K-loop starts;
-//   * q / K / V^T images, the score tiles and the output stores are attn_tile's, unchanged.  One K/V image set: a wave can
-//     only write the next head's images behind that head's K-loop barriers, i.e. after every wave has left the previous
-//     head's tiles.
-// 256 registers per lane -> two workgroups (six waves) per CU; LDS 20 KB images + RING x 6 KB.
-constexpr int QX_WROWS = 96;                             // weight rows of one head: q | k | v, 32 each
-constexpr int QX_SLOT = QX_WROWS * 64;                   // bytes of one ring slot (32 channels)
-
-template <bool SHIFTED, int C, int RING>
-__global__ __launch_bounds__(192, 2) void window_attn_qkvx_bf16_kernel(const u16* __restrict__ x, int ldx,
-                                                                       const u16* __restrict__ wqkv,
-                                                                       const float* __restrict__ bqkv,
-                                                                       const u16* __restrict__ esb, u16* __restrict__ out,
-                                                                       float* __restrict__ lse, WinGeom g, int n_tok,
-                                                                       int heads) {
-  constexpr int KS = C / 32;
-  constexpr int NIW = 2;                                 // LDS-DMA instructions per wave and step (6 x 1 KB over 3 waves)
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const Ks = smem;                                    // [144][64 B]
-  unsigned char* const Vt = Ks + PANGU_WTOK * 64;                    // [32][VT_LD]
-  unsigned char* const ring = Vt + 32 * VT_LD;                       // RING slots of 96 rows x 64 B
-
-  // blocks b, b+8, .. share an XCD: the windows of one type run back to back there (its `heads` bias tiles stay in that L2)
-  const int b = blockIdx.x;
-  const int xcd = b & 7, local = b >> 3;
-  const int l = local % g.nLon;
-  const int t = (local / g.nLon) * 8 + xcd;
-  if (t >= g.types) return;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lq = lane & 15, lg = lane >> 4;
-  const int tile0 = 3 * wave;
-
-  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<u16*>(x), 0, (int)(((size_t)(n_tok - 1) * ldx + C) * sizeof(u16)), 0x00020000);
-  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<u16*>(wqkv), 0, 3 * C * C * (int)sizeof(u16), 0x00020000);
-
-  // ---- the window's rows: fragment (ks, i) = x[token of slot (tile0 + i) * 16 + lq][32 ks + 8 lg .. +7]; pad rows read zeros
-  int qtok[3];
-  bf16x8 fx[KS][3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    qtok[i] = win_src_token(g, l, t, (tile0 + i) * 16 + lq, SHIFTED);
-    const unsigned base = qtok[i] >= 0 ? ((unsigned)qtok[i] * (unsigned)ldx + 8 * lg) * 2u : 0x7FFFFFF0u;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-      fx[ks][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)base, ks * 64, 0));
-  }
-
-  // ---- weight stream: flat step s = hd * KS + ks -> slot s % RING.  Instruction q (1 KB) = slot rows 16q .. 16q+15; wave w
-  // issues q = w and w + 3; this lane fills (row, physical chunk lane & 3) with the logical chunk (lane & 3) ^ F(row),
-  // F = {0,2,3,1}[(row >> 2) & 3] (the conflict-free b128 fragment reads of the kernel above)
-  auto fsw = [](int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; };
-  unsigned voff[NIW];
-#pragma unroll
-  for (int i = 0; i < NIW; ++i) {
-    const int row = 16 * (wave + 3 * i) + (lane >> 2);
-    const int which = row >> 5, d = row & 31;
-    voff[i] = ((unsigned)(which * C + d) * (unsigned)C + (((lane & 3) ^ fsw(row)) * 8)) * 2u;
-  }
-  auto issue = [&](int s) {                                 // s < heads * KS
-    const int hd = s / KS, ks = s - hd * KS;
-    unsigned char* base = ring + (s % RING) * QX_SLOT;
-#pragma unroll
-    for (int i = 0; i < NIW; ++i) {
-      auto dst = (__attribute__((address_space(3))) void*)(base + (wave + 3 * i) * 1024);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, dst, 16, (int)voff[i], (hd * 32 * C + ks * 32) * 2, 0, 0);
-    }
-  };
-  const int n_steps = heads * KS;
-#pragma unroll
-  for (int s = 0; s < RING - 1; ++s) issue(s);
-
-  bool zcut = false, hcut = false;
-  unsigned long long kz_bits = 0ull, kh_bits = 0ull;
-  if (SHIFTED) {
-    const int zwin = t / g.nHw, hwin = t - zwin * g.nHw;
-    zcut = zwin == g.nZw - 1;
-    hcut = hwin == g.nHw - 1;
-#pragma unroll
-    for (int j = 0; j < 9; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kn = key_of(j, lg * 4 + r);
-        if (kn >= 72) kz_bits |= 1ull << (4 * j + r);
-        if (((kn / 12) % 6) < 3) kh_bits |= 1ull << (4 * j + r);
-      }
-  }
-
-  for (int hd = 0; hd < heads; ++hd) {
-    const u16* bias_tile = esb + (size_t)(t * heads + hd) * PANGU_WTOK * PANGU_WTOK;
-    // accumulators as in the kernel above: [rt 0,1 = q | 2,3 = k] transposed, [rt 4,5 = v]; initial value = bias
-    f32x4 acc[6][3];
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(bqkv + (rt >> 1) * C + hd * 32 + (rt & 1) * 16 + 4 * lg);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) acc[rt][i] = bv;
-    }
-#pragma unroll
-    for (int rt = 4; rt < 6; ++rt) {
-      const float bv = bqkv[2 * C + hd * 32 + (rt - 4) * 16 + lq];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) acc[rt][i] = f32x4{bv, bv, bv, bv};
-    }
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {                       // fully unrolled: fx is indexed by compile-time ks
-      const int s = hd * KS + ks;
-      if (RING >= 3 && s + 1 < n_steps) wait_vmcnt<NIW>(); else wait_vmcnt<0>();      // step s landed (this wave's pieces)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // no fragment read of the slot re-requested below is still queued
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();                         // ... for every wave; the slot of step s-1 is free
-      asm volatile("" ::: "memory");
-      if (s + RING - 1 < n_steps) issue(s + RING - 1);
-      const unsigned char* slot = ring + (s % RING) * QX_SLOT;
-      bf16x8 fw[6];
-#pragma unroll
-      for (int rt = 0; rt < 6; ++rt) {
-        const int row = rt * 16 + lq;
-        fw[rt] = *reinterpret_cast<const bf16x8*>(slot + row * 64 + ((lg ^ fsw(row)) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) acc[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[rt], fx[ks][i], acc[rt][i], 0, 0, 0);
-#pragma unroll
-        for (int rt = 4; rt < 6; ++rt) acc[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[ks][i], fw[rt], acc[rt][i], 0, 0, 0);
-      }
-    }
-    // ---- q fragments (registers), K image and V^T image (every wave is past the previous head's tiles: K-loop barriers)
-    BiasRow b0 = load_bias_row(bias_tile, tile0 * 16 + lq, lg);
-    bf16x8 qf[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      qf[i] = __builtin_bit_cast(bf16x8, u32x4{pack2(acc[0][i][0], acc[0][i][1]), pack2(acc[0][i][2], acc[0][i][3]),
-                                               pack2(acc[1][i][0], acc[1][i][1]), pack2(acc[1][i][2], acc[1][i][3])});
-      const int n = (tile0 + i) * 16 + lq;
-      *reinterpret_cast<u32x4*>(Ks + kswz(n, lg)) = u32x4{pack2(acc[2][i][0], acc[2][i][1]), pack2(acc[2][i][2], acc[2][i][3]),
-                                                          pack2(acc[3][i][0], acc[3][i][1]), pack2(acc[3][i][2], acc[3][i][3])};
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-        *reinterpret_cast<u32x2*>(Vt + (dt * 16 + lq) * VT_LD + ((tile0 + i) * 16 + 4 * lg) * 2) =
-            u32x2{pack2(acc[4 + dt][i][0], acc[4 + dt][i][1]), pack2(acc[4 + dt][i][2], acc[4 + dt][i][3])};
-    }
-    __syncthreads();
-    const BiasRow b1 = load_bias_row(bias_tile, (tile0 + 1) * 16 + lq, lg);
-    attn_tile<SHIFTED>(Ks, Vt, qf[0], b0, tile0 * 16 + lq, qtok[0], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
-    b0 = load_bias_row(bias_tile, (tile0 + 2) * 16 + lq, lg);
-    attn_tile<SHIFTED>(Ks, Vt, qf[1], b1, (tile0 + 1) * 16 + lq, qtok[1], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
-    attn_tile<SHIFTED>(Ks, Vt, qf[2], b0, (tile0 + 2) * 16 + lq, qtok[2], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
-  }
-}
 
 }  // namespace
 
@@ -906,88 +527,28 @@ extern "C" int pangu_window_attn_fwd_bf16(pangu_stream_t stream, const void* qkv
 }
 
 static int launch_attn_qkv(pangu_stream_t stream, const void* x, int ldx, const void* w_qkv, const float* b_qkv,
-                           const void* esb, void* out, float* lse, int Z, int H, int W, int C, int heads, int shifted,
-                           void* qkv_out) {
+                           const void* esb, void* out, float* lse, int Z, int H, int W, int C, int heads, int shifted) {
   if (!x || !w_qkv || !b_qkv || !esb || !out) return PANGU_E_NULL;
   if (Z <= 0 || H <= 0 || W <= 0 || Z % PANGU_WZ || (H + PANGU_PAD_H) % PANGU_WH || W % PANGU_WW) return PANGU_E_SHAPE;
   if (heads <= 0 || C != heads * PANGU_HEAD_DIM || (C != 192 && C != 384) || ldx < C || (ldx & 7)) return PANGU_E_SHAPE;
   const int n_tok = Z * H * W;
   // the pad-row sentinels of the K-loop (0x7FFFFFF0) and of the side stores must stay out of range
   if (!pangu_fits_u32(n_tok, ldx, 2) || (size_t)n_tok * ldx * 2 >= 0x7FFFFFF0ull) return PANGU_E_RANGE;
-  if (qkv_out && !pangu_fits_u32(n_tok, 3 * C, 2)) return PANGU_E_RANGE;
   const WinGeom g = make_geom(Z, H, W);
   const int n_pairs = g.types * heads;
   const int grid = ((g.types + 7) / 8) * 8 * g.nLon * heads;
-  // A/B knob PANGU_ATTN_QKV_MODE = <ring><bk/32>: 21 (default) ring of 2 x 32 channels, four workgroups per CU; 31 ring of 3;
-  // 12 one slot of 64 channels (half the steps); 22 ring of 2 x 64 channels (two workgroups per CU)
-  // PANGU_ATTN_QKV_HG=1: HG heads of a window per workgroup (4 at C = 384, 2 at C = 192: the x slice of a K-step requested
-  // once for all of them, 45 % / 30 % fewer L2 -> LDS bytes at the same twelve waves per CU).  Built and parity-tested in
-  // round 3, NOT the default: 0.247 / 0.267 ms against 0.222 / 0.242 ms at C = 384 and 0.463 / 0.481 against 0.372 / 0.352 at
-  // C = 192 (MI355X, interleaved runs) -- one barrier per K-step now couples twelve (six) waves instead of three, and the
-  // skew it adds costs more than the bytes save: the small independent (window, head) workgroups ARE the latency cover.
-  static const int hgmode = getenv("PANGU_ATTN_QKV_HG") ? atoi(getenv("PANGU_ATTN_QKV_HG")) : 0;
-  if (hgmode && !qkv_out) {
-    hipStream_t sg = (hipStream_t)stream;
-#define PANGU_QG_LAUNCH(SH, CC, HGG)                                                                                      \
-  do {                                                                                                                    \
-    constexpr size_t slot_b = (size_t)(PANGU_WTOK + 96 * HGG) * 64, img_b = (size_t)HGG * (PANGU_WTOK * 64 + 32 * VT_LD); \
-    constexpr size_t shm_g = 2 * slot_b > img_b ? 2 * slot_b : img_b;                                                     \
-    auto kern = window_attn_qkvg_bf16_kernel<SH, CC, HGG>;                                                                \
-    PANGU_ENSURE_DYN_LDS(kern, shm_g);                                                                                    \
-    const int grid_g = ((g.types + 7) / 8) * 8 * g.nLon * (heads / HGG);                                                  \
-    hipLaunchKernelGGL(kern, dim3(grid_g), dim3(192 * HGG), shm_g, sg, (const u16*)x, ldx, (const u16*)w_qkv, b_qkv,      \
-                       (const u16*)esb, (u16*)out, lse, g, n_tok, heads);                                                 \
-  } while (0)
-    if (C == 384) {
-      if (shifted) PANGU_QG_LAUNCH(true, 384, 4); else PANGU_QG_LAUNCH(false, 384, 4);
-    } else {
-      if (shifted) PANGU_QG_LAUNCH(true, 192, 2); else PANGU_QG_LAUNCH(false, 192, 2);
-    }
-#undef PANGU_QG_LAUNCH
-    return pangu_launch_status();
-  }
-  // PANGU_ATTN_QKV_X=1: the register-resident-rows kernel (one workgroup per window, all heads; ring of 3 weight slots).
-  // Built and parity-tested in round 3, NOT the default: 0.384-0.396 ms against 0.347-0.370 ms of the (window, head) kernel at
-  // C = 192 (MI355X, interleaved) although it moves 2.5x fewer bytes through the L2 -> LDS path -- 250 registers leave two
-  // workgroups (six waves) per CU instead of four (twelve), and these kernels are chains of dependent steps that only more
-  // resident waves cover (rings of 2 / 3 / 4 slots: same time).
-  static const int xmode = getenv("PANGU_ATTN_QKV_X") ? atoi(getenv("PANGU_ATTN_QKV_X")) : 0;
-  // C = 384 would need 144 (rows) + 72 (accumulators) + the score tiles' ~110 registers: it spills 60-76 registers at the
-  // 256 cap (profiles/r03 notes), so only C = 192 takes this kernel
-  if (xmode && !qkv_out && C == 192) {
-    const size_t shm_x = (size_t)PANGU_WTOK * 64 + 32 * VT_LD + (size_t)3 * QX_SLOT;
-    const int grid_x = ((g.types + 7) / 8) * 8 * g.nLon;
-    hipStream_t sx = (hipStream_t)stream;
-#define PANGU_QX_LAUNCH1(SH, CC, RG)                                                                                      \
-  do {                                                                                                                    \
-    auto kern = window_attn_qkvx_bf16_kernel<SH, CC, RG>;                                                                 \
-    PANGU_ENSURE_DYN_LDS(kern, shm_x);                                                                                    \
-    hipLaunchKernelGGL(kern, dim3(grid_x), dim3(192), shm_x, sx, (const u16*)x, ldx, (const u16*)w_qkv, b_qkv,            \
-                       (const u16*)esb, (u16*)out, lse, g, n_tok, heads);                                                 \
-  } while (0)
-    if (shifted) PANGU_QX_LAUNCH1(true, 192, 3); else PANGU_QX_LAUNCH1(false, 192, 3);
-#undef PANGU_QX_LAUNCH1
-    return pangu_launch_status();
-  }
-  static const int mode = getenv("PANGU_ATTN_QKV_MODE") ? atoi(getenv("PANGU_ATTN_QKV_MODE")) : 21;
-  const int ring = qkv_out ? 2 : mode / 10, bk = qkv_out ? 32 : (mode % 10) * 32;      // the training forward: default pipeline only
-  if ((ring != 1 && ring != 2 && ring != 3) || (bk != 32 && bk != 64) || (ring == 3 && bk == 64) || (ring == 1 && bk == 32)) return PANGU_E_ARG;
-  const size_t shm = (size_t)ring * QK_SLOT * (bk / 32);                          // >= the K + V^T images (19968 B) that reuse it
+  // ring of 2 x 32 channels, four workgroups per CU.  Measured and removed (round 4; DESIGN.md keeps the numbers): ring of 3 (three
+  // workgroups per CU, -5 %), one slot of 64 channels (+-1 %), ring of 2 x 64 channels (two workgroups per CU, -20 %), HG heads of a
+  // window per workgroup sharing the x slice (-10..-30 %), window rows register-resident with the heads looped (-8 %), and the
+  // training variant with qkv + lse side outputs (+0.3 ms per step): resident workgroups decide, not the pipeline inside one.
+  const size_t shm = (size_t)2 * QK_SLOT;                          // >= the K + V^T images (19968 B) that reuse it
   hipStream_t s = (hipStream_t)stream;
-#define PANGU_QKV_LAUNCH1(SH, CC, RG, BKK, SD)                                                                            \
-  do {                                                                                                                    \
-    auto kern = window_attn_qkv_bf16_kernel<SH, CC, RG, BKK, SD>;                                                         \
-    PANGU_ENSURE_DYN_LDS(kern, shm);                                                                                      \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(192), shm, s, (const u16*)x, ldx, (const u16*)w_qkv, b_qkv,                 \
-                       (const u16*)esb, (u16*)out, lse, g, n_tok, heads, n_pairs, (u16*)qkv_out);                         \
-  } while (0)
 #define PANGU_QKV_LAUNCH(SH, CC)                                                                                          \
   do {                                                                                                                    \
-    if (qkv_out) PANGU_QKV_LAUNCH1(SH, CC, 2, 32, true);              /* training forward: the default pipeline only */   \
-    else if (mode == 31) PANGU_QKV_LAUNCH1(SH, CC, 3, 32, false);                                                         \
-    else if (mode == 12) PANGU_QKV_LAUNCH1(SH, CC, 1, 64, false);                                                         \
-    else if (mode == 22) PANGU_QKV_LAUNCH1(SH, CC, 2, 64, false);                                                         \
-    else PANGU_QKV_LAUNCH1(SH, CC, 2, 32, false);                                                                         \
+    auto kern = window_attn_qkv_bf16_kernel<SH, CC>;                                                                      \
+    PANGU_ENSURE_DYN_LDS(kern, shm);                                                                                      \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(192), shm, s, (const u16*)x, ldx, (const u16*)w_qkv, b_qkv,                 \
+                       (const u16*)esb, (u16*)out, lse, g, n_tok, heads, n_pairs);                                        \
   } while (0)
   if (C == 192) {
     if (shifted) PANGU_QKV_LAUNCH(true, 192); else PANGU_QKV_LAUNCH(false, 192);
@@ -995,22 +556,13 @@ static int launch_attn_qkv(pangu_stream_t stream, const void* x, int ldx, const 
     if (shifted) PANGU_QKV_LAUNCH(true, 384); else PANGU_QKV_LAUNCH(false, 384);
   }
 #undef PANGU_QKV_LAUNCH
-#undef PANGU_QKV_LAUNCH1
   return pangu_launch_status();
 }
 
 extern "C" int pangu_window_attn_qkv_fwd_bf16(pangu_stream_t stream, const void* x, int ldx, const void* w_qkv,
                                               const float* b_qkv, const void* esb, void* out, float* lse, int Z, int H, int W,
                                               int C, int heads, int shifted) {
-  return launch_attn_qkv(stream, x, ldx, w_qkv, b_qkv, esb, out, lse, Z, H, W, C, heads, shifted, nullptr);
-}
-
-// Training forward: as above, and the projected qkv (n_tok x 3C bf16, dense) + lse leave too (what pangu_window_attn_bwd_bf16 reads).
-extern "C" int pangu_window_attn_qkv_train_fwd_bf16(pangu_stream_t stream, const void* x, int ldx, const void* w_qkv,
-                                                    const float* b_qkv, const void* esb, void* out, float* lse, void* qkv_out,
-                                                    int Z, int H, int W, int C, int heads, int shifted) {
-  if (!qkv_out || !lse) return PANGU_E_NULL;
-  return launch_attn_qkv(stream, x, ldx, w_qkv, b_qkv, esb, out, lse, Z, H, W, C, heads, shifted, qkv_out);
+  return launch_attn_qkv(stream, x, ldx, w_qkv, b_qkv, esb, out, lse, Z, H, W, C, heads, shifted);
 }
 
 #ifdef PANGU_ATTN_STAMP

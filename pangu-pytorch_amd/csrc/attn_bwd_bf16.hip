@@ -1,12 +1,9 @@
 // Backward of the Earth-specific window attention, bf16 operands / fp32 softmax + accumulation, gfx950.
 //
 // Same decomposition as attn_bwd_f32.hip: one 9-wave workgroup per (window type, head) walks the longitude windows and
-// keeps d_esb[t][head] = sum_l dS in registers; wave w owns query tile w (dQ, d_esb; scores as S^T) and key tile w
-// (dK, dV; scores as S), so every accumulator is directly the operand of the next v_mfma_f32_16x16x32_bf16.
-// A 16x16 score tile is ONE MFMA (K = head_dim = 32); products that contract over tokens take two adjacent tiles'
-// accumulator quads as one 8-element operand (k index permuted identically on both sides) against TRANSPOSED
-// token-major images K^T, Q^T, dO^T ([32 d][160 tokens], 336-B rows) that the staging pass writes next to the
-// row-major ones.  66 MFMAs per wave and window: the kernel is bound by the exp/softmax VALU work and HBM.
+// keeps d_esb[t][head] = sum_l dS in registers.  A 16x16 score tile is ONE v_mfma_f32_16x16x32_bf16 (K = head_dim = 32).  The
+// kernel below computes the scores in ONE orientation (see its header comment); the round-1 kernel (both orientations, transposed
+// token-major LDS copies, 66 instead of 48 MFMAs per wave and window: 0.86 vs 0.60 ms at C = 192) was removed in round 4.
 #include "common.h"
 #include <stdlib.h>
 
@@ -17,9 +14,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16;
 
 constexpr int NW = 9, NT = NW * 64;
-constexpr int T_LD = 336;                      // bytes per row of a transposed image (160 tokens + pad)
 constexpr int ROWIMG = PANGU_WTOK * 64;        // bytes of a row-major [144][32] bf16 image
-constexpr int TIMG = 32 * T_LD;
 
 __device__ inline u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
 __device__ inline unsigned pack2(float a, float b) { return pack_bf16x2(a, b); }
@@ -44,255 +39,6 @@ __device__ inline int kswz(int row, int chunk) {
 __device__ inline bf16x8 pack8(const f32x4& a, const f32x4& b) {
   return __builtin_bit_cast(bf16x8, u32x4{pack2(a[0], a[1]), pack2(a[2], a[3]), pack2(b[0], b[1]), pack2(b[2], b[3])});
 }
-// 8-token fragment of a transposed image: tokens {32u + 4lg + e} and {32u + 16 + 4lg + e}, e = 0..3, of row `row`
-__device__ inline bf16x8 tfrag(const unsigned char* img, int row, int u, int lg) {
-  const unsigned char* p = img + row * T_LD + (32 * u + 4 * lg) * 2;
-  const u32x2 a = *reinterpret_cast<const u32x2*>(p);
-  const u32x2 b = *reinterpret_cast<const u32x2*>(p + 32);
-  return __builtin_bit_cast(bf16x8, u32x4{a[0], a[1], b[0], b[1]});
-}
-
-template <bool SHIFTED>
-__global__ __launch_bounds__(NT) void window_attn_bwd_bf16_kernel(
-    const u16* __restrict__ qkv, const u16* __restrict__ qkv_bias, const u16* __restrict__ esb,
-    const u16* __restrict__ out, const float* __restrict__ lse, const u16* __restrict__ dout, u16* __restrict__ dqkv,
-    float* __restrict__ dqkv_bias, float* __restrict__ d_esb, WinGeom g, int C, int heads) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* Kr = smem;
-  unsigned char* Vr = Kr + ROWIMG;
-  unsigned char* Qr = Vr + ROWIMG;
-  unsigned char* Gr = Qr + ROWIMG;
-  unsigned char* Kt = Gr + ROWIMG;
-  unsigned char* Qt = Kt + TIMG;
-  unsigned char* Gt = Qt + TIMG;
-  float* lse_s = reinterpret_cast<float*>(Gt + TIMG);
-  float* del_s = lse_s + PANGU_WTOK;
-  int* tok_s = reinterpret_cast<int*>(del_s + PANGU_WTOK);
-  float* pad_s = reinterpret_cast<float*>(tok_s + PANGU_WTOK);     // [2][32]: dK, dV summed over the zero-pad keys
-  u16* Bs = reinterpret_cast<u16*>(pad_s + 64);                    // [144][144] bf16 bias tile (window-invariant)
-
-  // the two heads sharing each token's 128-B line (a bf16 head slice is 64 B) run side by side on ONE XCD (blocks b and
-  // b+8 share an L2) and walk the longitude windows together: the second head's reads / writes hit that L2
-  int pair = blockIdx.x;
-  if (!(heads & 1)) {
-    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-    pair = 2 * ((local >> 1) * 8 + xcd) + (local & 1);
-  }
-  if (pair >= g.types * heads) return;
-  const int t = pair / heads, hd = pair - t * heads;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lq = lane & 15, lg = lane >> 4;
-  const int C3 = 3 * C;
-  const float scale = 0.17677669529663687f;
-  constexpr float K_LOG2E = 1.4426950408889634f;
-  const float scale2 = scale * K_LOG2E;
-  constexpr float K_MASK2 = -100.0f * K_LOG2E;
-  const u16* bias_tile = esb + (size_t)pair * PANGU_WTOK * PANGU_WTOK;
-
-  bool zcut = false, hcut = false;
-  if (SHIFTED) {
-    const int zwin = t / g.nHw, hwin = t - zwin * g.nHw;
-    zcut = zwin == g.nZw - 1;
-    hcut = hwin == g.nHw - 1;
-  }
-  auto masked = [&](int nq, int nk) -> bool {
-    const bool zd = (nq >= 72) != (nk >= 72);
-    const bool hdiff = (((nq / 12) % 6) < 3) != (((nk / 12) % 6) < 3);
-    return (zcut && zd) || (hcut && hdiff);
-  };
-
-  // zero the 16 pad tokens (144..159) of the three transposed images once: they meet zero probabilities but must be finite
-  for (int i = tid; i < 3 * 32 * 2; i += NT) {
-    const int img = i / 64, row = (i >> 1) & 31, half = i & 1;
-    *reinterpret_cast<u32x4*>(Kt + img * TIMG + row * T_LD + 288 + 16 * half) = u32x4{0u, 0u, 0u, 0u};
-  }
-
-  if (tid < 64) pad_s[tid] = 0.f;
-  for (int i = tid; i < PANGU_WTOK * PANGU_WTOK / 8; i += NT)
-    reinterpret_cast<u32x4*>(Bs)[i] = reinterpret_cast<const u32x4*>(bias_tile)[i];
-
-  f32x4 dbias[9];
-#pragma unroll
-  for (int j = 0; j < 9; ++j) dbias[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  for (int l = 0; l < g.nLon; ++l) {
-    __syncthreads();
-    int lz = 0;
-    asm volatile("" : "+v"(lz));                  // keep the (window-invariant) bias reads inside the loop
-    const u16* bias_l = Bs + lz;
-    if (tid < PANGU_WTOK) tok_s[tid] = win_src_token(g, l, t, tid, SHIFTED);
-    __syncthreads();
-    // ---- stage: one 16-B chunk (8 dims) of q, k, v, dO, O per thread
-    {
-      const int n = tid >> 2, ch = tid & 3;
-      const int tok = tok_s[n];
-      const u16* src = tok >= 0 ? qkv + (size_t)tok * C3 : qkv_bias;
-      const u32x4 qv = *reinterpret_cast<const u32x4*>(src + hd * 32 + ch * 8);
-      const u32x4 kv = *reinterpret_cast<const u32x4*>(src + C + hd * 32 + ch * 8);
-      const u32x4 vv = *reinterpret_cast<const u32x4*>(src + 2 * C + hd * 32 + ch * 8);
-      u32x4 gv = {0u, 0u, 0u, 0u}, ov = {0u, 0u, 0u, 0u};
-      if (tok >= 0) {
-        gv = *reinterpret_cast<const u32x4*>(dout + (size_t)tok * C + hd * 32 + ch * 8);
-        ov = *reinterpret_cast<const u32x4*>(out + (size_t)tok * C + hd * 32 + ch * 8);
-      }
-      const int ro = kswz(n, ch);
-      *reinterpret_cast<u32x4*>(Qr + ro) = qv;
-      *reinterpret_cast<u32x4*>(Kr + ro) = kv;
-      *reinterpret_cast<u32x4*>(Vr + ro) = vv;
-      *reinterpret_cast<u32x4*>(Gr + ro) = gv;
-      float d = 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int d0 = (ch * 8 + 2 * e) * T_LD + n * 2;
-        *reinterpret_cast<u16*>(Kt + d0) = (u16)(kv[e] & 0xFFFFu);
-        *reinterpret_cast<u16*>(Kt + d0 + T_LD) = (u16)(kv[e] >> 16);
-        *reinterpret_cast<u16*>(Qt + d0) = (u16)(qv[e] & 0xFFFFu);
-        *reinterpret_cast<u16*>(Qt + d0 + T_LD) = (u16)(qv[e] >> 16);
-        *reinterpret_cast<u16*>(Gt + d0) = (u16)(gv[e] & 0xFFFFu);
-        *reinterpret_cast<u16*>(Gt + d0 + T_LD) = (u16)(gv[e] >> 16);
-        d += bflo(gv[e]) * bflo(ov[e]) + bfhi(gv[e]) * bfhi(ov[e]);
-      }
-      d += __shfl_xor(d, 1, 64);
-      d += __shfl_xor(d, 2, 64);
-      if (ch == 0) {
-        // row constants in the form the score epilogue consumes: p = exp2(S*scale*log2e + b*log2e - lse*log2e) and
-        // dS = p * (dP - delta) with -delta as the INITIAL ACCUMULATOR of the dP product
-        del_s[n] = -d;
-        lse_s[n] = tok >= 0 ? -K_LOG2E * lse[(size_t)tok * heads + hd] : -1e30f;     // pad query: p = exp2(-huge) = 0
-      }
-    }
-    __syncthreads();
-
-    // =========================== phase A: query tile `wave`, S^T orientation ===========================
-    {
-      const int qn = wave * 16 + lq;
-      const int qtok = tok_s[qn];
-      const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qr + kswz(qn, lg));
-      const bf16x8 gf = *reinterpret_cast<const bf16x8*>(Gr + kswz(qn, lg));
-      const float nl2 = lse_s[qn], nl2m = nl2 + K_MASK2;          // -lse*log2e (and with the -100 mask folded in)
-      const float nd = del_s[qn];
-      const f32x4 ndel = {nd, nd, nd, nd};
-      const u16* brow = bias_l + (size_t)qn * PANGU_WTOK + lg * 4;
-      f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
-      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int u = 0; u < 5; ++u) {
-        __builtin_amdgcn_sched_barrier(0);
-        f32x4 dsp[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int j = 2 * u + h;
-          dsp[h] = zero;
-          if (j < 9) {
-            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kr + kswz(j * 16 + lq, lg));
-            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vr + kswz(j * 16 + lq, lg));
-            const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, zero, 0, 0, 0);
-            const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, gf, ndel, 0, 0, 0);     // dP - delta
-            const u32x2 bq = *reinterpret_cast<const u32x2*>(brow + j * 16);
-            const float bb[4] = {bflo(bq[0]), bfhi(bq[0]), bflo(bq[1]), bfhi(bq[1])};
-            float c = nl2;                  // the 4 keys of a lane share the mask (cuts fall on multiples of 12 and at 72)
-            if (SHIFTED) { if (masked(qn, j * 16 + lg * 4)) c = nl2m; }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float p = __builtin_amdgcn_exp2f(fmaf(s[r], scale2, fmaf(bb[r], K_LOG2E, c)));
-              dsp[h][r] = p * dp[r];
-            }
-            dbias[j] += dsp[h];
-          }
-        }
-        // dQ^T[d][query] += K^T[d][keys of tiles 2u, 2u+1] . dS^T
-        const bf16x8 dsf = pack8(dsp[0], dsp[1]);
-        dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(Kt, lq, u, lg), dsf, dq0, 0, 0, 0);
-        dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(Kt, 16 + lq, u, lg), dsf, dq1, 0, 0, 0);
-      }
-      if (qtok >= 0) {        // lane: dQ^T[d = 16dt + 4lg + r][query qn]
-        u16* dst = dqkv + (size_t)qtok * C3 + hd * 32 + lg * 4;
-        *reinterpret_cast<u32x2*>(dst) = u32x2{pack2(dq0[0] * scale, dq0[1] * scale), pack2(dq0[2] * scale, dq0[3] * scale)};
-        *reinterpret_cast<u32x2*>(dst + 16) = u32x2{pack2(dq1[0] * scale, dq1[1] * scale), pack2(dq1[2] * scale, dq1[3] * scale)};
-      }
-    }
-
-    // =========================== phase B: key tile `wave`, S orientation ===========================
-    {
-      const int kn = wave * 16 + lq;
-      const int ktok = tok_s[kn];
-      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kr + kswz(kn, lg));
-      const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vr + kswz(kn, lg));
-      f32x4 dv0 = {0.f, 0.f, 0.f, 0.f}, dv1 = dv0, dk0 = dv0, dk1 = dv0;
-      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-      for (int u = 0; u < 5; ++u) {
-        f32x4 pp[2], dsp[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int i = 2 * u + h;
-          pp[h] = zero; dsp[h] = zero;
-          if (i < 9) {
-            const bf16x8 af = *reinterpret_cast<const bf16x8*>(Qr + kswz(i * 16 + lq, lg));
-            const bf16x8 bf = *reinterpret_cast<const bf16x8*>(Gr + kswz(i * 16 + lq, lg));
-            const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, kf, zero, 0, 0, 0);     // S[query 4lg+r][key lq]
-            const f32x4 dl = *reinterpret_cast<const f32x4*>(&del_s[i * 16 + lg * 4]);      // -delta
-            const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, vf, dl, 0, 0, 0);      // dP - delta
-            const f32x4 ls = *reinterpret_cast<const f32x4*>(&lse_s[i * 16 + lg * 4]);      // -lse*log2e
-            float cm = 0.f;                 // the 4 queries of a lane share the mask
-            if (SHIFTED) { if (masked(i * 16 + lg * 4, kn)) cm = K_MASK2; }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int qn = i * 16 + lg * 4 + r;
-              const float p = __builtin_amdgcn_exp2f(
-                  fmaf(s[r], scale2, fmaf(bf1(bias_l[(size_t)qn * PANGU_WTOK + kn]), K_LOG2E, ls[r] + cm)));
-              pp[h][r] = p;
-              dsp[h][r] = p * dp[r];
-            }
-          }
-        }
-        // dV^T[d][key] += dO^T[d][queries] . P ;  dK^T[d][key] += Q^T[d][queries] . dS   (queries of tiles 2u, 2u+1)
-        const bf16x8 pf = pack8(pp[0], pp[1]);
-        const bf16x8 dsf = pack8(dsp[0], dsp[1]);
-        dv0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(Gt, lq, u, lg), pf, dv0, 0, 0, 0);
-        dv1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(Gt, 16 + lq, u, lg), pf, dv1, 0, 0, 0);
-        dk0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(Qt, lq, u, lg), dsf, dk0, 0, 0, 0);
-        dk1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(Qt, 16 + lq, u, lg), dsf, dk1, 0, 0, 0);
-      }
-      // lane: dK^T / dV^T [d = 16dt + 4lg + r][key kn]
-      dk0 *= scale; dk1 *= scale;
-      if (ktok >= 0) {
-        u16* dst = dqkv + (size_t)ktok * C3 + hd * 32 + lg * 4;
-        *reinterpret_cast<u32x2*>(dst + C) = u32x2{pack2(dk0[0], dk0[1]), pack2(dk0[2], dk0[3])};
-        *reinterpret_cast<u32x2*>(dst + C + 16) = u32x2{pack2(dk1[0], dk1[1]), pack2(dk1[2], dk1[3])};
-        *reinterpret_cast<u32x2*>(dst + 2 * C) = u32x2{pack2(dv0[0], dv0[1]), pack2(dv0[2], dv0[3])};
-        *reinterpret_cast<u32x2*>(dst + 2 * C + 16) = u32x2{pack2(dv1[0], dv1[1]), pack2(dv1[2], dv1[3])};
-      }
-      // zero-pad keys all carry linear1.bias: their gradients are summed (lanes of a pad key, then LDS, then ONE
-      // global atomic per value at the end) instead of 64 same-address global atomics per pad key and window
-      if (__any(ktok < 0)) {
-        const float keep = ktok < 0 ? 1.f : 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float a0 = dk0[r] * keep, a1 = dk1[r] * keep, b0 = dv0[r] * keep, b1 = dv1[r] * keep;
-#pragma unroll
-          for (int o = 1; o < 16; o <<= 1) {
-            a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64);
-            b0 += __shfl_xor(b0, o, 64); b1 += __shfl_xor(b1, o, 64);
-          }
-          if (lq == 0) {
-            atomicAdd(&pad_s[lg * 4 + r], a0);
-            atomicAdd(&pad_s[16 + lg * 4 + r], a1);
-            atomicAdd(&pad_s[32 + lg * 4 + r], b0);
-            atomicAdd(&pad_s[48 + lg * 4 + r], b1);
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (tid < 64 && pad_s[tid] != 0.f) atomicAdd(dqkv_bias + (tid < 32 ? C : 2 * C) + hd * 32 + (tid & 31), pad_s[tid]);
-  float* drow = d_esb + (size_t)pair * PANGU_WTOK * PANGU_WTOK + (size_t)(wave * 16 + lq) * PANGU_WTOK + lg * 4;
-#pragma unroll
-  for (int j = 0; j < 9; ++j) *reinterpret_cast<f32x4*>(drow + j * 16) = dbias[j];
-}
-
-
 // ===================================================================================================================
 // v2 (round 2): ONE score orientation.  Wave w owns KEY tile w in phase 1: S = Q K^T and dP = dO V^T with the key on
 // the lane, so P and dS (two adjacent query tiles' accumulator quads = one 8-token operand) feed dV^T += dO^T P and
@@ -678,33 +424,17 @@ extern "C" int pangu_window_attn_bwd_bf16(pangu_stream_t stream, const void* qkv
   if ((size_t)Z * H * W * 3 * C * sizeof(u16) >= 0x7FFFFFF0ull) return PANGU_E_RANGE;
   const WinGeom g = make_geom(Z, H, W);
   const int n_pairs = (heads & 1) ? g.types * heads : ((g.types * heads / 2 + 7) / 8) * 16;    // padded to whole XCD rounds
-  const size_t shm = 4 * (size_t)ROWIMG + 3 * (size_t)TIMG + 3 * PANGU_WTOK * sizeof(float) + 64 * sizeof(float) +
-                     (size_t)PANGU_WTOK * PANGU_WTOK * sizeof(u16);
   hipStream_t s = (hipStream_t)stream;
-  static const int version = [] { const char* e = getenv("PANGU_ATTN_BWD_V"); return e ? atoi(e) : 2; }();
-  if (version == 2) {
-    const size_t shm2 = L_END;
-    PANGU_ENSURE_DYN_LDS(window_attn_bwd2_bf16_kernel<true>, shm2);
-    PANGU_ENSURE_DYN_LDS(window_attn_bwd2_bf16_kernel<false>, shm2);
-    if (shifted)
-      hipLaunchKernelGGL(window_attn_bwd2_bf16_kernel<true>, dim3(n_pairs), dim3(NT), shm2, s, (const u16*)qkv,
-                         (const u16*)qkv_bias, (const u16*)esb, (const u16*)out, lse, (const u16*)dout, (u16*)dqkv,
-                         dqkv_bias, d_esb, g, C, heads);
-    else
-      hipLaunchKernelGGL(window_attn_bwd2_bf16_kernel<false>, dim3(n_pairs), dim3(NT), shm2, s, (const u16*)qkv,
-                         (const u16*)qkv_bias, (const u16*)esb, (const u16*)out, lse, (const u16*)dout, (u16*)dqkv,
-                         dqkv_bias, d_esb, g, C, heads);
-    return pangu_launch_status();
-  }
-  PANGU_ENSURE_DYN_LDS(window_attn_bwd_bf16_kernel<true>, shm);
-  PANGU_ENSURE_DYN_LDS(window_attn_bwd_bf16_kernel<false>, shm);
+  const size_t shm2 = L_END;
+  PANGU_ENSURE_DYN_LDS(window_attn_bwd2_bf16_kernel<true>, shm2);
+  PANGU_ENSURE_DYN_LDS(window_attn_bwd2_bf16_kernel<false>, shm2);
   if (shifted)
-    hipLaunchKernelGGL(window_attn_bwd_bf16_kernel<true>, dim3(n_pairs), dim3(NT), shm, s, (const u16*)qkv,
-                       (const u16*)qkv_bias, (const u16*)esb, (const u16*)out, lse, (const u16*)dout, (u16*)dqkv, dqkv_bias,
-                       d_esb, g, C, heads);
+    hipLaunchKernelGGL(window_attn_bwd2_bf16_kernel<true>, dim3(n_pairs), dim3(NT), shm2, s, (const u16*)qkv,
+                       (const u16*)qkv_bias, (const u16*)esb, (const u16*)out, lse, (const u16*)dout, (u16*)dqkv,
+                       dqkv_bias, d_esb, g, C, heads);
   else
-    hipLaunchKernelGGL(window_attn_bwd_bf16_kernel<false>, dim3(n_pairs), dim3(NT), shm, s, (const u16*)qkv,
-                       (const u16*)qkv_bias, (const u16*)esb, (const u16*)out, lse, (const u16*)dout, (u16*)dqkv, dqkv_bias,
-                       d_esb, g, C, heads);
+    hipLaunchKernelGGL(window_attn_bwd2_bf16_kernel<false>, dim3(n_pairs), dim3(NT), shm2, s, (const u16*)qkv,
+                       (const u16*)qkv_bias, (const u16*)esb, (const u16*)out, lse, (const u16*)dout, (u16*)dqkv,
+                       dqkv_bias, d_esb, g, C, heads);
   return pangu_launch_status();
 }

@@ -1,20 +1,12 @@
-// Backward of the Earth-specific window attention, fp32, gfx950.
+// Backward of the Earth-specific window attention, fp32, gfx950 (the single-score-orientation kernel, `v2` below).
 //
 // One workgroup of 12 waves (9 tile owners + 3 helpers) per (window type t, head); it walks the nLon longitude windows
-// that share the bias tile esb[t][head], so the bias gradient d_esb[t][head] = sum_l dS stays in registers (36 per
-// owner wave) and is written once: no atomics, no (..,144,144) tensor in HBM.
-// Per window, Q(scaled), K, V, dO (144 x 32 each) are staged in LDS; P is recomputed from the saved
-// log-sum-exp.  Wave w owns QUERY tile w for {dQ, d_esb} and KEY tile w for {dK, dV}; the scores are computed in
-// both orientations (S^T for the first, S for the second) so that every probability / dS accumulator is
-// directly an MFMA operand of the next product (no LDS transposes, no cross-wave reductions):
-//   phase A (S^T[key][query], query tile w):  dP^T = V dO^T,  dS^T = P^T o (dP^T - delta),  dQ^T = K^T dS^T
-//   phase B (S[query][key],  key tile w):     dP = dO V^T,    dS = P o (dP - delta),  dV = P^T dO,  dK = dS^T Qs
-// 504 v_mfma_f32_16x16x4_f32 per key/query tile and window.  The workgroup is alone on its CU, and nine waves would sit
-// 3/2/2/2 on the four SIMDs with the full one setting the pace of every window: three helper waves take the last four
-// query tiles of every key tile's phase B (partial dK/dV handed back through LDS), so that each SIMD runs three waves
-// of 376-384 MFMAs (+20 % unshifted).  The shift mask is window-invariant and constant over the 4 tokens a lane holds
-// per tile: one bit per tile, built once before the window loop (+38 % shifted).  Zero-pad slots (q/k/v = linear1.bias) send their k/v gradient
-// to dqkv_bias with atomics (2.7 % of slots); every real token row of dqkv is written exactly once.
+// that share the bias tile esb[t][head], so the bias gradient d_esb[t][head] = sum_l dS stays in registers and is written
+// once: no atomics, no (..,144,144) tensor in HBM.  P is recomputed from the saved log-sum-exp.  The shift mask is
+// window-invariant and constant over the 4 tokens a lane holds per tile: one bit per tile, built once before the window loop.
+// Zero-pad slots (q/k/v = linear1.bias) send their k/v gradient to dqkv_bias with atomics (2.7 % of slots); every real token
+// row of dqkv is written exactly once.  (The round-1 kernel, which computed the scores in both orientations -- 56 instead of 40
+// MFMAs per 16x16 tile pair, 2.36 vs 1.93 ms per launch at C = 192 -- was removed in round 4; DESIGN.md keeps its measurements.)
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -25,7 +17,6 @@ constexpr int KV_LD = 36;
 constexpr int NQ = 9;                      // query tiles = key tiles (16 tokens each)
 constexpr int NW = 12;                     // waves per workgroup: 9 tile owners + 3 helpers (three waves on every SIMD)
 constexpr int NT = NW * 64;
-constexpr int I_SPLIT = 5;                 // phase B: the owner of key tile k sums query tiles [0,5), a helper [5,9)
 
 // streaming accesses (every 128-B head slice of qkv / dO / O is read by exactly one workgroup, every dqkv slice written
 // once): with the `nt` hint they do not displace the 83-KB bias tiles the 32 workgroups of an XCD re-read from L2 twice per
@@ -44,286 +35,6 @@ __device__ inline void stg1(float* p, float v) {
   if (NTH) __builtin_nontemporal_store(v, p);
   else *p = v;
 }
-
-template <bool SHIFTED, bool NTH>
-__global__ __launch_bounds__(NT) void window_attn_bwd_f32_kernel(
-    const float* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ esb,
-    const float* __restrict__ out, const float* __restrict__ lse, const float* __restrict__ dout,
-    float* __restrict__ dqkv, float* __restrict__ dqkv_bias, float* __restrict__ d_esb, WinGeom g, int C, int heads) {
-  __shared__ __attribute__((aligned(16))) float Qs[PANGU_WTOK * KV_LD];
-  __shared__ __attribute__((aligned(16))) float Ks[PANGU_WTOK * KV_LD];
-  __shared__ __attribute__((aligned(16))) float Vs[PANGU_WTOK * KV_LD];
-  __shared__ __attribute__((aligned(16))) float Gs[PANGU_WTOK * KV_LD];     // dO
-  __shared__ __attribute__((aligned(16))) float lse_s[PANGU_WTOK];
-  __shared__ __attribute__((aligned(16))) float del_s[PANGU_WTOK];
-  __shared__ int tok_s[PANGU_WTOK];
-  __shared__ float pad_s[64];            // [2][32]: dK, dV summed over the zero-pad keys of this (type, head)
-  __shared__ __attribute__((aligned(16))) f32x4 part_s[NQ * 4 * 64];      // helpers' partial dK/dV per key tile
-  // the last DB_LDS of the nine d_esb accumulator quads live in LDS (lane-private slots): at the 168-VGPR cap the
-  // compiler would keep them in scratch instead (read-modify-write through L2/HBM every window: +1.6 GB per launch)
-  constexpr int DB_LDS = 4, DB_REG = 9 - DB_LDS;
-  __shared__ __attribute__((aligned(16))) f32x4 dbias_s[DB_LDS * NQ * 64];
-
-  const int pair = blockIdx.x;
-  const int t = pair / heads, hd = pair - t * heads;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lq = lane & 15, lg = lane >> 4;
-  const int C3 = 3 * C;
-  const float scale = 0.17677669529663687f;
-  constexpr float K_LOG2E = 1.4426950408889634f;
-  const float* bias_tile = esb + (size_t)pair * PANGU_WTOK * PANGU_WTOK;
-
-  bool zcut = false, hcut = false;
-  if (SHIFTED) {
-    const int zwin = t / g.nHw, hwin = t - zwin * g.nHw;
-    zcut = zwin == g.nZw - 1;
-    hcut = hwin == g.nHw - 1;
-  }
-  auto masked = [&](int nq, int nk) -> bool {
-    const bool zd = (nq >= 72) != (nk >= 72);
-    const bool hdiff = (((nq / 12) % 6) < 3) != (((nk / 12) % 6) < 3);
-    return (zcut && zd) || (hcut && hdiff);
-  };
-
-  if (tid < 64) pad_s[tid] = 0.f;
-  f32x4 dbias[DB_REG];
-#pragma unroll
-  for (int j = 0; j < DB_REG; ++j) dbias[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (tid < NQ * 64) {
-#pragma unroll
-    for (int j = 0; j < DB_LDS; ++j) dbias_s[j * NQ * 64 + tid] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-
-  // An owner (wave < 9) sums query tiles [0, I_SPLIT) for its key tile in phase B (and keeps the sums in registers);
-  // helper h sums [I_SPLIT, 9) for key tiles 3h .. 3h+2 and hands the partial sums over through LDS: 216 + 160 MFMAs
-  // per owner, 3 x 128 per helper -- every SIMD runs three waves with the same load (nine waves alone would put three
-  // on one SIMD and two on the others, and the full SIMD sets the pace of every window)
-  const bool owner = wave < NQ;
-  const int ntask = owner ? 1 : 3, i0 = owner ? 0 : I_SPLIT, i1 = owner ? I_SPLIT : NQ;
-  // The mask does not depend on the window, and it is the same for the 4 tokens 16x + 4lg + r a lane holds (the cuts
-  // fall on multiples of 12 and at 72): one bit per 16-token tile, built once.  maskA bit j: key tile j against this
-  // lane's query (phase A); maskB bit 9*kk + i: query tile i against this lane's key of task kk (phase B).
-  unsigned maskA = 0u, maskB = 0u;
-  if (SHIFTED) {
-    if (zcut || hcut) {
-      if (owner)
-        for (int j = 0; j < 9; ++j)
-          if (masked(wave * 16 + lq, j * 16 + lg * 4)) maskA |= 1u << j;
-      for (int kk = 0; kk < ntask; ++kk) {
-        const int kn = (owner ? wave : 3 * (wave - NQ) + kk) * 16 + lq;
-        for (int i = 0; i < 9; ++i)
-          if (masked(i * 16 + lg * 4, kn)) maskB |= 1u << (9 * kk + i);
-      }
-    }
-  }
-
-  for (int l = 0; l < g.nLon; ++l) {
-    __syncthreads();                               // previous window's LDS reads are done
-    // the bias tile is the same for every window: stop the compiler from hoisting its 72 loads out of this loop
-    // (register cap 168 at 9 waves per workgroup); it is re-read from L2 instead
-    long lz = 0;
-    asm volatile("" : "+s"(lz));
-    const float* bias_l = bias_tile + lz;
-    if (tid < PANGU_WTOK) tok_s[tid] = win_src_token(g, l, t, tid, SHIFTED);
-    __syncthreads();
-    // ---- stage Qs (scaled), K, V, dO; delta = rowsum(dO o O); lse
-    for (int f = tid; f < PANGU_WTOK * 8; f += NT) {
-      const int n = f >> 3, c4 = (f & 7) * 4;
-      const int tok = tok_s[n];
-      const float* src = tok >= 0 ? qkv + (size_t)tok * C3 : qkv_bias;
-      f32x4 qv = ldg4<NTH>(src + hd * 32 + c4);
-      const f32x4 kv = ldg4<NTH>(src + C + hd * 32 + c4);
-      const f32x4 vv = ldg4<NTH>(src + 2 * C + hd * 32 + c4);
-      f32x4 gv = {0.f, 0.f, 0.f, 0.f}, ov = {0.f, 0.f, 0.f, 0.f};
-      if (tok >= 0) {
-        gv = ldg4<NTH>(dout + (size_t)tok * C + hd * 32 + c4);
-        ov = ldg4<NTH>(out + (size_t)tok * C + hd * 32 + c4);
-      }
-      qv *= scale;
-      *reinterpret_cast<f32x4*>(&Qs[n * KV_LD + c4]) = qv;
-      *reinterpret_cast<f32x4*>(&Ks[n * KV_LD + c4]) = kv;
-      *reinterpret_cast<f32x4*>(&Vs[n * KV_LD + c4]) = vv;
-      *reinterpret_cast<f32x4*>(&Gs[n * KV_LD + c4]) = gv;
-      float d = (gv[0] * ov[0] + gv[1] * ov[1]) + (gv[2] * ov[2] + gv[3] * ov[3]);
-      d += __shfl_xor(d, 1, 64);
-      d += __shfl_xor(d, 2, 64);
-      d += __shfl_xor(d, 4, 64);
-      if ((f & 7) == 0) {
-        // row constants in the form the score epilogue consumes: p = exp2(S*log2e - lse*log2e), and -delta as the
-        // INITIAL ACCUMULATOR of the dP product (dS = p * (dP - delta)).  A pad query's row of P must vanish (its
-        // output is discarded): -huge makes exp2(..) = 0
-        del_s[n] = -d;
-        lse_s[n] = tok >= 0 ? -K_LOG2E * lse[(size_t)tok * heads + hd] : -1e30f;
-      }
-    }
-    __syncthreads();
-
-    // =========================== phase A: query tile `wave`, S^T orientation (tile owners) =============
-    if (wave < NQ) {
-      const int qn = wave * 16 + lq;
-      const int qtok = tok_s[qn];
-      const f32x4 q0 = *reinterpret_cast<const f32x4*>(&Qs[qn * KV_LD + lg * 8]);
-      const f32x4 q1 = *reinterpret_cast<const f32x4*>(&Qs[qn * KV_LD + lg * 8 + 4]);
-      const f32x4 g0 = *reinterpret_cast<const f32x4*>(&Gs[qn * KV_LD + lg * 8]);
-      const f32x4 g1 = *reinterpret_cast<const f32x4*>(&Gs[qn * KV_LD + lg * 8 + 4]);
-      const float nl2 = lse_s[qn], nd = del_s[qn];           // -lse*log2e, -delta
-      const float nl2m = nl2 - 100.0f * K_LOG2E;
-      const float* brow = bias_l + (size_t)qn * PANGU_WTOK + lg * 4;
-      f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < 9; ++j) {
-        __builtin_amdgcn_sched_barrier(0);      // keep each key tile's loads inside its iteration (VGPR cap 168)
-        const int krow = (j * 16 + lq) * KV_LD + lg * 8;
-        const f32x4 k0 = *reinterpret_cast<const f32x4*>(&Ks[krow]);
-        const f32x4 k1 = *reinterpret_cast<const f32x4*>(&Ks[krow + 4]);
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(&Vs[krow]);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(&Vs[krow + 4]);
-        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {nd, nd, nd, nd};
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          s = __builtin_amdgcn_mfma_f32_16x16x4f32(k0[ks], q0[ks], s, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x4f32(v0[ks], g0[ks], dp, 0, 0, 0);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          s = __builtin_amdgcn_mfma_f32_16x16x4f32(k1[ks], q1[ks], s, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x4f32(v1[ks], g1[ks], dp, 0, 0, 0);
-        }
-        // lane: [key = 16j + 4lg + r][query = qn]
-        s += *reinterpret_cast<const f32x4*>(brow + j * 16);
-        f32x4 ds;
-        float c = nl2;                      // mask folded into the row constant
-        if (SHIFTED) { if ((maskA >> j) & 1u) c = nl2m; }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(s[r], K_LOG2E, c));
-          ds[r] = p * dp[r];
-        }
-        if (j < DB_REG) dbias[j] += ds;
-        else dbias_s[(j - DB_REG) * NQ * 64 + tid] += ds;          // own slot only: no barrier
-        // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = j * 16 + lg * 4 + r;
-          dq0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[key * KV_LD + lq], ds[r], dq0, 0, 0, 0);
-          dq1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[key * KV_LD + 16 + lq], ds[r], dq1, 0, 0, 0);
-        }
-      }
-      // lane: dQ^T[d = 16dt + 4lg + r][query = qn]; q was pre-scaled, so dq = scale * dQs
-      if (qtok >= 0) {
-        float* dst = dqkv + (size_t)qtok * C3 + hd * 32 + lg * 4;
-        stg4<NTH>(dst, dq0 * scale);
-        stg4<NTH>(dst + 16, dq1 * scale);
-      }
-    }
-
-    // =========================== phase B: key tile kt, S orientation, query tiles [i0, i1) ===============
-    auto phase_b = [&](int kt, unsigned mbits, f32x4& dv0, f32x4& dv1, f32x4& dk0, f32x4& dk1) {
-      const int kn = kt * 16 + lq;                          // this lane's key column
-      const f32x4 k0 = *reinterpret_cast<const f32x4*>(&Ks[kn * KV_LD + lg * 8]);
-      const f32x4 k1 = *reinterpret_cast<const f32x4*>(&Ks[kn * KV_LD + lg * 8 + 4]);
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(&Vs[kn * KV_LD + lg * 8]);
-      const f32x4 v1 = *reinterpret_cast<const f32x4*>(&Vs[kn * KV_LD + lg * 8 + 4]);
-#pragma unroll 1
-      for (int i = i0; i < i1; ++i) {
-        const int qrow = (i * 16 + lq) * KV_LD + lg * 8;
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(&Qs[qrow]);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(&Qs[qrow + 4]);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(&Gs[qrow]);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(&Gs[qrow + 4]);
-        const f32x4 ls = *reinterpret_cast<const f32x4*>(&lse_s[i * 16 + lg * 4]);      // -lse*log2e
-        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = *reinterpret_cast<const f32x4*>(&del_s[i * 16 + lg * 4]);      // -delta
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          s = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[ks], k0[ks], s, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[ks], v0[ks], dp, 0, 0, 0);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          s = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ks], k1[ks], s, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[ks], v1[ks], dp, 0, 0, 0);
-        }
-        // lane: [query = 16i + 4lg + r][key = kn]
-        f32x4 p, ds;
-        float cm = 0.f;
-        if (SHIFTED) { if ((mbits >> i) & 1u) cm = -100.0f * K_LOG2E; }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int qn = i * 16 + lg * 4 + r;
-          const float sv = s[r] + bias_l[(size_t)qn * PANGU_WTOK + kn];
-          p[r] = __builtin_amdgcn_exp2f(fmaf(sv, K_LOG2E, ls[r] + cm));
-          ds[r] = p[r] * dp[r];
-        }
-        // dV[key][d] += P[query][key] dO[query][d];  dK[key][d] += dS[query][key] Qs[query][d]
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int qn = i * 16 + lg * 4 + r;
-          dv0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p[r], Gs[qn * KV_LD + lq], dv0, 0, 0, 0);
-          dv1 = __builtin_amdgcn_mfma_f32_16x16x4f32(p[r], Gs[qn * KV_LD + 16 + lq], dv1, 0, 0, 0);
-          dk0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[r], Qs[qn * KV_LD + lq], dk0, 0, 0, 0);
-          dk1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[r], Qs[qn * KV_LD + 16 + lq], dk1, 0, 0, 0);
-        }
-      }
-    };
-    f32x4 dv0, dv1, dk0, dk1;
-#pragma unroll 1
-    for (int kk = 0; kk < ntask; ++kk) {
-      const int kt = owner ? wave : 3 * (wave - NQ) + kk;
-      dv0 = f32x4{0.f, 0.f, 0.f, 0.f}; dv1 = dv0; dk0 = dv0; dk1 = dv0;
-      phase_b(kt, maskB >> (9 * kk), dv0, dv1, dk0, dk1);
-      if (!owner) {
-        f32x4* dst = part_s + kt * 4 * 64 + lane;
-        dst[0] = dv0; dst[64] = dv1; dst[128] = dk0; dst[192] = dk1;
-      }
-    }
-    __syncthreads();
-    if (wave < NQ) {
-      const f32x4* src = part_s + wave * 4 * 64 + lane;
-      dv0 += src[0]; dv1 += src[64]; dk0 += src[128]; dk1 += src[192];
-      // lane: dK/dV[key = 16*wave + 4lg + r][d = 16dt + lq]
-      bool any_pad = false;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ktok = tok_s[wave * 16 + lg * 4 + r];
-        if (ktok >= 0) {
-          float* dst = dqkv + (size_t)ktok * C3 + hd * 32 + lq;
-          stg1<NTH>(dst + C, dk0[r]);
-          stg1<NTH>(dst + C + 16, dk1[r]);
-          stg1<NTH>(dst + 2 * C, dv0[r]);
-          stg1<NTH>(dst + 2 * C + 16, dv1[r]);
-        } else {
-          any_pad = true;
-        }
-      }
-      // zero-pad keys all carry linear1.bias: sum their gradients over the keys this lane holds, then over the four
-      // key groups, then in LDS; ONE global atomic per value at the end (instead of 64 per pad key and window)
-      if (__any(any_pad)) {
-        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (tok_s[wave * 16 + lg * 4 + r] < 0) { a0 += dk0[r]; a1 += dk1[r]; b0 += dv0[r]; b1 += dv1[r]; }
-        a0 += __shfl_xor(a0, 16, 64); a1 += __shfl_xor(a1, 16, 64); b0 += __shfl_xor(b0, 16, 64); b1 += __shfl_xor(b1, 16, 64);
-        a0 += __shfl_xor(a0, 32, 64); a1 += __shfl_xor(a1, 32, 64); b0 += __shfl_xor(b0, 32, 64); b1 += __shfl_xor(b1, 32, 64);
-        if (lg == 0) {
-          atomicAdd(&pad_s[lq], a0);
-          atomicAdd(&pad_s[16 + lq], a1);
-          atomicAdd(&pad_s[32 + lq], b0);
-          atomicAdd(&pad_s[48 + lq], b1);
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (tid < 64 && pad_s[tid] != 0.f) atomicAdd(dqkv_bias + (tid < 32 ? C : 2 * C) + hd * 32 + (tid & 31), pad_s[tid]);
-  // ---- bias gradient tile: lane holds sum_l dS^T[key = 16j + 4lg + r][query = 16*wave + lq]
-  if (wave < NQ) {
-    float* drow = d_esb + (size_t)pair * PANGU_WTOK * PANGU_WTOK + (size_t)(wave * 16 + lq) * PANGU_WTOK + lg * 4;
-#pragma unroll
-    for (int j = 0; j < 9; ++j)
-      *reinterpret_cast<f32x4*>(drow + j * 16) = j < DB_REG ? dbias[j] : dbias_s[(j - DB_REG) * NQ * 64 + tid];
-  }
-}
-
 
 // ===================================================================================================================
 // v2 (round 2): ONE score orientation.  Phase 1: the owner of KEY tile w computes S = Qs K^T and dP = dO V^T with the key
@@ -756,21 +467,10 @@ extern "C" int pangu_window_attn_bwd(pangu_stream_t stream, const float* qkv, co
   const WinGeom g = make_geom(Z, H, W);
   const int n_pairs = g.types * heads;
   hipStream_t s = (hipStream_t)stream;
-  static const bool nt_hint = [] { const char* e = getenv("PANGU_ATTN_BWD_NT"); return e ? atoi(e) != 0 : true; }();
-  static const int version = [] { const char* e = getenv("PANGU_ATTN_BWD_V"); return e ? atoi(e) : 2; }();
-#define PANGU_LAUNCH_BWD(KERN, SH, NTH)                                                                           \
-  hipLaunchKernelGGL((KERN<SH, NTH>), dim3(n_pairs), dim3(NT), 0, s, qkv, qkv_bias, esb, out, lse, dout, dqkv, \
-                     dqkv_bias, d_esb, g, C, heads)
-#define PANGU_LAUNCH_BWD_V(KERN)                                                                   \
-  do {                                                                                             \
-    if (shifted) {                                                                                 \
-      if (nt_hint) PANGU_LAUNCH_BWD(KERN, true, true); else PANGU_LAUNCH_BWD(KERN, true, false);   \
-    } else {                                                                                       \
-      if (nt_hint) PANGU_LAUNCH_BWD(KERN, false, true); else PANGU_LAUNCH_BWD(KERN, false, false); \
-    }                                                                                              \
-  } while (0)
-  if (version == 1) PANGU_LAUNCH_BWD_V(window_attn_bwd_f32_kernel); else PANGU_LAUNCH_BWD_V(v2::window_attn_bwd2_f32_kernel);
-#undef PANGU_LAUNCH_BWD_V
+#define PANGU_LAUNCH_BWD(SH)                                                                                            \
+  hipLaunchKernelGGL((v2::window_attn_bwd2_f32_kernel<SH, true>), dim3(n_pairs), dim3(NT), 0, s, qkv, qkv_bias, esb, out, lse, \
+                     dout, dqkv, dqkv_bias, d_esb, g, C, heads)
+  if (shifted) PANGU_LAUNCH_BWD(true); else PANGU_LAUNCH_BWD(false);
 #undef PANGU_LAUNCH_BWD
   return pangu_launch_status();
 }

@@ -412,8 +412,7 @@ static int launch_attn_fwd(pangu_stream_t stream, const float* qkv, const float*
 #define PANGU_LAUNCH_ATTN(SH, CP)                                                                                      \
   hipLaunchKernelGGL((window_attn_f32_kernel<SH, CP>), dim3(grid), dim3(192), 0, s, qkv, qkv_bias, esb, out, lse, g, C, \
                      heads, n_pairs, shifted ? 1 : 0)
-  static const int tpl = getenv("PANGU_ATTN_F32_TPL") ? atoi(getenv("PANGU_ATTN_F32_TPL")) : 0;
-  if (shifted || tpl == 1) {
+  if (shifted) {
     if (compact) PANGU_LAUNCH_ATTN(true, true); else PANGU_LAUNCH_ATTN(true, false);
   } else {
     if (compact) PANGU_LAUNCH_ATTN(false, true); else PANGU_LAUNCH_ATTN(false, false);

@@ -277,7 +277,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const u16* __restr
 // physical chunk p of row r fetches logical chunk p ^ F(r).  Rows >= M / >= N fall outside the descriptor's range
 // and arrive as zeros.
 constexpr int GBK = 32;
-constexpr int GST = 4;
 
 __device__ inline int kswz64(int row, int chunk) {      // 64-byte rows, 4 chunks: F = {0,2,3,1}[(row>>2)&3]
   const int f = (0x78 >> (((row >> 2) & 3) * 2)) & 3;
@@ -381,23 +380,15 @@ int launch_bf16(hipStream_t s, const u16* A, int lda, const u16* W, const float*
   // runs THREE workgroups per CU (no staging registers, 53 KB of LDS) and wins 7-13 % on the K = 384 / 768 shapes; for
   // K >= 1024 the register-staged BK = 64 kernel (two workgroups per CU, half the barriers) is 4 % ahead; the ring of 4
   // equals the register-staged kernel everywhere.  PANGU_BF16_GLDS = 0 / 1 / 2 forces register staging / ring of 4 / ring of 2.
-  static const int forced = getenv("PANGU_BF16_GLDS") ? atoi(getenv("PANGU_BF16_GLDS")) : -1;
-  const int glds_mode = forced >= 0 ? forced : (K < 1024 ? 2 : 0);
-  const bool glds = (glds_mode == 1 || glds_mode == 2) && (K % GBK == 0);
+  const bool glds = K < 1024 && (K % GBK == 0);      // (a ring of 4 measured equal to register staging: removed)
   const size_t epi = OUT_F32 ? 0 : (size_t)4 * 64 * (32 * TN * 2 + 16);
-  const size_t ring = (size_t)(glds_mode == 2 ? 2 : GST) * (BBM + BN) * 64;
+  const size_t ring = (size_t)2 * (BBM + BN) * 64;
   const size_t shm = glds ? (ring > epi ? ring : epi) : 2 * (size_t)(BBM + BN) * 128;
   dim3 g(grid), blk(256);
 #define PANGU_BGEMM(ACT, HB)                                                                                          \
   do {                                                                                                                \
-    if (glds && glds_mode == 2) {                                                                                     \
-      auto kern = gemm_tn_bf16_glds_kernel<TN, ACT, HB, OUT_F32, 2>;                                                  \
-      PANGU_ENSURE_DYN_LDS(kern, shm);                                                                                \
-      hipLaunchKernelGGL(kern, g, blk, shm, s, A, lda, W, bias, C, ldc, M, N, K, m_tiles, n_tiles, aux, aux2);        \
-      break;                                                                                                          \
-    }                                                                                                                 \
     if (glds) {                                                                                                       \
-      auto kern = gemm_tn_bf16_glds_kernel<TN, ACT, HB, OUT_F32, GST>;                                                \
+      auto kern = gemm_tn_bf16_glds_kernel<TN, ACT, HB, OUT_F32, 2>;                                                  \
       PANGU_ENSURE_DYN_LDS(kern, shm);                                                                                \
       hipLaunchKernelGGL(kern, g, blk, shm, s, A, lda, W, bias, C, ldc, M, N, K, m_tiles, n_tiles, aux, aux2);        \
       break;                                                                                                          \
@@ -439,19 +430,13 @@ extern "C" int pangu_linear_gelu_bwd_bf16(pangu_stream_t stream, const void* A, 
   // read and the dpre / h writes; measured (tools/bench_kernels.py mlp_train, MI355X) the tiled LDS-DMA kernel is 7-13 % ahead
   // on this epilogue (0.677 vs 0.729 ms with h, 0.479 vs 0.553 without), so it is the default; PANGU_BF16_WS_GELU_BWD=1 = the
   // weights-stationary kernel
-  static const bool ws_bwd = getenv("PANGU_BF16_WS_GELU_BWD") && atoi(getenv("PANGU_BF16_WS_GELU_BWD")) == 1;
-  if (ws_bwd && M >= 4096) {
-    const int rc = pangu_linear_ws_bf16(s, A, lda, W, nullptr, dpre, ldc, M, N, K, act, const_cast<void*>(pre), 0, h);
-    if (rc != PANGU_E_SHAPE) return rc;
-  }
   const u16* a = (const u16*)A;
   const u16* w = (const u16*)W;
   u16* x = (u16*)const_cast<void*>(pre);
   // with h the epilogue moves three (tokens x N) tensors per tile: 128 x 128 tiles (116 VGPRs, 37 KB of patches: four workgroups
   // per CU cover its load -> gelu' -> store chain) beat 128 x 192 (three per CU): 0.53 vs 0.57 ms at C = 192, 0.34 vs 0.36 at
   // C = 384 (tools/bench_kernels.py mlp_train); without h the two are level.  PANGU_GELU_BWD_TN=3 / 2 forces one.
-  static const int tn_forced = getenv("PANGU_GELU_BWD_TN") ? atoi(getenv("PANGU_GELU_BWD_TN")) : 0;
-  const bool tn2 = tn_forced ? tn_forced == 2 : h != nullptr;
+  const bool tn2 = h != nullptr;
   if (tn2 && N % 128 == 0) return launch_bf16<2, false>(s, a, lda, w, nullptr, dpre, ldc, M, N, K, act, x, (u16*)h);
   if ((N % 192 == 0) || (N > 128 && N < 192)) return launch_bf16<3, false>(s, a, lda, w, nullptr, dpre, ldc, M, N, K, act, x, (u16*)h);
   if (N % 128 == 0) return launch_bf16<2, false>(s, a, lda, w, nullptr, dpre, ldc, M, N, K, act, x, (u16*)h);
@@ -469,18 +454,16 @@ extern "C" int pangu_linear_fwd_bf16(pangu_stream_t stream, const void* A, int l
   if (out_dtype != PANGU_BF16 && out_dtype != PANGU_F32) return PANGU_E_DTYPE;
   if (out_dtype == PANGU_BF16 && (ldc & 7)) return PANGU_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
-  // K <= 384: weights-stationary barrier-free kernel (PANGU_BF16_WS=0 disables it: A/B knob)
-  static const bool allow_ws = !(getenv("PANGU_BF16_WS") && atoi(getenv("PANGU_BF16_WS")) == 0);
-  static const bool ws_bwd = getenv("PANGU_BF16_WS_GELU_BWD") && atoi(getenv("PANGU_BF16_WS_GELU_BWD")) == 1;
-  if (allow_ws && M >= 4096 && act != PANGU_ACT_ADD && (act != PANGU_ACT_GELU_BWD || ws_bwd)) {      // GELU_BWD: see pangu_linear_gelu_bwd_bf16
+  // K <= 192: weights-stationary barrier-free kernel (gemm_ws_bf16.hip; not for the GELU-backward epilogue: the tiled LDS-DMA
+  // kernel is 7-13 % ahead there, see pangu_linear_gelu_bwd_bf16)
+  if (M >= 4096 && act != PANGU_ACT_ADD && act != PANGU_ACT_GELU_BWD) {
     const int rc = pangu_linear_ws_bf16(s, A, lda, W, bias, C, ldc, M, N, K, act, aux, out_dtype == PANGU_F32);
     if (rc != PANGU_E_SHAPE) return rc;
   }
   const u16* a = (const u16*)A;
   const u16* w = (const u16*)W;
   u16* x = (u16*)aux;
-  static const int tn_env = getenv("PANGU_BF16_TN") ? atoi(getenv("PANGU_BF16_TN")) : 0;      // A/B knob: 2 = 128 x 128 tiles wherever N % 128 == 0
-  const bool wide = ((N % 192 == 0) || (N > 128 && N < 192)) && !(tn_env == 2 && N % 128 == 0);
+  const bool wide = (N % 192 == 0) || (N > 128 && N < 192);
   if (out_dtype == PANGU_F32) {
     if (wide) return launch_bf16<3, true>(s, a, lda, w, bias, C, ldc, M, N, K, act, x);
     if (N % 128 == 0) return launch_bf16<2, true>(s, a, lda, w, bias, C, ldc, M, N, K, act, x);

@@ -221,27 +221,12 @@ extern "C" int pangu_linear_fwd(pangu_stream_t stream, const float* A, int lda, 
   if ((act == PANGU_ACT_GELU_BWD || act == PANGU_ACT_ADD) && !aux) return PANGU_E_NULL;
   if (!pangu_fits_u32(M, lda, 4) || !pangu_fits_u32(M, ldc, 4)) return PANGU_E_RANGE;
   hipStream_t s = (hipStream_t)stream;
-  static const int force_tn = getenv("PANGU_GEMM_TN") ? atoi(getenv("PANGU_GEMM_TN")) : 0;   // tuning knob
-  if (force_tn == 1) return launch_tn<1>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
-  if (force_tn == 2) return launch_tn<2>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
-  if (force_tn == 3) return launch_tn<3>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
-  // Tile width (measured per shape on MI355X, tools/bench_kernels.py): 192 columns wherever N is a multiple of 192
-  // or fits one tile (N = 160: 17 % padded MFMAs still beat three 64-wide tiles); N = 384 as 3 x 128 (3072 tiles =
-  // exactly 4 waves of the 768 resident workgroups, vs 2048 = 2.67 with 192-wide tiles).
-  // 128 x 128 LDS-DMA tiles (five workgroups per CU) for N = 384, where 192-wide tiles would leave 2.67 rounds of workgroups;
-  // PANGU_GEMM_DMA2 = 0: register-staged kernel, 2: 128-wide DMA tiles for every N % 128 == 0 (A/B knobs)
-  static const int dma2 = getenv("PANGU_GEMM_DMA2") ? atoi(getenv("PANGU_GEMM_DMA2")) : 1;
-  if (N == 384 || (dma2 == 2 && N % 128 == 0)) {
-    if (dma2) return pangu_linear_f32_dma(s, A, lda, W, bias, C, ldc, M, N, K, act, aux, 2);
-    return launch_tn<2>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
-  }
-  if (N % 192 == 0 || (N > 128 && N < 192)) {
-    // default: the LDS-DMA kernel (gemm_f32_dma.hip, four workgroups per CU), +3.5-11 % over the register-staged kernel below
-    // on every 192-wide-tile shape of the model; PANGU_GEMM_DMA=0 selects the register-staged kernel (A/B knob)
-    static const int dma = getenv("PANGU_GEMM_DMA") ? atoi(getenv("PANGU_GEMM_DMA")) : 1;
-    if (dma) return pangu_linear_f32_dma(s, A, lda, W, bias, C, ldc, M, N, K, act, aux, 3);
-    return launch_tn<3>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
-  }
+  // Tile width (measured per shape on MI355X, tools/bench_kernels.py): the LDS-DMA kernel (gemm_f32_dma.hip) with 192 columns
+  // wherever N is a multiple of 192 or fits one tile (N = 160: 17 % padded MFMAs still beat three 64-wide tiles; four workgroups
+  // per CU, +3.5-11 % over the register-staged kernel), 128-column LDS-DMA tiles for N = 384 (five workgroups per CU; 192-wide
+  // tiles would leave 2.67 rounds of workgroups); the register-staged kernel below for the other widths (N = 64, 128, ..).
+  if (N == 384) return pangu_linear_f32_dma(s, A, lda, W, bias, C, ldc, M, N, K, act, aux, 2);
+  if (N % 192 == 0 || (N > 128 && N < 192)) return pangu_linear_f32_dma(s, A, lda, W, bias, C, ldc, M, N, K, act, aux, 3);
   if (N % 128 == 0) return launch_tn<2>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
   return launch_tn<1>(s, A, lda, W, bias, C, ldc, M, N, K, act, aux);
 }

@@ -194,10 +194,15 @@ int launch_ln_dma(hipStream_t s, const float* A, int lda, const float* W, const 
 
 }  // namespace
 
-// gemm_ln_f32.hip dispatches here (N = 192 or 384)
-int pangu_linear_ln_f32_dma(hipStream_t s, const float* A, int lda, const float* W, const float* bias, const float* shortcut,
-                            int lds, const float* gamma, const float* beta, float* out, int ldo, int M, int N, int K,
-                            float branch_scale) {
+extern "C" int pangu_linear_ln_residual_fwd(pangu_stream_t stream, const float* A, int lda, const float* W, const float* bias,
+                                            const float* shortcut, int lds, const float* gamma, const float* beta, float* out,
+                                            int ldo, int M, int N, int K, float branch_scale) {
+  if (!A || !W || !shortcut || !gamma || !beta || !out) return PANGU_E_NULL;
+  if (M <= 0 || K <= 0 || (K % BK) != 0 || lda < K || (lda & 3) || ldo < N || (ldo & 3) || lds < N || (lds & 3))
+    return PANGU_E_SHAPE;
+  if (N != 192 && N != 384) return PANGU_E_SHAPE;          // the tile must span the whole row
+  if (!pangu_fits_u32(M, lda, 4) || !pangu_fits_u32(M, ldo, 4) || !pangu_fits_u32(M, lds, 4)) return PANGU_E_RANGE;
+  hipStream_t s = (hipStream_t)stream;
   if (N == 192) return launch_ln_dma<2>(s, A, lda, W, bias, shortcut, lds, gamma, beta, out, ldo, M, K, branch_scale);
   return launch_ln_dma<4>(s, A, lda, W, bias, shortcut, lds, gamma, beta, out, ldo, M, K, branch_scale);
 }

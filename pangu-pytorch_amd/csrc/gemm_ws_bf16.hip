@@ -79,9 +79,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_bf16_kernel(const u16* __restr
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       aux, 0, aux ? (int)((size_t)M * N * sizeof(u16)) : 0, 0x00020000);
 
-  const __amdgpu_buffer_rsrc_t h_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      aux2, 0, ACT == PANGU_ACT_GELU_BWD_H ? (int)((size_t)M * N * sizeof(u16)) : 0, 0x00020000);
-
   // activation fragments of one tile: [k-step][row sub-tile]; rows past M read as zeros (range-checked descriptor)
   u32x4 af[KS][2];
   auto fetch = [&](int tile) {
@@ -123,43 +120,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_bf16_kernel(const u16* __restr
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       constexpr int CPR = ROWB / 16;
-      if (ACT == PANGU_ACT_GELU_BWD || ACT == PANGU_ACT_GELU_BWD_H) {
-#pragma unroll
-        for (int it = 0; it < (16 * (BNW / 8) + 63) / 64; ++it) {
-          const int f = lane + 64 * it, row = f / (BNW / 8), ch = f % (BNW / 8);
-          const int col = n0 + ch * 8;
-          if (f < 16 * (BNW / 8)) {
-            const unsigned off = col < N ? ((unsigned)(m_cur + mt * 16 + row) * (unsigned)N + (unsigned)col) * 2u : 0xFFFFFFFFu;
-            *reinterpret_cast<u32x4*>(ep + row * EP_LD + ch * 16) = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)off, 0, 0);
-          }
-        }
-      }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int col = n0 + j * 16 + lg * 4;
         f32x4 v = acc[mt][j];
         if (HAS_BIAS) v += *reinterpret_cast<const f32x4*>(bias_s + j * 16 + lg * 4);   // LDS: no vmcnt coupling with the in-flight next-tile loads
-        if (ACT == PANGU_ACT_GELU_BWD) {
-          const u32x2 xp = *reinterpret_cast<const u32x2*>(ep + lc * EP_LD + (j * 16 + lg * 4) * 2);
-          v[0] *= gelu_erf_grad_lp(__builtin_bit_cast(float, xp[0] << 16));
-          v[1] *= gelu_erf_grad_lp(__builtin_bit_cast(float, xp[0] & 0xFFFF0000u));
-          v[2] *= gelu_erf_grad_lp(__builtin_bit_cast(float, xp[1] << 16));
-          v[3] *= gelu_erf_grad_lp(__builtin_bit_cast(float, xp[1] & 0xFFFF0000u));
-        }
-        if (ACT == PANGU_ACT_GELU_BWD_H) {      // gelu'(x) and h = gelu(x) share Phi(x); h leaves as an 8-B piece per lane
-          const u32x2 xp = *reinterpret_cast<const u32x2*>(ep + lc * EP_LD + (j * 16 + lg * 4) * 2);
-          const f32x4 x = {__builtin_bit_cast(float, xp[0] << 16), __builtin_bit_cast(float, xp[0] & 0xFFFF0000u),
-                           __builtin_bit_cast(float, xp[1] << 16), __builtin_bit_cast(float, xp[1] & 0xFFFF0000u)};
-          f32x4 hh;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float phi_c = 0.5f * (1.0f + erf_poly(x[c] * 0.70710678118654752440f));
-            hh[c] = x[c] * phi_c;
-            v[c] *= phi_c + x[c] * 0.3989422804014327f * __expf(-0.5f * x[c] * x[c]);
-          }
-          const unsigned ho = col < N ? ((unsigned)(m_cur + mt * 16 + lc) * (unsigned)N + (unsigned)col) * 2u : 0xFFFFFFFFu;
-          __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(hh[0], hh[1]), pack2(hh[2], hh[3])}, h_rsrc, (int)ho, 0, 0);
-        }
         if (ACT == PANGU_ACT_GELU) {
           if (aux) {
             const unsigned xo = col < N ? ((unsigned)(m_cur + mt * 16 + lc) * (unsigned)N + (unsigned)col) * 2u : 0xFFFFFFFFu;
@@ -203,10 +168,6 @@ int launch_ws(hipStream_t s, const u16* A, int lda, const u16* W, const float* b
   } while (0)
   if (act == PANGU_ACT_GELU) {
     if (bias) PANGU_WS(PANGU_ACT_GELU, true); else PANGU_WS(PANGU_ACT_GELU, false);
-  } else if (act == PANGU_ACT_GELU_BWD) {
-    PANGU_WS(PANGU_ACT_GELU_BWD, false);
-  } else if (act == PANGU_ACT_GELU_BWD_H) {
-    if constexpr (OUT_F32) return PANGU_E_SHAPE; else PANGU_WS(PANGU_ACT_GELU_BWD_H, false);
   } else {
     if (bias) PANGU_WS(PANGU_ACT_NONE, true); else PANGU_WS(PANGU_ACT_NONE, false);
   }
@@ -221,20 +182,10 @@ int launch_ws(hipStream_t s, const u16* A, int lda, const u16* W, const float* b
 int pangu_linear_ws_bf16(hipStream_t s, const void* A, int lda, const void* W, const float* bias, void* C, int ldc, int M,
                          int N, int K, int act, void* aux, int out_f32, void* aux2) {
   // Measured (tools/bench_kernels.py gemm_bf16, MI355X): with K <= 192 a 192-column slice is resident and the kernel beats
-  // the tiled one by 5-25 %; with K = 384 only 96 columns fit (activations re-read twice as often) and it LOSES 20-40 %,
-  // so those shapes stay on the tiled kernel.  The <96,384> instantiation is kept for PANGU_BF16_WS=2 experiments.
-  static const int mode = getenv("PANGU_BF16_WS") ? atoi(getenv("PANGU_BF16_WS")) : 1;
-  if ((K & 31) || K > (mode == 2 ? 384 : 192) || (lda & 7) || (N & 7)) return PANGU_E_SHAPE;
-  if (out_f32 && K <= 192) return PANGU_E_SHAPE;            // fp32 patch of a 192-wide slice does not fit next to W
-  if ((act == PANGU_ACT_GELU_BWD || act == PANGU_ACT_GELU_BWD_H) && (out_f32 || bias)) return PANGU_E_SHAPE;
-  const u16* a = (const u16*)A;
-  const u16* w = (const u16*)W;
-  u16* x = (u16*)aux;
-  u16* x2 = (u16*)aux2;
-  if (K <= 192) {
-    return out_f32 ? launch_ws<192, 192, true>(s, a, lda, w, bias, C, ldc, M, N, K, act, x, x2)
-                   : launch_ws<192, 192, false>(s, a, lda, w, bias, C, ldc, M, N, K, act, x, x2);
-  }
-  return out_f32 ? launch_ws<96, 384, true>(s, a, lda, w, bias, C, ldc, M, N, K, act, x, x2)
-                 : launch_ws<96, 384, false>(s, a, lda, w, bias, C, ldc, M, N, K, act, x, x2);
+  // the tiled one by 5-25 %; with K = 384 only 96 columns fit (activations re-read twice as often) and it LOSES 20-40 %
+  // (instantiation removed in round 4), as it does on the GELU-backward epilogue (7-13 %): those stay on the tiled kernel.
+  if ((K & 31) || K > 192 || (lda & 7) || (N & 7)) return PANGU_E_SHAPE;
+  if (out_f32) return PANGU_E_SHAPE;                        // fp32 patch of a 192-wide slice does not fit next to W
+  if (act != PANGU_ACT_NONE && act != PANGU_ACT_GELU) return PANGU_E_SHAPE;
+  return launch_ws<192, 192, false>(s, (const u16*)A, lda, (const u16*)W, bias, C, ldc, M, N, K, act, (u16*)aux, (u16*)aux2);
 }

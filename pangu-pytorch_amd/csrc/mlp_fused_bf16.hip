@@ -122,7 +122,7 @@ using Int = std::integral_constant<int, N>;
 //                     re-creates h = GELU(pre) from it for the W2 weight gradient, so h is never stored by the forward);
 //                     may be null (recompute mode: the backward re-runs the MLP-up GEMM);
 //   Mo[m][C]   (bf16): the second product + b2 BEFORE LayerNorm (what the LayerNorm backward normalises again).
-template <int C, int T, int NW, int TR>      // TR: 0 inference, 1 training (Mo only: recompute mode), 2 training (Pre + Mo)
+template <int C, int T, int NW, int TR>      // TR: 0 inference, 2 training (side outputs Pre + Mo)
 __global__ __launch_bounds__(64 * NW, NW / 4) void mlp_ln_residual_bf16_kernel(
     const u16* __restrict__ X, int ldx, const u16* __restrict__ Wimg, const float* __restrict__ b1,
     const float* __restrict__ b2, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -580,11 +580,8 @@ extern "C" int pangu_mlp_ln_residual_fwd_bf16(pangu_stream_t stream, const void*
   if (!pangu_fits_u32(M, ldx, 2) || !pangu_fits_u32(M, ldo, 2)) return PANGU_E_RANGE;
   hipStream_t s = (hipStream_t)stream;
   if (C == 192) {
-    // A/B knob: 4 waves x 64 tokens (one wave per SIMD, 512 registers) or 8 waves x 32 tokens (two per SIMD, 256 registers)
-    static const int nw = getenv("PANGU_MLP_NW192") ? atoi(getenv("PANGU_MLP_NW192")) : 4;
-    if (nw == 8)
-      return launch_mlp<192, 1, 8>(s, (const u16*)x, ldx, (const u16*)w_packed, b1, b2, gamma, beta, (u16*)out, ldo, M,
-                                   branch_scale);
+    // 4 waves x 64 tokens (one wave per SIMD, 512 registers); 8 waves x 32 tokens (two per SIMD, 256 registers) measured the same
+    // wall time and was removed in round 4
     return launch_mlp<192, 2, 4>(s, (const u16*)x, ldx, (const u16*)w_packed, b1, b2, gamma, beta, (u16*)out, ldo, M,
                                  branch_scale);
   }
@@ -600,18 +597,17 @@ extern "C" int pangu_mlp_ln_residual_train_fwd_bf16(pangu_stream_t stream, const
                                                     const float* b1, const float* b2, const float* gamma,
                                                     const float* beta, void* out, int ldo, void* pre, int ldp, void* m,
                                                     int ldm, int M, int C, float branch_scale) {
-  if (!x || !w_packed || !b1 || !b2 || !gamma || !beta || !out || !m) return PANGU_E_NULL;
+  if (!x || !w_packed || !b1 || !b2 || !gamma || !beta || !out || !m || !pre) return PANGU_E_NULL;
   if (M <= 0 || ldx < C || ldo < C || ldm < C || (ldx & 7) || (ldo & 7) || (ldm & 7)) return PANGU_E_SHAPE;
-  if (pre && (ldp < 4 * C || (ldp & 7))) return PANGU_E_SHAPE;
-  if (!pangu_fits_u32(M, ldx, 2) || !pangu_fits_u32(M, ldo, 2) || !pangu_fits_u32(M, ldm, 2) ||
-      (pre && !pangu_fits_u32(M, ldp, 2)))
+  if (ldp < 4 * C || (ldp & 7)) return PANGU_E_SHAPE;
+  if (!pangu_fits_u32(M, ldx, 2) || !pangu_fits_u32(M, ldo, 2) || !pangu_fits_u32(M, ldm, 2) || !pangu_fits_u32(M, ldp, 2))
     return PANGU_E_RANGE;
   hipStream_t s = (hipStream_t)stream;
 #define PANGU_MLP_TR(CC, TT, MODE)                                                                                        \
   launch_mlp<CC, TT, 4, MODE>(s, (const u16*)x, ldx, (const u16*)w_packed, b1, b2, gamma, beta, (u16*)out, ldo, M,        \
                               branch_scale, (u16*)pre, ldp, (u16*)m, ldm)
-  if (C == 192) return pre ? PANGU_MLP_TR(192, 2, 2) : PANGU_MLP_TR(192, 2, 1);
-  if (C == 384) return pre ? PANGU_MLP_TR(384, 1, 2) : PANGU_MLP_TR(384, 1, 1);
+  if (C == 192) return PANGU_MLP_TR(192, 2, 2);
+  if (C == 384) return PANGU_MLP_TR(384, 1, 2);
 #undef PANGU_MLP_TR
   return PANGU_E_SHAPE;
 }

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void patch_recover_scatter_kernel(const float*
 }
 
 int row_grid(int rows) {
-  static const int cap = getenv("PANGU_ROW_BLOCKS") ? atoi(getenv("PANGU_ROW_BLOCKS")) : 8192;
+  constexpr int cap = 8192;
   int blocks = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
   return blocks < cap ? blocks : cap;
 }

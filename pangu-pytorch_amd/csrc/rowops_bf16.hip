@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void patch_embed_gather_bf16_kernel(
 }
 
 int row_grid(int rows) {
-  static const int cap = getenv("PANGU_ROW_BLOCKS") ? atoi(getenv("PANGU_ROW_BLOCKS")) : 8192;
+  constexpr int cap = 8192;
   int blocks = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
   return blocks < cap ? blocks : cap;
 }
@@ -404,7 +404,7 @@ extern "C" int pangu_ln_residual_fwd_bf16(pangu_stream_t stream, const void* y, 
   hipStream_t s = (hipStream_t)stream;
   dim3 g(row_grid(N)), b(256);
   if ((C & 7) == 0 && C <= 512 && (lds & 7) == 0 && (ldo & 7) == 0) {
-    static const int cap = getenv("PANGU_LN_BLOCKS") ? atoi(getenv("PANGU_LN_BLOCKS")) : 2048;   // 8 workgroups per CU, grid-stride: workgroup launch rate limits smaller blocks
+    constexpr int cap = 2048;   // 8 workgroups per CU, grid-stride: workgroup launch rate limits smaller blocks
     if (C <= 256) {
       const int blocks = (N + 15) / 16;
       hipLaunchKernelGGL(ln_residual_bf16_v8_kernel<32>, dim3(blocks < cap ? blocks : cap), b, 0, s, (const u16*)y,
@@ -426,7 +426,7 @@ extern "C" int pangu_downsample_ln_fwd_bf16(pangu_stream_t stream, const void* x
   if (Z <= 0 || H <= 0 || W <= 0 || (W & 1) || (C & 3) || 4 * C > 1024 || ldx < C || (ldx & 3)) return PANGU_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   dim3 g(row_grid(Z * ((H + 1) / 2) * (W / 2))), b(256);
-  static const bool fast = ((getenv("PANGU_RESAMPLE_FAST") ? atoi(getenv("PANGU_RESAMPLE_FAST")) : 3) & 1) != 0;      // A/B knob
+  constexpr bool fast = true;      // 16-B fast path where the shape allows (the generic one-row-per-wave kernel below otherwise)
   if (fast && (C & 15) == 0 && C <= 256 && (ldx & 7) == 0) {
     const int rows = Z * ((H + 1) / 2) * (W / 2), blocks = (rows + 7) / 8;
     hipLaunchKernelGGL(downsample_ln_bf16_v16_kernel<2>, dim3(blocks < 2048 ? blocks : 2048), b, 0, s, (const u16*)x, ldx, gamma,
@@ -443,7 +443,7 @@ extern "C" int pangu_upsample_ln_fwd_bf16(pangu_stream_t stream, const void* y, 
   if (Z <= 0 || H2 <= 0 || W2 <= 0 || H <= 0 || H > 2 * H2 || (Co & 3) || Co > 1024) return PANGU_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   dim3 g(row_grid(Z * H * 2 * W2)), b(256);
-  static const bool fast = ((getenv("PANGU_RESAMPLE_FAST") ? atoi(getenv("PANGU_RESAMPLE_FAST")) : 3) & 1) != 0;
+  constexpr bool fast = true;      // 16-B fast path where the shape allows (the generic one-row-per-wave kernel below otherwise)
   if (fast && (Co & 7) == 0 && Co <= 256) {
     const int rows = Z * H * 2 * W2, blocks = (rows + 15) / 16;
     hipLaunchKernelGGL(upsample_ln_bf16_v8_kernel<2>, dim3(blocks < 2048 ? blocks : 2048), b, 0, s, (const u16*)y, gamma, beta,

@@ -175,9 +175,8 @@ int launch_wgrad_bf16(hipStream_t s, const u16* dC, int lddc, const u16* A, int 
   const int tiles = n_tiles * k_tiles;
   // ONE round of the 512 resident workgroups (2 per CU), as many M-splits as fit: every workgroup ends with 98 KB of fp32
   // atomics into dW, which costs 10-45 % of the kernel at these shapes, so fewer, longer workgroups win as long as no
-  // second (partial) round appears (measured sweep, tools/bench_kernels.py wgrad_bf16).  PANGU_WGRAD_WGS overrides.
-  static const int knob = getenv("PANGU_WGRAD_WGS") ? atoi(getenv("PANGU_WGRAD_WGS")) : 0;
-  int split = knob ? (((knob + tiles - 1) / tiles + 7) & ~7) : (512 / tiles) & ~7;   // multiple of 8: equal share per XCD
+  // second (partial) round appears (measured sweep, tools/bench_kernels.py wgrad_bf16).
+  int split = (512 / tiles) & ~7;   // multiple of 8: equal share per XCD
   if (split < 8) split = 8;
   int rows = ((M + split - 1) / split + 63) / 64 * 64;
   if (rows < 256) rows = 256;
@@ -211,14 +210,12 @@ extern "C" int pangu_linear_wgrad_bf16_ws(pangu_stream_t stream, const void* dC,
   // LDS-DMA kernel (three workgroups per CU) for the large products: +5-21 % at qkv / MLP shapes (>= 115 GFLOP); the small
   // ones (proj, down/up-sampling, embed/recover: <= 77 GFLOP) end in the fp32 atomics of their tile sooner than the extra
   // workgroups pay, and stay on the register-staged kernel (measured per shape, tools/bench_kernels.py wgrad_bf16).
-  // PANGU_WGRAD_BF16_DMA=0 / 2: never / always.
-  static const int dma_mode = getenv("PANGU_WGRAD_BF16_DMA") ? atoi(getenv("PANGU_WGRAD_BF16_DMA")) : 1;
-  static const int dma_target = getenv("PANGU_WGRAD_BF16_DMA_WGS") ? atoi(getenv("PANGU_WGRAD_BF16_DMA_WGS")) : 768;
+  constexpr int dma_target = 768;
   // with a workspace the partial tiles leave with plain stores and a second launch sums them (no atomic tail): -5...-10 % at
   // the qkv / MLP shapes, and the LDS-DMA kernel then also wins at the 77-GFLOP down/up-sampling shapes (not at the 38-GFLOP
   // projections: 0.136 vs 0.108 ms at C = 192)
   const bool ws_ok = workspace != nullptr && workspace_bytes > 0 && (reinterpret_cast<size_t>(workspace) & 15) == 0;
-  if (dma_mode == 2 || (dma_mode == 1 && 2.0 * M * N * K >= (ws_ok ? 6.0e10 : 1.0e11))) {
+  if (2.0 * M * N * K >= (ws_ok ? 6.0e10 : 1.0e11)) {
     const int rc = pangu_linear_wgrad_bf16_dma(s, d, lddc, a, lda, dW, db, M, N, K, dma_target, ws_ok ? workspace : nullptr,
                                                ws_ok ? (size_t)workspace_bytes : 0);
     if (rc != 1) return rc;

@@ -170,7 +170,7 @@ int launch_wgrad(hipStream_t s, const float* dC, int lddc, const float* A, int l
   const int n_tiles = (N + WG_BN - 1) / WG_BN, k_tiles = (K + BKC - 1) / BKC;
   const int tiles = n_tiles * k_tiles;
   // ~3 workgroups per CU slot-pair: enough M-splits to fill 256 CUs x 2, slabs a multiple of the K-step
-  static const int target = getenv("PANGU_WGRAD_WGS") ? atoi(getenv("PANGU_WGRAD_WGS")) : 768;    // tuning knob (measured sweep: 768 best)
+  constexpr int target = 768;    // measured sweep: 768 best
   int split = ((target + tiles - 1) / tiles + 7) & ~7;              // equal share per XCD
   int rows = ((M + split - 1) / split + WG_BM - 1) / WG_BM * WG_BM;
   if (rows < 8 * WG_BM) rows = 8 * WG_BM;
@@ -198,13 +198,11 @@ extern "C" int pangu_linear_wgrad_ws(pangu_stream_t stream, const float* dC, int
     return PANGU_E_SHAPE;
   if (!pangu_fits_u32(M, lddc, 4) || !pangu_fits_u32(M, lda, 4)) return PANGU_E_RANGE;
   hipStream_t s = (hipStream_t)stream;
-  static const int force_tnn = getenv("PANGU_WGRAD_TNN") ? atoi(getenv("PANGU_WGRAD_TNN")) : 0;   // tuning knob
   // measured (tools/bench_kernels.py wgrad): 192-row tiles win where 128-row tiles would be part empty (N = 192, 576, 160)
   // and at N = 1152 (12 instead of 18 tiles per slab); 128-row tiles win at N = 384, 768, 1536
-  const bool wide = force_tnn ? force_tnn == 3 : (N % 192 == 0 && N % 384 != 0) || (N > 128 && N < 192) || N == 1152;
-  static const int use_dma = getenv("PANGU_WGRAD_DMA") ? atoi(getenv("PANGU_WGRAD_DMA")) : 1;      // A/B knob
-  static const int dma_target = getenv("PANGU_WGRAD_DMA_WGS") ? atoi(getenv("PANGU_WGRAD_DMA_WGS")) : 768;    // measured sweep 768 / 1024 / 1536 / 2048: 768 best (1536 within 1 %)
-  if (use_dma) {
+  const bool wide = (N % 192 == 0 && N % 384 != 0) || (N > 128 && N < 192) || N == 1152;
+  constexpr int dma_target = 768;    // measured sweep 768 / 1024 / 1536 / 2048: 768 best (1536 within 1 %)
+  {
     const bool ws_ok = workspace != nullptr && workspace_bytes > 0 && (reinterpret_cast<size_t>(workspace) & 15) == 0;
     const int rc = pangu_linear_wgrad_f32_dma(s, dC, lddc, A, lda, dW, db, M, N, K, wide ? 3 : 2, dma_target,
                                               ws_ok ? workspace : nullptr, ws_ok ? (size_t)workspace_bytes : 0);

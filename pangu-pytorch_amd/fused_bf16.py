@@ -12,9 +12,6 @@ def _stamp(p):
     return ops.param_stamp(p)
 
 
-_BULK = os.environ.get("PANGU_SHADOW_BULK", "1") != "0"      # A/B knob: 0 = re-make stale shadows one tensor at a time with torch ops
-
-
 class WeightShadow:
     """bf16 copies of the projection weights and bias tables (and the transposed / packed weight images of the backward GEMMs
     and the fused MLP kernel), re-made when a parameter's stamp changes (ops.param_stamp).  Never pickled / deep-copied with
@@ -61,7 +58,7 @@ class WeightShadow:
 
     def _record(self, key, mode, params, dst, idx=None):
         """Remember how `dst` derives from `params` (all contiguous fp32 on dst's device), for the bulk refresh."""
-        if not _BULK or not dst.is_cuda or not dst.is_contiguous() or dst.dtype != torch.bfloat16:
+        if not dst.is_cuda or not dst.is_contiguous() or dst.dtype != torch.bfloat16:
             return
         if any(p.dtype != torch.float32 or not p.is_contiguous() or p.device != dst.device for p in params):
             return
@@ -155,7 +152,6 @@ class WeightShadow:
 
 
 _FUSE_LN = os.environ.get("PANGU_BF16_FUSE_LN", "1") != "0"      # A/B knob: 0 = separate GEMM + LN-residual launches
-_FUSE_LN384 = int(os.environ.get("PANGU_BF16_FUSE_LN384", "1"))   # C = 384: 0 = never, 1 = attention projection (measured -1.2 % on the forward), 2 = also MLP-down (unused: fused MLP)
 _FUSE_QKV = os.environ.get("PANGU_BF16_FUSE_QKV", "1") != "0"    # A/B knob: 0 = QKV projection as its own GEMM launch
 _FUSE_MLP = os.environ.get("PANGU_BF16_FUSE_MLP", "1") != "0"    # A/B knob: 0 = MLP-up, MLP-down(+LN) as separate launches
 
@@ -172,8 +168,8 @@ def _block(blk, sh, x, Z, H, W, roll, out=None):
     # loses what the fusion saves (measured), so stage 1/2 keeps the separate launches
     ok = _FUSE_LN and x.is_contiguous() and s1 == 1.0 and s2 == 1.0
     fuse = ok and C == 192
-    fuse_proj = fuse or (ok and C == 384 and _FUSE_LN384 >= 1)
-    fuse_mlp = fuse or (ok and C == 384 and _FUSE_LN384 >= 2)
+    fuse_proj = fuse or (ok and C == 384)      # C = 384: the attention projection only (-1.2 % on the forward); MLP-down: see below
+    fuse_mlp = fuse
     if s1 != 0.0:
         if _FUSE_QKV and C in (192, 384):
             # QKV projection inside the attention kernel: the (N, 3C) qkv tensor never reaches HBM

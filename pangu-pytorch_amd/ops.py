@@ -8,27 +8,6 @@ from . import _lib
 
 ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_ADD = 0, 1, 2, 3
 
-# fp32 projection arithmetic: False = exact f32 MFMA (default, the parity-tested headline path); True = opt-in
-# split-bf16 ("bf16x3") products on the bf16 matrix pipe (see csrc/gemm_f32x3.hip).
-_F32_SPLIT = False
-
-
-class f32_split:
-    """Context manager / switch: `with ops.f32_split(True): ...` routes fp32 projections through the bf16x3 kernel."""
-
-    def __init__(self, on):
-        self.on = bool(on)
-
-    def __enter__(self):
-        global _F32_SPLIT
-        self.prev, _F32_SPLIT = _F32_SPLIT, self.on
-        return self
-
-    def __exit__(self, *exc):
-        global _F32_SPLIT
-        _F32_SPLIT = self.prev
-
-
 # Optional live kernel timing (bench.py): HIP events recorded on the launch stream around each launch.
 _timing = None
 
@@ -314,10 +293,8 @@ def linear(a, weight, bias=None, act=ACT_NONE, out=None, aux=None):
         for m0, m1 in chunks:
             linear(a[m0:m1], weight, bias, act, out[m0:m1], aux[m0:m1] if aux is not None else None)
         return out
-    split = _F32_SPLIT and K % 8 == 0 and act != ACT_ADD
-    fn = lib.pangu_linear_fwd_f32x3 if split else lib.pangu_linear_fwd
-    with _timed("linear_x3" if split else "linear", 2.0 * M * N * K):
-        _lib.check(fn(_stream(a), ap, lda, wp, bp, op, ldc, M, N, K, act,
+    with _timed("linear", 2.0 * M * N * K):
+        _lib.check(lib.pangu_linear_fwd(_stream(a), ap, lda, wp, bp, op, ldc, M, N, K, act,
                       _chk(aux, "linear.aux") if aux is not None else None), "linear_fwd")
     return out
 

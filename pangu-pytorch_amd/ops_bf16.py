@@ -77,25 +77,6 @@ def window_attention_qkv(x, w_qkv, b_qkv, esb, Z, H, W, heads, shifted, want_lse
     return (out, lse) if want_lse else out
 
 
-def window_attention_qkv_train(x, w_qkv, b_qkv, esb, Z, H, W, heads, shifted):
-    """Training forward of `window_attention_qkv`: -> (out (N, C) bf16, lse (N, heads) fp32, qkv (N, 3C) bf16): the projected
-    qkv leaves as a side output of the same launch (what window_attention_bwd reads), no separate QKV GEMM."""
-    lib = _lib.load()
-    xp, ldx = _rows(x, "attn_qkv.x")
-    N, C = x.shape
-    if N != Z * H * W or tuple(w_qkv.shape) != (3 * C, C) or x.dtype != torch.bfloat16:
-        raise RuntimeError(f"window_attention_qkv_train: x {tuple(x.shape)} {x.dtype}, w_qkv {tuple(w_qkv.shape)}, grid {(Z, H, W)}")
-    out = torch.empty((N, C), dtype=torch.bfloat16, device=x.device)
-    lse = torch.empty((N, heads), dtype=torch.float32, device=x.device)
-    qkv = torch.empty((N, 3 * C), dtype=torch.bfloat16, device=x.device)
-    Np = (Z // 2) * ((H + 5) // 6) * (W // 12) * 144
-    with _timed("attn_qkv_bf16", 4.0 * Np * 144 * C + 6.0 * Np * C * C):
-        _lib.check(lib.pangu_window_attn_qkv_train_fwd_bf16(
-            _stream(x), xp, ldx, _p(w_qkv, "w_qkv"), _p(b_qkv, "b_qkv", torch.float32), _p(esb, "esb"), out.data_ptr(),
-            lse.data_ptr(), qkv.data_ptr(), Z, H, W, C, heads, int(shifted)), "window_attn_qkv_train_fwd_bf16")
-    return out, lse, qkv
-
-
 def linear_ln_residual(a, weight, bias, shortcut, gamma, beta, out=None):
     """out = shortcut + LayerNorm(a @ weight^T + bias) * gamma + beta in ONE launch (N = 192 or 384; inference path)."""
     lib = _lib.load()
@@ -197,9 +178,9 @@ def mlp_ln_residual(x, w_packed, b1, b2, gamma, beta, out=None, branch_scale=1.0
     return out
 
 
-def mlp_ln_residual_train(x, w_packed, b1, b2, gamma, beta, branch_scale=1.0, want_pre=True, out=None):
+def mlp_ln_residual_train(x, w_packed, b1, b2, gamma, beta, branch_scale=1.0, out=None):
     """Training forward of the MLP branch in ONE launch: -> (out, pre, m) with out as `mlp_ln_residual`, pre (M, 4C) bf16 =
-    x W1^T + b1 before the GELU (None with want_pre=False: the backward re-runs the MLP-up GEMM) and m (M, C) bf16 =
+    x W1^T + b1 before the GELU and m (M, C) bf16 =
     GELU(pre) W2^T + b2 before the LayerNorm.  h = GELU(pre) is not stored (linear_gelu_bwd re-creates it)."""
     lib = _lib.load()
     xp, ldx = _rows(x, "mlp.x")
@@ -212,12 +193,12 @@ def mlp_ln_residual_train(x, w_packed, b1, b2, gamma, beta, branch_scale=1.0, wa
         out = torch.empty((M, C), dtype=torch.bfloat16, device=x.device)
     op, ldo = _rows(out, "mlp.out")              # may be one half of the (M, 2C) skip-concat buffer
     m = torch.empty((M, C), dtype=torch.bfloat16, device=x.device)
-    pre = torch.empty((M, 4 * C), dtype=torch.bfloat16, device=x.device) if want_pre else None
+    pre = torch.empty((M, 4 * C), dtype=torch.bfloat16, device=x.device)
     with _timed("mlp_fused_bf16", 16.0 * M * C * C):
         _lib.check(lib.pangu_mlp_ln_residual_train_fwd_bf16(
             _stream(x), xp, ldx, _p(w_packed, "w_packed"), _p(b1, "b1", torch.float32), _p(b2, "b2", torch.float32),
             _p(gamma, "gamma", torch.float32), _p(beta, "beta", torch.float32), op, ldo,
-            pre.data_ptr() if want_pre else None, 4 * C, m.data_ptr(), C, M, C, float(branch_scale)),
+            pre.data_ptr(), 4 * C, m.data_ptr(), C, M, C, float(branch_scale)),
             "mlp_ln_residual_train_fwd_bf16")
     return out, pre, m
 

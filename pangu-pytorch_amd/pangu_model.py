@@ -47,11 +47,10 @@ class PanguModel(nn.Module):
         self.register_buffer("_c_maps", None, persistent=False)
         self.register_buffer("_c_const_h", None, persistent=False)
         self.compute_dtype = torch.float32
-        self.f32_split = False
         self._shadow = None
         self._compact_bias = False
 
-    def set_compute_dtype(self, dtype, f32_split=False):
+    def set_compute_dtype(self, dtype):
         """torch.float32 (default; parity <= 1e-3 with the reference) or torch.bfloat16 (inference: bf16 activations and
         weight shadows, fp32 LayerNorm/softmax/accumulation).  bf16 is also selected by an enclosing
         `torch.autocast("cuda", dtype=torch.bfloat16)` — the switch the reference leaves commented out at
@@ -59,9 +58,6 @@ class PanguModel(nn.Module):
         if dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
         self.compute_dtype = dtype
-        # f32_split (fp32 only, opt-in): projections evaluate their fp32 products as split-bf16 triples on the bf16
-        # matrix pipe (csrc/gemm_f32x3.hip): ~5x fewer matrix cycles, ~1e-5 instead of ~1e-7 relative error
-        self.f32_split = bool(f32_split) and dtype == torch.float32
         self.invalidate_shadows()
         return self
 
@@ -186,8 +182,7 @@ class PanguModel(nn.Module):
         from . import ops
         if self._compact_bias and not grad_path:
             self._build_compact_bias()            # no-op while the tables exist (dropped with the weight shadows)
-        with ops.f32_split(self.f32_split):
-            return self._forward_f32(input, input_surface, statistics, maps, const_h, grad_path)
+        return self._forward_f32(input, input_surface, statistics, maps, const_h, grad_path)
 
     def _forward_f32(self, input, input_surface, statistics, maps, const_h, grad_path):
         B = input.shape[0]

@@ -84,12 +84,9 @@ class WeightedL1LossFn(torch.autograd.Function):
         return d_o, d_os, None, None
 
 
-_HIP_LOSS = __import__("os").environ.get("PANGU_HIP_LOSS", "1") != "0"      # A/B knob: 0 = the torch expression on every device
-
-
 def _hip_loss_ok(output, output_surface, target, target_surface):
     ts = (output, output_surface, target, target_surface)
-    return (_HIP_LOSS and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.device == output.device for t in ts)
+    return (all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.device == output.device for t in ts)
             and output.dim() == 5 and output_surface.dim() == 4 and output.shape == target.shape
             and output_surface.shape == target_surface.shape and output.shape[0] == output_surface.shape[0]
             and output.shape[1] == len(UPPER_WEIGHTS) and output_surface.shape[1] == len(SURFACE_WEIGHTS)
@@ -152,7 +149,7 @@ class HipAdam(torch.optim.Optimizer):
         for gi, group in enumerate(self.param_groups):
             rows, first, dev = [], 0, None
             beta1, beta2 = group["betas"]
-            ws = getattr(self._shadow_of, "_shadow", None) if self._shadow_of is not None and _ADAM_SHADOW else None
+            ws = getattr(self._shadow_of, "_shadow", None) if self._shadow_of is not None else None
             imaged = []
             for p in group["params"]:
                 if p.grad is None and not (missing_as_zero and p.requires_grad):
@@ -220,17 +217,12 @@ class HipAdam(torch.optim.Optimizer):
         return loss
 
 
-_HIP_ADAM = __import__("os").environ.get("PANGU_HIP_ADAM", "1") != "0"      # A/B knob: 0 = torch.optim.Adam(fused=True)
-_ADAM_SHADOW = __import__("os").environ.get("PANGU_ADAM_SHADOW", "1") != "0"      # A/B knob: 0 = HipAdam leaves every bf16 image to the refresh launch
-
-
 def make_optimizer(model, lr=5e-6, weight_decay=3e-6):
     """The reference's optimiser (finetune_fully.py:121: Adam(lr=5e-6, weight_decay=3e-6)).  Parameters on a HIP device: the
-    one-launch HipAdam above (bit-identical to torch's fused Adam, whose single-kernel multi-tensor form -- one launch instead
-    of ~10 per parameter tensor -- is what PANGU_HIP_ADAM=0 selects); CPU parameters (host-side tests): torch.optim.Adam."""
+    one-launch HipAdam above (bit-identical to torch's fused Adam); CPU parameters (host-side tests): torch.optim.Adam."""
     params = [p for p in model.parameters() if p.requires_grad]
     on_gpu = all(p.is_cuda for p in params)
-    if on_gpu and _HIP_ADAM and all(p.dtype == torch.float32 and p.is_contiguous() for p in params):
+    if on_gpu and all(p.dtype == torch.float32 and p.is_contiguous() for p in params):
         return HipAdam(params, lr=lr, weight_decay=weight_decay, shadow_of=model)
     return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, fused=on_gpu)
 

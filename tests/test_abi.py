@@ -43,10 +43,12 @@ def test_argument_validation_without_gpu():
     P8 = 8          # any non-NULL address: the calls below return before touching memory
     assert lib.pangu_mlp_ln_residual_train_fwd_bf16(None, P8, 192, P8, P8, P8, P8, P8, P8, 192, P8, 768, None, 192, 64, 192, 1.0) == -2   # m is required
     assert lib.pangu_mlp_ln_residual_train_fwd_bf16(None, P8, 192, P8, P8, P8, P8, P8, P8, 192, P8, 760, P8, 192, 64, 192, 1.0) == -1    # ldp < 4C
-    assert lib.pangu_mlp_ln_residual_train_fwd_bf16(None, P8, 256, P8, P8, P8, P8, P8, P8, 256, None, 0, P8, 256, 64, 256, 1.0) == -1    # C not 192 / 384
+    assert lib.pangu_mlp_ln_residual_train_fwd_bf16(None, P8, 256, P8, P8, P8, P8, P8, P8, 256, P8, 1024, P8, 256, 64, 256, 1.0) == -1   # C not 192 / 384
+    assert lib.pangu_mlp_ln_residual_train_fwd_bf16(None, P8, 192, P8, P8, P8, P8, P8, P8, 192, None, 768, P8, 192, 64, 192, 1.0) == -2   # pre is required
     assert lib.pangu_linear_gelu_bwd_bf16(None, P8, 192, P8, P8, 768, 64, 768, 192, None, None) == -2                                   # pre is required
     assert lib.pangu_linear_gelu_bwd_bf16(None, P8, 192, P8, P8, 760, 64, 768, 192, P8, None) == -1                                    # ldc < N
-    assert lib.pangu_window_attn_qkv_train_fwd_bf16(None, P8, 192, P8, P8, P8, P8, P8, None, 8, 181, 24, 192, 6, 0) == -2              # qkv_out is required
+    assert lib.pangu_attn_windows_fwd(None, P8, P8, None, 0, P8, 2, 124, 5, 192) == -1                                                 # C != 32 * heads
+    assert lib.pangu_attn_windows_fwd(None, P8, P8, P8, 7, P8, 2, 124, 6, 192) == -4                                                   # mask stride
     assert lib.pangu_patch_recover_scatter_denorm(None, P8, P8, P8, P8, P8, P8, P8, P8, P8, None, 721, 1440) == -2
     assert lib.pangu_patch_recover_scatter_denorm(None, P8, P8, P8, P8, P8, P8, P8, P8, P8, P8, 721, 1442) == -1                       # LON % 4
     # 32-bit buffer offsets of the attention backward kernels: a grid whose (n_tok x 3C) tensor reaches 2 GiB is refused

@@ -114,24 +114,6 @@ def test_window_attention_bwd(P, C, shifted):
     assert rel_err(dqkv, qkv.grad[0]) < TIGHT
     assert rel_err(desb, esb.grad[0]) < TIGHT
     assert rel_err(dqb, b1.grad) < TIGHT
-    if C == 384:
-        # the instantiation without the `nt` cache hints (PANGU_ATTN_BWD_NT=0, read once per process) gives the same bits
-        import subprocess
-        import sys
-        import tempfile
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        with tempfile.TemporaryDirectory() as d:
-            torch.save((qkv[0].detach(), b1.detach(), esb[0].detach(), o.cpu(), lse.cpu(), do[0], Z, H, W, heads, shifted),
-                       os.path.join(d, "in.pt"))
-            code = ("import sys, torch; sys.path.insert(0, %r); import pangu_pytorch_amd as P\n"
-                    "a = torch.load(%r)\n"
-                    "r = P.ops.window_attention_bwd(*[x.cuda() if torch.is_tensor(x) else x for x in a])\n"
-                    "torch.save(tuple(x.cpu() for x in r), %r)\n") % (root, os.path.join(d, "in.pt"), os.path.join(d, "out.pt"))
-            subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, PANGU_ATTN_BWD_NT="0"))
-            d0, b0, e0 = torch.load(os.path.join(d, "out.pt"))
-        assert torch.equal(d0.cuda(), dqkv) and torch.equal(e0.cuda(), desb)
-        assert rel_err(b0.cuda(), dqb) < 1e-5            # the pad-key sums go through atomics: order-dependent rounding
-
 
 @pytest.mark.parametrize("Z,H,W,heads", [(4, 7, 24, 3), (2, 13, 12, 2)])
 @pytest.mark.parametrize("shifted", [False, True])

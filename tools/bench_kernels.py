@@ -43,10 +43,6 @@ def gemm(lib_compare):
         out = torch.empty(M, N, device="cuda")
         ms = timeit(lambda: ops.linear(a, w, b, act=act, out=out))
         line = f"{name:14s} M={M:6d} N={N:4d} K={K:4d}  {ms:7.3f} ms  {2.0 * M * N * K / ms / 1e9:6.1f} TF/s"
-        if K % 8 == 0:
-            with ops.f32_split(True):
-                ms3 = timeit(lambda: ops.linear(a, w, b, act=act, out=out))
-            line += f"   | x3 {ms3:7.3f} ms {2.0 * M * N * K / ms3 / 1e9:6.1f} TF/s {(M * K + M * N) * 4.0 / ms3 / 1e6:7.1f} GB/s"
         if lib_compare:
             f = (lambda: torch.nn.functional.gelu(torch.addmm(b, a, w.t()))) if act else (lambda: torch.addmm(b, a, w.t()))
             ms2 = timeit(f)
@@ -112,7 +108,6 @@ def mlp_train():
         img = ob.pack_mlp_weights(w1, w2)
         t_inf = timeit(lambda: ob.mlp_ln_residual(x, img, b1, b2, g, be))
         t_tr = timeit(lambda: ob.mlp_ln_residual_train(x, img, b1, b2, g, be))
-        t_m = timeit(lambda: ob.mlp_ln_residual_train(x, img, b1, b2, g, be, want_pre=False))
 
         def sep():
             pre = torch.empty((M, 4 * C), dtype=bf, device="cuda")
@@ -125,7 +120,7 @@ def mlp_train():
         t_b0 = timeit(lambda: ob.linear(dm, w2t, None, act=ob.ACT_GELU_BWD, aux=pre))
         t_b1 = timeit(lambda: ob.linear_gelu_bwd(dm, w2t, pre))
         print(f"{name} MLP forward  M={M:6d} C={C:3d}: inference launch {t_inf:6.3f} ms | training launch (pre + m out) {t_tr:6.3f} | "
-              f"training launch (m only: recompute mode) {t_m:6.3f} | three launches writing pre AND h {t_sep:6.3f}")
+              f"three launches writing pre AND h {t_sep:6.3f}")
         print(f"{name} MLP backward M={M:6d} C={C:3d}: dpre = (dm W2) * gelu'(pre) {t_b0:6.3f} ms | the same + h = GELU(pre) written {t_b1:6.3f}")
 
 

@@ -33,18 +33,15 @@ for DT in f32 bf16; do
 done
 python3 tools/pmc_train_table.py --json gpurun_out/pmc_train.json /tmp/trpmc_f32 /tmp/trpmc_bf16 2 && cp gpurun_out/pmc_train.json profiles/
 {
-  echo "## attn_qkv_bf16 with PANGU_ATTN_QKV_X=1 (rows register-resident, one workgroup per window: C = 192 only)"
-  PANGU_ATTN_QKV_X=1 timeout 400 python3 tools/bench_kernels.py attn_qkv_bf16 2>&1 | grep -v "amdgpu.ids"
   for sec in mlp_fused mlp_train attn_qkv_bf16 attn_bf16 gemm_bf16 wgrad_bf16 gemm_ln_bf16 attn attn_bwd gemm wgrad; do
     echo "## $sec"
     timeout 400 python3 tools/bench_kernels.py $sec --lib-compare 2>&1 | grep -v "amdgpu.ids"
   done
 } > gpurun_out/${TAG}_kernel_microbench.txt
-# training-step A/B of the round's knobs (one process per arm, interleaved, two rounds)
+# training-step A/B of the one remaining training knob (one process per arm, interleaved, two rounds)
 {
   for r in 1 2; do
-    for m in 0 1 3; do echo "PANGU_BF16_TRAIN_MLP=$m: $(PANGU_BF16_TRAIN_MLP=$m timeout 300 python3 tools/profile_train.py bf16 6 2 2>&1 | grep train)"; done
-    echo "PANGU_BF16_TRAIN_QKV=1: $(PANGU_BF16_TRAIN_QKV=1 timeout 300 python3 tools/profile_train.py bf16 6 2 2>&1 | grep train)"
+    for m in 0 1; do echo "PANGU_BF16_TRAIN_MLP=$m: $(PANGU_BF16_TRAIN_MLP=$m timeout 300 python3 tools/profile_train.py bf16 6 2 2>&1 | grep train)"; done
   done
 } > gpurun_out/${TAG}_train_ab.txt 2>&1
 timeout 900 python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
