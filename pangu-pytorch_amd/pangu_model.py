@@ -179,7 +179,6 @@ class PanguModel(nn.Module):
             if grad_path:
                 return autograd_bf16.forward_train(self, input, input_surface, statistics, maps, const_h)
             return fused_bf16.forward(self, input, input_surface, statistics, maps, const_h)
-        from . import ops
         if self._compact_bias and not grad_path:
             self._build_compact_bias()            # no-op while the tables exist (dropped with the weight shadows)
         return self._forward_f32(input, input_surface, statistics, maps, const_h, grad_path)
