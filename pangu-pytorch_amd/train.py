@@ -135,9 +135,8 @@ class HipAdam(torch.optim.Optimizer):
         """missing_as_zero: parameters without a gradient are stepped with a ZERO gradient (moments decay, weight decay applies)
         instead of being skipped -- what the reference's DropPath-dropped branches get (the branch is computed and multiplied by
         zero there) -- without materialising the zeros."""
+        import math
         import struct
-
-        import numpy as np
 
         from . import _lib
         from .ops import _stream
@@ -186,8 +185,10 @@ class HipAdam(torch.optim.Optimizer):
                 continue
             if group.get("amsgrad") or group.get("maximize"):
                 raise RuntimeError("HipAdam implements torch.optim.Adam without amsgrad / maximize (a loaded state_dict asked for them)")
-            # ATen's fused Adam (FusedAdamUtils / adam_math): bias_correction2 is rounded to float BEFORE the square root
-            bias = lambda k: (1.0 - beta1 ** k, float(np.sqrt(np.float32(1.0 - beta2 ** k))))
+            # ATen's fused Adam (ATen/native/cuda/fused_adam_utils.cuh:130-137, torch 2.10): both corrections AND the square root
+            # are formed in double (`std::pair<double, double>`), then narrowed to the float arguments of adam_math -- checked bit
+            # for bit over 40 steps by tests/test_gpu_hardening.py (rounding to float before the root, as ADVICE r3 suggested, breaks it)
+            bias = lambda k: (1.0 - beta1 ** k, math.sqrt(1.0 - beta2 ** k))
             uniform = all(r[6] == rows[0][6] for r in rows)
             # the table holds pointers (and per-tensor bias corrections only when the step counts differ): with gradients that keep
             # their addresses -- FlatGradSync's flat buffer, or the caching allocator handing the same blocks back every step -- it
