@@ -148,9 +148,12 @@ int pangu_ln_residual_bwd(pangu_stream_t stream, const float* dout, int lddo, co
 int pangu_downsample_ln_fwd(pangu_stream_t stream, const float* x, int ldx, const float* gamma,
                             const float* beta, float* out, float* mean_rstd, int Z, int H, int W, int C);
 
-/* Backward: dout [rows][4C] -> dx [Z*H*W][C] (overwritten, every token once); dgamma/dbeta [4C] ACCUMULATED. */
+/* Backward: dout [rows][4C] -> dx [Z*H*W][C] (overwritten, every token once); dgamma/dbeta [4C] ACCUMULATED.
+ * dx_add (may be NULL): a second gradient of the same tokens, dense [Z*H*W][C] -- the skip connection's (reference
+ * pangu_model.py:62,81: layer 0's output feeds both the down-sampling and the channel concat) -- added to dx in this pass
+ * instead of by a separate elementwise kernel. */
 int pangu_downsample_ln_bwd(pangu_stream_t stream, const float* dout, const float* x, int ldx, const float* gamma,
-                            float* dx, float* dgamma, float* dbeta, int Z, int H, int W, int C);
+                            float* dx, float* dgamma, float* dbeta, int Z, int H, int W, int C, const float* dx_add);
 
 /* UpSample pixel-shuffle + crop + LayerNorm(Co): y[Z][H2][W2][4*Co] -> out[Z][H][2*W2][Co] with
  * out[z][2h+dh][2w+dw][c] = y[z][h][w][dh*2Co + dw*Co + c], rows h >= H dropped.  Reference layers.py:480-495.
@@ -281,7 +284,7 @@ int pangu_window_attn_bwd_bf16(pangu_stream_t stream, const void* qkv, const voi
 int pangu_ln_residual_bwd_bf16(pangu_stream_t stream, const void* dout, int lddo, const void* y, const float* gamma,
                                void* dy, float* dgamma, float* dbeta, int N, int C, float branch_scale);
 int pangu_downsample_ln_bwd_bf16(pangu_stream_t stream, const void* dout, const void* x, int ldx, const float* gamma,
-                                 void* dx, float* dgamma, float* dbeta, int Z, int H, int W, int C);
+                                 void* dx, float* dgamma, float* dbeta, int Z, int H, int W, int C, const void* dx_add);
 int pangu_upsample_ln_bwd_bf16(pangu_stream_t stream, const void* dout, const void* y, const float* gamma, void* dy,
                                float* dgamma, float* dbeta, int Z, int H2, int W2, int H, int Co);
 int pangu_patch_recover_gather_bwd_bf16(pangu_stream_t stream, const float* d_output, const float* d_output_surface,

@@ -29,7 +29,7 @@ SIGNATURES = {
     "pangu_linear_wgrad_ws": [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _P, _c.c_longlong],
     "pangu_window_attn_bwd": [_P] * 10 + [_I] * 6,
     "pangu_ln_residual_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _F],
-    "pangu_downsample_ln_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I],
+    "pangu_downsample_ln_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "pangu_upsample_ln_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I],
     "pangu_patch_recover_gather_bwd": [_P, _P, _P, _P, _P, _I, _I],
     "pangu_lat_weighted_sums": [_P, _P, _P, _P, _P, _I, _I, _I],
@@ -53,7 +53,7 @@ SIGNATURES = {
     "pangu_weighted_l1_loss_bwd": [_P] * 10 + [_I, _I, _c.c_longlong, _I, _c.c_longlong],
     "pangu_window_attn_bwd_bf16": [_P] * 10 + [_I] * 6,
     "pangu_ln_residual_bwd_bf16": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _F],
-    "pangu_downsample_ln_bwd_bf16": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I],
+    "pangu_downsample_ln_bwd_bf16": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "pangu_upsample_ln_bwd_bf16": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I],
     "pangu_patch_recover_gather_bwd_bf16": [_P, _P, _P, _P, _P, _I, _I],
     "pangu_window_attn_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I],

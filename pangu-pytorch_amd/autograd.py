@@ -51,14 +51,7 @@ class EarthBlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        C = dout.shape[-1]
-        # every atomically accumulated gradient buffer of the block (4 weight+bias pairs, 2 LayerNorm pairs, the pad-slot
-        # bias gradient: 12 C^2 + 16 C floats) comes out of ONE zero fill
-        with ops.zero_arena(12 * C * C + 64 * C, dout.device):
-            return EarthBlockFn._backward(ctx, dout)
-
-    @staticmethod
-    def _backward(ctx, dout):
+        # (every atomically accumulated gradient buffer of the whole backward pass comes out of ONE zero fill: ops._zeros)
         Z, H, W, heads, shifted = ctx.geom
         s1, s2 = ctx.s1, ctx.s2
         sv = list(ctx.saved_tensors)
@@ -134,11 +127,15 @@ class DownSampleFn(torch.autograd.Function):
     """reference models/layers.py:432-459 for one sample."""
 
     @staticmethod
-    def forward(ctx, x, lw, nw, nb, geom):
+    def forward(ctx, x, lw, nw, nb, geom, skip_grad=None):
+        # skip_grad: one-slot list shared with PatchRecoverHalvesFn (the skip connection's other gradient, summed inside the
+        # down-sampling backward kernel instead of by autograd's elementwise add): see autograd_bf16.DownSampleFnBF16
         Z, H, W = geom
         g = ops.downsample_ln(x, nw, nb, Z, H, W)
         ctx.save_for_backward(x, g, lw, nw)
-        ctx.geom = geom
+        ctx.geom, ctx.skip_grad = geom, skip_grad
+        if skip_grad is not None:
+            skip_grad[1] = True
         return ops.linear(g, lw)
 
     @staticmethod
@@ -148,8 +145,11 @@ class DownSampleFn(torch.autograd.Function):
         dout = dout.contiguous()
         dlw, _ = ops.linear_wgrad(dout, g, want_bias=False)
         dg = ops.linear(dout, _wt(lw))
-        dx, dnw, dnb = ops.downsample_ln_bwd(dg, x, nw, Z, H, W)
-        return dx, dlw, dnw, dnb, None
+        add = None
+        if ctx.skip_grad is not None:
+            add, ctx.skip_grad[0] = ctx.skip_grad[0], None
+        dx, dnw, dnb = ops.downsample_ln_bwd(dg, x, nw, Z, H, W, add=add)
+        return dx, dlw, dnw, dnb, None, None
 
 
 class UpSampleFn(torch.autograd.Function):
@@ -208,7 +208,8 @@ class PatchRecoverHalvesFn(torch.autograd.Function):
     its own DENSE gradient in the backward (two N = C products instead of row-strided views of one N = 2C product)."""
 
     @staticmethod
-    def forward(ctx, skip, x, cw, cb, sw, sb, geom):
+    def forward(ctx, skip, x, cw, cb, sw, sb, geom, skip_grad=None):
+        ctx.skip_grad = skip_grad
         n_s, LAT, LON = geom
         N, C = skip.shape
         assert skip.stride() == (2 * C, 1) and x.stride() == (2 * C, 1) and x.data_ptr() == skip.data_ptr() + 4 * C
@@ -233,4 +234,7 @@ class PatchRecoverHalvesFn(torch.autograd.Function):
         for dst, rows in ((d_skip, slice(0, C)), (d_x, slice(C, 2 * C))):
             ops.linear(dy_s, wt_s[rows], out=dst[:n_s])
             ops.linear(dy_u, wt_u[rows], out=dst[n_s:])
-        return d_skip, d_x, dcw.reshape(cw.shape), dcb, dsw.reshape(sw.shape), dsb, None
+        sg = ctx.skip_grad
+        if sg is not None and sg[1] and ctx.needs_input_grad[0]:
+            sg[0], d_skip = d_skip, None          # the down-sampling backward adds it in its own pass (DownSampleFn)
+        return d_skip, d_x, dcw.reshape(cw.shape), dcb, dsw.reshape(sw.shape), dsb, None, None

@@ -59,14 +59,7 @@ class EarthBlockFnBF16(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        C = dout.shape[-1]
-        # every atomically accumulated gradient buffer of the block (4 weight+bias pairs, 2 LayerNorm pairs, the pad-slot
-        # bias gradient: 12 C^2 + 16 C floats) comes out of ONE zero fill
-        with ops.zero_arena(12 * C * C + 64 * C, dout.device):
-            return EarthBlockFnBF16._backward(ctx, dout)
-
-    @staticmethod
-    def _backward(ctx, dout):
+        # (every atomically accumulated gradient buffer of the whole backward pass comes out of ONE zero fill: ops._zeros)
         Z, H, W, heads, shifted = ctx.geom
         s1, s2, sh = ctx.s1, ctx.s2, ctx.sh
         n1w, n2w, m1w, m2w, esb, a1w, a1b, a2w, m1b = ctx.params
@@ -153,11 +146,16 @@ class PatchEmbedFnBF16(torch.autograd.Function):
 
 class DownSampleFnBF16(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, lw, nw, nb, geom, sh):
+    def forward(ctx, x, lw, nw, nb, geom, sh, skip_grad=None):
+        # skip_grad: a one-slot list shared with PatchRecoverFnBF16 -- x is the skip connection (reference pangu_model.py:62, :81),
+        # whose OTHER gradient (through the channel concat) that function leaves in the slot instead of handing it to autograd:
+        # the backward below sums the two inside the down-sampling kernel (no elementwise add over the 200 MB)
         Z, H, W = geom
         g = ob.downsample_ln(x, nw, nb, Z, H, W)
         ctx.save_for_backward(x, g)
-        ctx.geom, ctx.sh, ctx.params = geom, sh, (lw, nw)
+        ctx.geom, ctx.sh, ctx.params, ctx.skip_grad = geom, sh, (lw, nw), skip_grad
+        if skip_grad is not None:
+            skip_grad[1] = True                  # armed: this node's backward will consume the slot
         return ob.linear(g, sh.get(lw))
 
     @staticmethod
@@ -168,8 +166,11 @@ class DownSampleFnBF16(torch.autograd.Function):
         dout = dout.contiguous()
         dlw, _ = ob.linear_wgrad(dout, g, want_bias=False)
         dg = ob.linear(dout, ctx.sh.get_t(lw))
-        dx, dnw, dnb = ob.downsample_ln_bwd(dg, x, nw, Z, H, W)
-        return dx, dlw, dnw, dnb, None, None
+        add = None
+        if ctx.skip_grad is not None:
+            add, ctx.skip_grad[0] = ctx.skip_grad[0], None
+        dx, dnw, dnb = ob.downsample_ln_bwd(dg, x, nw, Z, H, W, add=add)
+        return dx, dlw, dnw, dnb, None, None, None
 
 
 class UpSampleFnBF16(torch.autograd.Function):
@@ -203,7 +204,8 @@ class PatchRecoverFnBF16(torch.autograd.Function):
     row-strided views: the consumers' fast paths want dense rows)."""
 
     @staticmethod
-    def forward(ctx, skip, x, cw, cb, sw, sb, geom, sh):
+    def forward(ctx, skip, x, cw, cb, sw, sb, geom, sh, skip_grad=None):
+        ctx.skip_grad = skip_grad
         n_s, LAT, LON = geom
         N, C = skip.shape
         adjacent = (skip.stride() == (2 * C, 1) and x.stride() == (2 * C, 1) and x.data_ptr() == skip.data_ptr() + 2 * C
@@ -230,7 +232,10 @@ class PatchRecoverFnBF16(torch.autograd.Function):
         for dst, rows in ((d_skip, slice(0, C)), (d_x, slice(C, 2 * C))):
             ob.linear(dy_s, wt_s[rows], out=dst[:n_s])
             ob.linear(dy_u, wt_u[rows], out=dst[n_s:])
-        return d_skip, d_x, dcw.reshape(cw.shape), dcb, dsw.reshape(sw.shape), dsb, None, None
+        sg = ctx.skip_grad
+        if sg is not None and sg[1] and ctx.needs_input_grad[0]:
+            sg[0], d_skip = d_skip, None          # the down-sampling backward adds it in its own pass (DownSampleFnBF16)
+        return d_skip, d_x, dcw.reshape(cw.shape), dcb, dsw.reshape(sw.shape), dsb, None, None, None
 
 
 def forward_train(model, inp, inp_surface, statistics, maps, const_h):
@@ -275,13 +280,14 @@ def forward_train(model, inp, inp_surface, statistics, maps, const_h):
         halves = [torch.empty(0, dtype=torch.bfloat16, device=dev).set_(cat.untyped_storage(), cat.storage_offset() + off, (Nn, Cc), (2 * Cc, 1))
                   for off in (0, Cc)]
         skip = run_layer(model.layers[0], x, 8, H4, W4, out=halves[0])
-        x = DownSampleFnBF16.apply(skip, dn.linear.weight, dn.norm.weight, dn.norm.bias, (8, H4, W4), sh)
+        skip_grad = [None, False]                 # [the concat path's gradient of `skip`, armed]: see DownSampleFnBF16
+        x = DownSampleFnBF16.apply(skip, dn.linear.weight, dn.norm.weight, dn.norm.bias, (8, H4, W4), sh, skip_grad)
         x = run_layer(model.layers[1], x, 8, H2, W2)
         x = run_layer(model.layers[2], x, 8, H2, W2)
         x = UpSampleFnBF16.apply(x, up.linear1.weight, up.linear2.weight, up.norm.weight, up.norm.bias, (8, H2, W2, H4), sh)
         x = run_layer(model.layers[3], x, 8, H4, W4, out=halves[1])
         o, os_ = PatchRecoverFnBF16.apply(skip, x, rec.conv.weight, rec.conv.bias, rec.conv_surface.weight,
-                                          rec.conv_surface.bias, (H4 * W4, LAT, LON), sh)
+                                          rec.conv_surface.bias, (H4 * W4, LAT, LON), sh, skip_grad)
         outs.append(o)
         outs_s.append(os_)
     if B == 1:

@@ -337,7 +337,8 @@ template <int UNR>
 __global__ __launch_bounds__(256) void downsample_ln_bwd_bf16_v16_kernel(const u16* __restrict__ dout, const u16* __restrict__ x,
                                                                          int ldx, const float* __restrict__ gamma,
                                                                          u16* __restrict__ dx, float* __restrict__ dgamma,
-                                                                         float* __restrict__ dbeta, int Z, int H, int W, int C) {
+                                                                         float* __restrict__ dbeta, int Z, int H, int W, int C,
+                                                                         const u16* __restrict__ add) {
   __shared__ float red[2 * 4 * 1024];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -404,10 +405,18 @@ __global__ __launch_bounds__(256) void downsample_ln_bwd_bf16_v16_kernel(const u
       const float m1 = wave_sum(s1) * inv_c, m2 = wave_sum(s2) * inv_c;
       if (src[u] >= 0) {
         u32x4 o0, o1;
+        float ad[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) ad[c] = 0.f;
+        if (add) {                                       // a second gradient of the same tokens (the skip connection's): summed here
+          unpack8(*reinterpret_cast<const u32x4*>(add + src[u]), ad);
+          unpack8(*reinterpret_cast<const u32x4*>(add + src[u] + 8), ad + 8);
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          o0[c] = pack_bf16x2((gg[2 * c] - m1 - y[2 * c] * m2) * rstd, (gg[2 * c + 1] - m1 - y[2 * c + 1] * m2) * rstd);
-          o1[c] = pack_bf16x2((gg[8 + 2 * c] - m1 - y[8 + 2 * c] * m2) * rstd, (gg[9 + 2 * c] - m1 - y[9 + 2 * c] * m2) * rstd);
+          o0[c] = pack_bf16x2((gg[2 * c] - m1 - y[2 * c] * m2) * rstd + ad[2 * c], (gg[2 * c + 1] - m1 - y[2 * c + 1] * m2) * rstd + ad[2 * c + 1]);
+          o1[c] = pack_bf16x2((gg[8 + 2 * c] - m1 - y[8 + 2 * c] * m2) * rstd + ad[8 + 2 * c],
+                              (gg[9 + 2 * c] - m1 - y[9 + 2 * c] * m2) * rstd + ad[9 + 2 * c]);
         }
         *reinterpret_cast<u32x4*>(dx + src[u]) = o0;
         *reinterpret_cast<u32x4*>(dx + src[u] + 8) = o1;
@@ -529,7 +538,7 @@ __global__ __launch_bounds__(256) void downsample_ln_bwd_kernel(const T* __restr
                                                                 const T* __restrict__ x, int ldx,
                                                                 const float* __restrict__ gamma, T* __restrict__ dx,
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                int Z, int H, int W, int C) {
+                                                                int Z, int H, int W, int C, const T* __restrict__ add) {
   extern __shared__ __attribute__((aligned(16))) float red[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int H2 = (H + 1) / 2, W2 = W / 2, C4 = 4 * C, nvec = C4 >> 2, cvec = C >> 2;
@@ -558,7 +567,7 @@ __global__ __launch_bounds__(256) void downsample_ln_bwd_kernel(const T* __restr
     row_ln_bwd<NV>(y, g, nvec, lane, C4, gamma, dg, db);
 #pragma unroll
     for (int i = 0; i < NV; ++i)
-      if (lane + 64 * i < nvec && real[i]) st4(dx + src[i], y[i]);
+      if (lane + 64 * i < nvec && real[i]) st4(dx + src[i], add ? y[i] + ld4(add + src[i]) : y[i]);
   }
   flush_param_grads<NV>(dg, db, nvec, lane, wave, dgamma, dbeta, red);
 }
@@ -682,12 +691,12 @@ extern "C" int pangu_ln_residual_bwd(pangu_stream_t stream, const float* dout, i
 
 extern "C" int pangu_downsample_ln_bwd(pangu_stream_t stream, const float* dout, const float* x, int ldx,
                                        const float* gamma, float* dx, float* dgamma, float* dbeta, int Z, int H, int W,
-                                       int C) {
+                                       int C, const float* dx_add) {
   if (!dout || !x || !gamma || !dx || !dgamma || !dbeta) return PANGU_E_NULL;
   if (Z <= 0 || H <= 0 || W <= 0 || (W & 1) || (C & 3) || 4 * C > 1024 || ldx < C || (ldx & 3)) return PANGU_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   dim3 g(row_grid(Z * ((H + 1) / 2) * (W / 2))), b(256);
-  PANGU_NV_DISPATCH(4 * C, downsample_ln_bwd_kernel, float, dout, x, ldx, gamma, dx, dgamma, dbeta, Z, H, W, C);
+  PANGU_NV_DISPATCH(4 * C, downsample_ln_bwd_kernel, float, dout, x, ldx, gamma, dx, dgamma, dbeta, Z, H, W, C, dx_add);
   return pangu_launch_status();
 }
 
@@ -749,7 +758,7 @@ extern "C" int pangu_ln_residual_bwd_bf16(pangu_stream_t stream, const void* dou
 
 extern "C" int pangu_downsample_ln_bwd_bf16(pangu_stream_t stream, const void* dout, const void* x, int ldx,
                                             const float* gamma, void* dx, float* dgamma, float* dbeta, int Z, int H, int W,
-                                            int C) {
+                                            int C, const void* dx_add) {
   if (!dout || !x || !gamma || !dx || !dgamma || !dbeta) return PANGU_E_NULL;
   if (Z <= 0 || H <= 0 || W <= 0 || (W & 1) || (C & 3) || 4 * C > 1024 || ldx < C || (ldx & 3)) return PANGU_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
@@ -758,11 +767,11 @@ extern "C" int pangu_downsample_ln_bwd_bf16(pangu_stream_t stream, const void* d
   if (fast && (C & 15) == 0 && C <= 256 && (ldx & 7) == 0) {
     const int rows = Z * ((H + 1) / 2) * (W / 2), blocks = (rows + 7) / 8;
     hipLaunchKernelGGL(downsample_ln_bwd_bf16_v16_kernel<2>, dim3(blocks < 2048 ? blocks : 2048), b, 0, s, (const u16*)dout,
-                       (const u16*)x, ldx, gamma, (u16*)dx, dgamma, dbeta, Z, H, W, C);
+                       (const u16*)x, ldx, gamma, (u16*)dx, dgamma, dbeta, Z, H, W, C, (const u16*)dx_add);
     return pangu_launch_status();
   }
   PANGU_NV_DISPATCH(4 * C, downsample_ln_bwd_kernel, u16, (const u16*)dout, (const u16*)x, ldx, gamma, (u16*)dx, dgamma,
-                    dbeta, Z, H, W, C);
+                    dbeta, Z, H, W, C, (const u16*)dx_add);
   return pangu_launch_status();
 }
 

@@ -142,10 +142,10 @@ def patch_embed(m, inp, inp_surface, statistics, maps, const_h):
     return x
 
 
-def down_sample(m, x, Z, H, W):
+def down_sample(m, x, Z, H, W, skip_grad=None):
     B, N, C = x.shape
     if _train_path(m, x):
-        return _stack([DownSampleFn.apply(xb, m.linear.weight, m.norm.weight, m.norm.bias, (Z, H, W))
+        return _stack([DownSampleFn.apply(xb, m.linear.weight, m.norm.weight, m.norm.bias, (Z, H, W), skip_grad if B == 1 else None)
                        for xb in _samples(x)], B)
     outs = []
     for b in range(B):
@@ -174,11 +174,11 @@ def up_sample(m, x, Z, H2, W2, H, out=None):
     return out
 
 
-def patch_recover_halves(m, skip, x, Z, H, W, LAT=721, LON=1440):
+def patch_recover_halves(m, skip, x, Z, H, W, LAT=721, LON=1440, skip_grad=None):
     """Training path, B = 1: reference layers.py:511-545 on cat(skip, x) where skip / x (1, N, C) are the two halves of one
     (N, 2C) buffer (PanguModel._forward_f32)."""
     o, os_ = PatchRecoverHalvesFn.apply(skip[0], x[0], m.conv.weight, m.conv.bias, m.conv_surface.weight, m.conv_surface.bias,
-                                        (H * W, LAT, LON))
+                                        (H * W, LAT, LON), skip_grad)
     return o.unsqueeze(0), os_.unsqueeze(0)
 
 

@@ -211,8 +211,8 @@ class DownSample(nn.Module):
         self.linear = nn.Linear(in_features=4 * dim, out_features=2 * dim, bias=False)
         self.norm = nn.LayerNorm(4 * dim)
 
-    def forward(self, x, Z, H, W):
-        return fused.down_sample(self, x, Z, H, W)
+    def forward(self, x, Z, H, W, skip_grad=None):
+        return fused.down_sample(self, x, Z, H, W, skip_grad=skip_grad)
 
 
 class UpSample(nn.Module):

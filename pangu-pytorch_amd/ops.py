@@ -120,8 +120,6 @@ def fill_dropped_grads(g, like):
     return g
 
 
-_zero_arena = None        # [flat fp32 zeros, used elements]: see zero_arena
-
 # Derived copies of parameters (bf16 weight shadows, packed weight images, compact bias tables) are keyed by a STAMP of the
 # parameter they were made from.  `_version` alone is not enough: torch's fused optimizers (Adam(fused=True), the form
 # train.make_optimizer uses) update the parameters through one multi-tensor kernel that does NOT bump `_version` (measured on
@@ -208,36 +206,38 @@ def grad_slot(param):
 
 
 
-class zero_arena:
-    """One zero fill for all the atomically accumulated gradient buffers of a backward step (weight / bias / LayerNorm /
-    pad-slot gradients): inside the context `_zeros` hands out 16-B aligned slices of ONE zeroed fp32 buffer instead of
-    launching a fill kernel per buffer (seven per block, 6.4 us each: 2.4 % of the bf16 training step)."""
+_PASS_ARENA_NUMEL = 28 << 20      # fp32 elements: every atomically accumulated gradient buffer of one backward pass of the
+                                  # model (16 blocks x (12 C^2 + 16 C) + the resampling / embedding / recovery weights = 24 M) fits
+_pass_arena = None                # [flat fp32 zeros, used elements] while a backward pass is running
 
-    def __init__(self, numel, device):
-        self.numel, self.device = int(numel), device
 
-    def __enter__(self):
-        global _zero_arena
-        self.prev = _zero_arena
-        _zero_arena = [torch.zeros((self.numel,), dtype=torch.float32, device=self.device), 0]
-        return self
-
-    def __exit__(self, *exc):
-        global _zero_arena
-        _zero_arena = self.prev
+def _release_pass_arena():
+    global _pass_arena
+    _pass_arena = None
 
 
 def _zeros(shape, device):
-    """fp32 zeros of `shape`: a slice of the active zero_arena when one is open on this device and has room."""
+    """fp32 zeros of `shape` for a gradient the kernels ACCUMULATE into (weight / bias / LayerNorm / pad-slot gradients).  Inside
+    an autograd backward pass they are 16-B aligned slices of ONE buffer zeroed by ONE fill at its first use (112 MB: ~25 us)
+    and dropped by an end-of-backward callback -- the per-buffer fills were 27 launches per training step (round 3: one per
+    block).  Outside a backward pass (direct op calls, tests) a plain torch.zeros."""
+    global _pass_arena
     n = 1
     for d in shape:
         n *= int(d)
-    a = _zero_arena
-    if a is not None and a[0].device == torch.device(device) and a[1] + n <= a[0].numel():
-        t = a[0][a[1]:a[1] + n].view(shape)
-        a[1] += (n + 3) & ~3
-        return t
-    return torch.zeros(shape, dtype=torch.float32, device=device)
+    dev = torch.device(device)
+    a = _pass_arena
+    if a is None or a[0].device != dev or a[1] + n > a[0].numel():
+        if n > _PASS_ARENA_NUMEL // 4:
+            return torch.zeros(shape, dtype=torch.float32, device=dev)
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_release_pass_arena)
+        except RuntimeError:      # not inside a backward pass
+            return torch.zeros(shape, dtype=torch.float32, device=dev)
+        a = _pass_arena = [torch.zeros((_PASS_ARENA_NUMEL,), dtype=torch.float32, device=dev), 0]
+    t = a[0][a[1]:a[1] + n].view(shape)
+    a[1] += (n + 3) & ~3
+    return t
 
 
 _U32_BYTES = (1 << 32) - (1 << 24)
@@ -434,14 +434,18 @@ def ln_residual_bwd(dout, y, gamma, branch_scale=1.0):
     return dy, dg, db
 
 
-def downsample_ln_bwd(dout, x, gamma, Z, H, W):
+def downsample_ln_bwd(dout, x, gamma, Z, H, W, add=None):
+    """add (optional, dense (Z*H*W, C)): a second gradient of the same tokens, summed into dx by the kernel."""
     lib = _lib.load()
     xp, ldx = _rows(x, "downsample_bwd.x")
     C = x.shape[1]
     dx = torch.empty((Z * H * W, C), dtype=torch.float32, device=x.device)
+    if add is not None and tuple(add.shape) != tuple(dx.shape):
+        raise RuntimeError(f"downsample_ln_bwd: addend {tuple(add.shape)} != {tuple(dx.shape)}")
     dg, db = _zeros((2, 4 * C), x.device).unbind(0)
     _lib.check(lib.pangu_downsample_ln_bwd(_stream(dout), _chk(dout, "dout"), xp, ldx, _chk(gamma, "gamma"), dx.data_ptr(),
-                                           dg.data_ptr(), db.data_ptr(), Z, H, W, C), "downsample_ln_bwd")
+                                           dg.data_ptr(), db.data_ptr(), Z, H, W, C,
+                                           _chk(add, "downsample_bwd.add") if add is not None else None), "downsample_ln_bwd")
     return dx, dg, db
 
 

@@ -327,15 +327,18 @@ def ln_residual_bwd(dout, y, gamma, branch_scale=1.0):
     return dy, dg, db
 
 
-def downsample_ln_bwd(dout, x, gamma, Z, H, W):
+def downsample_ln_bwd(dout, x, gamma, Z, H, W, add=None):
+    """add (optional, dense (Z*H*W, C) bf16): a second gradient of the same tokens, summed into dx by the kernel."""
     lib = _lib.load()
     xp, ldx = _rows(x, "x")
     C = x.shape[1]
     dx = torch.empty((Z * H * W, C), dtype=torch.bfloat16, device=x.device)
+    if add is not None and tuple(add.shape) != tuple(dx.shape):
+        raise RuntimeError(f"downsample_ln_bwd: addend {tuple(add.shape)} != {tuple(dx.shape)}")
     dg, db = _zeros((2, 4 * C), x.device).unbind(0)
     _lib.check(lib.pangu_downsample_ln_bwd_bf16(_stream(dout), _p(dout, "dout"), xp, ldx, _p(gamma, "gamma", torch.float32),
-                                                dx.data_ptr(), dg.data_ptr(), db.data_ptr(), Z, H, W, C),
-               "downsample_ln_bwd_bf16")
+                                                dx.data_ptr(), dg.data_ptr(), db.data_ptr(), Z, H, W, C,
+                                                _p(add, "add") if add is not None else None), "downsample_ln_bwd_bf16")
     return dx, dg, db
 
 

@@ -198,12 +198,13 @@ class PanguModel(nn.Module):
             halves = [torch.empty(0, dtype=x.dtype, device=x.device).set_(cat.untyped_storage(), cat.storage_offset() + off, (N, C), (2 * C, 1))
                       for off in (0, C)]
             skip = self.layers[0](x, 8, 181, 360, out=halves[0])
-            x = self.downsample(skip, 8, 181, 360)
+            skip_grad = [None, False]         # the skip connection's concat-path gradient, summed inside the down-sampling backward
+            x = self.downsample(skip, 8, 181, 360, skip_grad=skip_grad)
             x = self.layers[1](x, 8, 91, 180)
             x = self.layers[2](x, 8, 91, 180)
             x = self.upsample(x)
             x = self.layers[3](x, 8, 181, 360, out=halves[1])
-            return fused.patch_recover_halves(self._output_layer, skip, x, 8, 181, 360)
+            return fused.patch_recover_halves(self._output_layer, skip, x, 8, 181, 360, skip_grad=skip_grad)
         if grad_path:
             skip = self.layers[0](x, 8, 181, 360)                 # autograd path, B > 1: plain concat
             x = self.downsample(skip, 8, 181, 360)

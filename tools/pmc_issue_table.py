@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Join the passes of tools/pmc_issue_table.sh into one markdown table per kernel (bf16 forward)."""
+"""Join the passes of tools/pmc_issue_table.sh into one markdown table per kernel."""
 import collections
 import csv
 import glob
@@ -30,16 +30,16 @@ def durations(d):
     return tot, cnt
 
 
-def main(root):
+def main(root, cmd="tools/profile_fwd.py bf16 3"):
     c1, c2, c3 = (counters(os.path.join(root, p)) for p in ("p1", "p2", "p3"))
     tot, cnt = durations(os.path.join(root, "p3"))
-    print("Counters of `tools/profile_fwd.py bf16 3` (three separate `rocprofv3 --pmc` passes, tools/pmc_issue_table.sh).  Wave-cycle split: "
+    print(f"Counters of `{cmd}` (three separate `rocprofv3 --pmc` passes, tools/pmc_issue_table.sh).  Wave-cycle split: "
           "issuing = SQ_ACTIVE_INST_ANY, issue-stalled = SQ_WAIT_INST_ANY, parked (s_waitcnt / barrier) = SQ_WAIT_ANY, each over SQ_WAVE_CYCLES; "
           "LDS busy = SQ_LDS_IDX_ACTIVE (LDS-array cycles, summed over the CUs) / (GRBM_GUI_ACTIVE x 32: CU-cycles), conflict share = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / "
-          "(GRBM_GUI_ACTIVE x 128); effective clock = GRBM_GUI_ACTIVE / 8 / duration.\\n")
+          "(GRBM_GUI_ACTIVE x 128); effective clock = GRBM_GUI_ACTIVE / 8 / duration.\n")
     print("| kernel | launches | avg us | eff. clock GHz | MFMA busy | issuing | issue-stalled | parked | LDS busy (per CU) | LDS bank-conflict share | VALU instr per wave-cycle |")
     print("|---|---|---|---|---|---|---|---|---|---|---|")
-    for k in sorted(tot, key=lambda k: -tot[k])[:14]:
+    for k in sorted(tot, key=lambda k: -tot[k])[:24 if "train" in cmd else 14]:
         wc = c1[k].get("SQ_WAVE_CYCLES", 0.0) or 1.0
         gui = c3[k].get("GRBM_GUI_ACTIVE", 0.0)
         lds = c2[k].get("SQ_LDS_IDX_ACTIVE", 0.0)
@@ -50,4 +50,4 @@ def main(root):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(*sys.argv[1:3])
