@@ -1,0 +1,67 @@
+"""LDS images of the bf16 attention kernels (csrc/attn_bf16.hip) under the gfx950 bank rules (tools/lds_banks.py =
+MI355X_MICROARCH.md's LDS table): every fragment read conflict-free, the writes as documented.  The address functions below
+restate the kernel's (kswz, vt_off, key_of); VERDICT r3 item 2 (bank-conflict share 0.20-0.27 of the fused QKV + attention kernel)."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+from lds_banks import conflict_free, cycles  # noqa: E402
+
+F = [0, 2, 3, 1]
+
+
+def kswz(row, chunk):
+    return row * 64 + ((chunk ^ ((F[(row >> 3) & 3] ^ ((row >> 1) & (3 if row < 128 else 1))) & 3)) << 4)
+
+
+def vt_off(d, key):
+    c = key >> 3
+    return d * 384 + ((((c ^ (d >> 1) ^ (d >> 4)) & 7) | (c & ~7)) << 4) + (key & 7) * 2
+
+
+def key_of(j, i):
+    return 32 * (j >> 1) + 8 * (i >> 2) + 4 * (j & 1) + (i & 3) if j < 8 else 128 + i
+
+
+def test_images_are_bijective():
+    assert len({kswz(r, c) for r in range(144) for c in range(4)}) == 576 and max(kswz(r, c) for r in range(144) for c in range(4)) < 9216
+    offs = {vt_off(d, k) for d in range(32) for k in range(144)}
+    assert len(offs) == 32 * 144 and max(offs) < 32 * 384 and all(o % 2 == 0 for o in offs)
+    for d in range(32):                      # 8 consecutive keys = one 16-B chunk, 4 consecutive keys = one aligned 8-B piece
+        for k in range(0, 144, 8):
+            assert vt_off(d, k) % 16 == 0 and [vt_off(d, k + e) - vt_off(d, k) for e in range(8)] == [2 * e for e in range(8)]
+
+
+@pytest.mark.parametrize("j", range(9))
+def test_k_fragment_reads_conflict_free(j):
+    assert conflict_free("read_b128", lambda l: kswz(key_of(j, l & 15), l >> 4))
+
+
+@pytest.mark.parametrize("tile", range(9))
+def test_k_image_writes_of_the_fused_kernel_conflict_free(tile):
+    # lane (lq, lg) writes the 16-B piece (row tile * 16 + lq, logical chunk lg); the tail tile's rows: 2-way
+    c, n = cycles("write_b128", lambda l: kswz(tile * 16 + (l & 15), l >> 4))
+    assert c == n if tile < 8 else c <= 2 * n
+    # the unfused kernel: thread f -> (row f >> 2, chunk f & 3)
+    assert conflict_free("write_b128", lambda l: kswz(tile * 16 + (l >> 2), l & 3))
+
+
+@pytest.mark.parametrize("dt", range(2))
+def test_vt_fragment_reads_conflict_free(dt):
+    for u in range(4):
+        assert conflict_free("read_b128", lambda l: vt_off(dt * 16 + (l & 15), 32 * u + 8 * (l >> 4)))
+    assert conflict_free("read_b64", lambda l: vt_off(dt * 16 + (l & 15), 128 + 4 * (l >> 4)))
+
+
+def test_vt_writes():
+    # unfused kernel: 2-byte scatter, thread f -> key f >> 2, rows 8 (f & 3) + 2 e (+1): conflict-free
+    for e in range(4):
+        for odd in range(2):
+            for w in range(3):
+                assert conflict_free("write_b16", lambda l: vt_off((l & 3) * 8 + 2 * e + odd, 16 * w + (l >> 2)))
+    # fused kernel: 8-B pieces (row 16 dt + lq, keys 16 tile + 4 lg ..): 2-way (six instructions per wave and launch)
+    for t in range(9):
+        c, n = cycles("write_b64", lambda l: vt_off(l & 15, 16 * t + 4 * (l >> 4)))
+        assert c <= 2 * n
