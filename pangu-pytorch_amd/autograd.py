@@ -33,7 +33,8 @@ class EarthBlockFn(torch.autograd.Function):
             qkv = ops.linear(x, a1w, a1b)
             o, lse = ops.window_attention(qkv, a1b, esb[0], Z, H, W, heads, shifted, want_lse=True)
             y = ops.linear(o, a2w, a2b)
-            x1 = ops.ln_residual(y, x, n1w, n1b, branch_scale=s1)
+            # (a dropped MLP branch -- s2 == 0 -- makes x1 the block's result: written straight into `out`, no copy afterwards)
+            x1 = ops.ln_residual(y, x, n1w, n1b, branch_scale=s1, out=out if s2 == 0.0 else None)
             saved += [qkv, o, lse, y]
         if s2 != 0.0:
             pre = torch.empty((x.shape[0], m1w.shape[0]), dtype=x.dtype, device=x.device)
@@ -42,7 +43,8 @@ class EarthBlockFn(torch.autograd.Function):
             x2 = ops.ln_residual(m, x1, n2w, n2b, out=out, branch_scale=s2)
             saved += [x1, pre, h, m]
         elif out is not None:
-            out.copy_(x1)
+            if x1 is not out:
+                out.copy_(x1)                     # both branches dropped: the block is the identity
             x2 = out
         else:
             x2 = x1

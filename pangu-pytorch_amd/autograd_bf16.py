@@ -37,7 +37,8 @@ class EarthBlockFnBF16(torch.autograd.Function):
             qkv = ob.linear(x, sh.get(a1w), a1b)
             o, lse = ob.window_attention(qkv, sh.get(a1b), sh.get(esb), Z, H, W, heads, shifted, want_lse=True)
             y = ob.linear(o, sh.get(a2w), a2b)
-            x1 = ob.ln_residual(y, x, n1w, n1b, branch_scale=s1)
+            # (a dropped MLP branch -- s2 == 0 -- makes x1 the block's result: written straight into `out`, no copy afterwards)
+            x1 = ob.ln_residual(y, x, n1w, n1b, branch_scale=s1, out=out if s2 == 0.0 else None)
             saved += [qkv, o, lse, y]
         ctx.mlp_mode = mode = _mlp_mode(x.shape[1]) if x1.is_contiguous() else 0
         if s2 != 0.0 and mode:
@@ -50,7 +51,8 @@ class EarthBlockFnBF16(torch.autograd.Function):
             x2 = ob.ln_residual(m, x1, n2w, n2b, out=out, branch_scale=s2)
             saved += [x1, pre, h, m]
         elif out is not None:
-            out.copy_(x1)
+            if x1 is not out:
+                out.copy_(x1)                     # both branches dropped: the block is the identity
             x2 = out
         else:
             x2 = x1

@@ -24,16 +24,23 @@ typedef unsigned short u16;
 #ifndef PANGU_ATTN_OUT_WIDE
 #define PANGU_ATTN_OUT_WIDE 1      // 16-B output stores after a v_permlane16_swap exchange (0: two 8-B stores per lane)
 #endif
-// V^T image [32 d][144 keys] bf16: 384-byte rows, the 16-B chunk (8 keys) XOR-ed with ((d >> 1) ^ (d >> 4)) & 7.  Under the REAL
-// ds_read_b128 lane groups ({0-3, 12-15, 20-27}, ..: MI355X_MICROARCH.md) the padded 336-byte rows of rounds 1-3 were 2-way
-// conflicted on every PV fragment read (20-27 % of the kernels' LDS cycles, profiles/r03_fwd_bf16_issue_table.md); this image is
-// conflict-free for the fragment reads, the 8-B tail reads and the 2-B scatter writes, 2-way for the fused kernel's six 8-B
-// writes (tools/lds_banks.py, tests/test_lds_layouts_cpu.py).
-constexpr int VT_LD = 384;
+// V^T image [32 d][144 keys] bf16, two layouts:
+//   VSWZ (the fused QKV kernel): 384-byte rows, the 16-B chunk (8 keys) XOR-ed with ((d >> 1) ^ (d >> 4)) & 7.  Under the REAL
+//     ds_read_b128 lane groups ({0-3, 12-15, 20-27}, ..: MI355X_MICROARCH.md) the padded 336-byte rows of rounds 1-3 are 2-way
+//     conflicted on every PV fragment read (20-27 % of that kernel's LDS cycles, profiles/r03_fwd_bf16_issue_table.md); this image
+//     is conflict-free for the fragment reads and the 8-B tail reads, 2-way for the kernel's six 8-B writes: conflict share
+//     0.205 / 0.267 -> 0.035 / 0.048 (profiles/r04_fwd_bf16_issue_table.md; tools/lds_banks.py, tests/test_lds_layouts_cpu.py).
+//     The kernel's time did not move (216 / 310 us -> 220 / 317 us): its LDS pipe was never what bounds it.
+//   padded (the kernel that reads a qkv tensor): 336-byte rows as before -- there the swizzled addresses of the 24 two-byte
+//     scatter writes per thread cost more VALU than the conflicts (0.233-0.245 -> 0.251-0.263 ms at C = 192, interleaved A/B).
+template <bool VSWZ>
 __device__ inline int vt_off(int d, int key) {
+  if (!VSWZ) return d * 336 + key * 2;
   const int c = key >> 3;
-  return d * VT_LD + ((((c ^ (d >> 1) ^ (d >> 4)) & 7) | (c & ~7)) << 4) + (key & 7) * 2;
+  return d * 384 + ((((c ^ (d >> 1) ^ (d >> 4)) & 7) | (c & ~7)) << 4) + (key & 7) * 2;
 }
+constexpr int VT_BYTES_PAD = 32 * 336, VT_BYTES_SWZ = 32 * 384;
+static_assert(PANGU_WTOK * 64 + VT_BYTES_SWZ <= 2 * (PANGU_WTOK + 96) * 64, "the K + V^T images reuse the ring of the fused kernel");
 
 __device__ inline u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
 __device__ inline unsigned pack2(float a, float b) { return pack_bf16x2(a, b); }
@@ -73,7 +80,7 @@ __device__ inline BiasRow load_bias_row(const u16* __restrict__ bias_tile, int q
 
 // One 16-query tile of one wave: scores, softmax, PV, store.  Everything it needs from HBM (qf, bias) is already in
 // registers; K / V^T come from LDS.
-template <bool SHIFTED>
+template <bool SHIFTED, bool VSWZ>
 __device__ __forceinline__ void attn_tile(const unsigned char* Ks, const unsigned char* Vt, const bf16x8 qf,
                                           const BiasRow& bias, int qn, int qtok, int lq, int lg, bool zcut, bool hcut,
                                           unsigned long long kz_bits, unsigned long long kh_bits, u16* __restrict__ out,
@@ -154,9 +161,9 @@ __device__ __forceinline__ void attn_tile(const unsigned char* Ks, const unsigne
     for (int dt = 0; dt < 2; ++dt) {
       u32x4 vq;
       if (u < 4) {
-        vq = *reinterpret_cast<const u32x4*>(Vtq + vt_off(dt * 16 + lq, 32 * u + 8 * lg));
+        vq = *reinterpret_cast<const u32x4*>(Vtq + vt_off<VSWZ>(dt * 16 + lq, 32 * u + 8 * lg));
       } else {
-        const u32x2 va = *reinterpret_cast<const u32x2*>(Vtq + vt_off(dt * 16 + lq, 128 + 4 * lg));
+        const u32x2 va = *reinterpret_cast<const u32x2*>(Vtq + vt_off<VSWZ>(dt * 16 + lq, 128 + 4 * lg));
         vq = u32x4{va[0], va[1], 0u, 0u};
       }
       const bf16x8 vf = __builtin_bit_cast(bf16x8, vq);
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(192, 3) void window_attn_bf16_kernel(const u16* __r
                                                                   float* __restrict__ lse, WinGeom g, int C, int heads,
                                                                   int n_pairs) {
   __shared__ __attribute__((aligned(16))) unsigned char Ks[PANGU_WTOK * 64];
-  __shared__ __attribute__((aligned(16))) unsigned char Vt[32 * VT_LD];
+  __shared__ __attribute__((aligned(16))) unsigned char Vt[VT_BYTES_PAD];
 
   // Block order: a bf16 head slice is 64 B, half a cache line, so the two heads that share each token's 128-B line run
   // back to back on ONE XCD (blocks b, b+8, .. share an XCD/L2): unit = (window type, head pair), then the longitude
@@ -270,17 +277,17 @@ __global__ __launch_bounds__(192, 3) void window_attn_bf16_kernel(const u16* __r
     *reinterpret_cast<u32x4*>(Ks + kswz(n, ch)) = kv[i];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      *reinterpret_cast<u16*>(Vt + vt_off(ch * 8 + 2 * e, n)) = (u16)(vv[i][e] & 0xFFFFu);
-      *reinterpret_cast<u16*>(Vt + vt_off(ch * 8 + 2 * e + 1, n)) = (u16)(vv[i][e] >> 16);
+      *reinterpret_cast<u16*>(Vt + vt_off<false>(ch * 8 + 2 * e, n)) = (u16)(vv[i][e] & 0xFFFFu);
+      *reinterpret_cast<u16*>(Vt + vt_off<false>(ch * 8 + 2 * e + 1, n)) = (u16)(vv[i][e] >> 16);
     }
   }
   __syncthreads();
 
   const BiasRow b1 = load_bias_row(bias_tile, (wave + 3) * 16 + lq, lg);
-  attn_tile<SHIFTED>(Ks, Vt, qf[0], b0, wave * 16 + lq, qtok[0], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
+  attn_tile<SHIFTED, false>(Ks, Vt, qf[0], b0, wave * 16 + lq, qtok[0], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
   b0 = load_bias_row(bias_tile, (wave + 6) * 16 + lq, lg);
-  attn_tile<SHIFTED>(Ks, Vt, qf[1], b1, (wave + 3) * 16 + lq, qtok[1], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
-  attn_tile<SHIFTED>(Ks, Vt, qf[2], b0, (wave + 6) * 16 + lq, qtok[2], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
+  attn_tile<SHIFTED, false>(Ks, Vt, qf[1], b1, (wave + 3) * 16 + lq, qtok[1], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
+  attn_tile<SHIFTED, false>(Ks, Vt, qf[2], b0, (wave + 6) * 16 + lq, qtok[2], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
 }
 
 // ---- QKV projection fused in ----------------------------------------------------------------------------------------
@@ -348,7 +355,7 @@ __global__ __launch_bounds__(192, 2) void window_attn_qkv_bf16_kernel(const u16*
   // DMA round trip (a step's 15 KB per workgroup), not by its 54 MFMAs
   unsigned char* const ring = smem;                                  // QK_RING slots
   unsigned char* const Ks = smem;                                    // [144][64 B]
-  unsigned char* const Vt = Ks + PANGU_WTOK * 64;                    // [32][VT_LD]
+  unsigned char* const Vt = Ks + PANGU_WTOK * 64;                    // V^T image (swizzled layout, VT_BYTES_SWZ)
 
   // Block order: blocks b, b+8, .. share an XCD (its L2).  Every head of a window reads the SAME 144 input rows, so the
   // heads of one window run back to back on one XCD (x leaves HBM once, not `heads` times: PMC FETCH_SIZE 0.67 -> ...
@@ -478,7 +485,7 @@ __global__ __launch_bounds__(192, 2) void window_attn_qkv_bf16_kernel(const u16*
                                                         pack2(acc[3][i][0], acc[3][i][1]), pack2(acc[3][i][2], acc[3][i][3])};
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
-      *reinterpret_cast<u32x2*>(Vt + vt_off(dt * 16 + lq, (tile0 + i) * 16 + 4 * lg)) =
+      *reinterpret_cast<u32x2*>(Vt + vt_off<true>(dt * 16 + lq, (tile0 + i) * 16 + 4 * lg)) =
           u32x2{pack2(acc[4 + dt][i][0], acc[4 + dt][i][1]), pack2(acc[4 + dt][i][2], acc[4 + dt][i][3])};
   }
 
@@ -502,10 +509,10 @@ __global__ __launch_bounds__(192, 2) void window_attn_qkv_bf16_kernel(const u16*
   const unsigned long long st3 = attn_stamp();
 #endif
   const BiasRow b1 = load_bias_row(bias_tile, (tile0 + 1) * 16 + lq, lg);
-  attn_tile<SHIFTED>(Ks, Vt, qf[0], b0, tile0 * 16 + lq, qtok[0], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
+  attn_tile<SHIFTED, true>(Ks, Vt, qf[0], b0, tile0 * 16 + lq, qtok[0], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
   b0 = load_bias_row(bias_tile, (tile0 + 2) * 16 + lq, lg);
-  attn_tile<SHIFTED>(Ks, Vt, qf[1], b1, (tile0 + 1) * 16 + lq, qtok[1], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
-  attn_tile<SHIFTED>(Ks, Vt, qf[2], b0, (tile0 + 2) * 16 + lq, qtok[2], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
+  attn_tile<SHIFTED, true>(Ks, Vt, qf[1], b1, (tile0 + 1) * 16 + lq, qtok[1], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
+  attn_tile<SHIFTED, true>(Ks, Vt, qf[2], b0, (tile0 + 2) * 16 + lq, qtok[2], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
 #ifdef PANGU_ATTN_STAMP
   const unsigned long long st4 = attn_stamp();
   if (lane == 0 && (int)(blockIdx.x * 3 + wave) < STAMP_WAVES) {

@@ -7,9 +7,6 @@
 // SOURCE side (conflict-free ds_read_b128 lane groups), the fragments of the two k-halves share registers, and a ring of
 // two 20-KB stages leaves 40 KB per workgroup: FOUR workgroups per CU at <= 128 VGPRs.
 #include "common.h"
-#ifndef PANGU_GEMM_PRIO
-#define PANGU_GEMM_PRIO 0
-#endif
 #include <stdlib.h>
 
 namespace {
@@ -94,9 +91,6 @@ __global__ __launch_bounds__(256, TN == 3 ? 4 : 5) void gemm_tn_f32_dma_kernel(c
 
   const int KT = K / BK;
   issue(0);
-#if PANGU_GEMM_PRIO == 1
-  __builtin_amdgcn_s_setprio(1);      // experiment: the MFMA loop outranks the other workgroups' epilogue / prologue VALU on this SIMD
-#endif
   for (int kt = 0; kt < KT; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's part of step kt has landed
     __builtin_amdgcn_s_barrier();                          // ... and everybody's; slot (kt+1)&1 is free
@@ -119,11 +113,6 @@ __global__ __launch_bounds__(256, TN == 3 ? 4 : 5) void gemm_tn_f32_dma_kernel(c
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fw[j][s], acc[i][j], 0, 0, 0);
     }
   }
-#if PANGU_GEMM_PRIO == 1
-  __builtin_amdgcn_s_setprio(0);
-#elif PANGU_GEMM_PRIO == 2
-  __builtin_amdgcn_s_setprio(1);      // experiment: the epilogue outranks the other workgroups' MFMA loops (the tile slot frees sooner)
-#endif
   __syncthreads();                                         // every wave is done with the ring before the epilogue reuses it
 
   // epilogue (as gemm_f32.hip): each 32x32 tile is transposed through a wave-private LDS patch -> 16-B row segments

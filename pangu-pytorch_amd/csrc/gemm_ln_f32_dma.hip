@@ -9,9 +9,6 @@
 // DPP adds, the WNW partial rows meet in a small LDS table behind one barrier, then normalise / gamma / beta / branch scale /
 // shortcut and 16-B stores of whole 128-B row segments.
 #include "common.h"
-#ifndef PANGU_GEMM_PRIO
-#define PANGU_GEMM_PRIO 0
-#endif
 
 namespace {
 
@@ -90,9 +87,6 @@ __global__ __launch_bounds__(128 * WNW, 4) void gemm_ln_residual_f32_dma_kernel(
 
   const int KT = K / BK;
   issue(0);
-#if PANGU_GEMM_PRIO == 1
-  __builtin_amdgcn_s_setprio(1);      // experiment: the MFMA loop outranks the other workgroups' epilogue / prologue VALU on this SIMD
-#endif
   for (int kt = 0; kt < KT; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -115,11 +109,6 @@ __global__ __launch_bounds__(128 * WNW, 4) void gemm_ln_residual_f32_dma_kernel(
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fw[j][s], acc[i][j], 0, 0, 0);
     }
   }
-#if PANGU_GEMM_PRIO == 1
-  __builtin_amdgcn_s_setprio(0);
-#elif PANGU_GEMM_PRIO == 2
-  __builtin_amdgcn_s_setprio(1);      // experiment: the epilogue outranks the other workgroups' MFMA loops (the tile slot frees sooner)
-#endif
   __syncthreads();                                         // every wave is done with the ring before the epilogue reuses it
 
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
