@@ -22,7 +22,7 @@ CSRC = os.path.join(ROOT, "pangu-pytorch_amd", "csrc")
 # family -> (kernel-name substrings, source files)
 FAMILIES = {
     "f32": {"gemm": (("gemm_tn_f32_dma_kernel", "gemm_tn_f32_kernel"), ("gemm_f32_dma.hip", "gemm_f32.hip")),
-            "gemm_ln": (("gemm_ln_residual_f32",), ("gemm_ln_f32_dma.hip", "gemm_ln_f32.hip")),
+            "gemm_ln": (("gemm_ln_residual_f32",), ("gemm_ln_f32_dma.hip",)),
             "attn": (("window_attn_f32_kernel",), ("attn_f32.hip",))},
     "bf16": {"mlp_fused": (("mlp_ln_residual_bf16_kernel",), ("mlp_fused_bf16.hip",)),
              "attn_qkv": (("window_attn_qkv_bf16_kernel",), ("attn_bf16.hip",)),
