@@ -111,6 +111,13 @@ int pangu_window_attn_fwd_compact(pangu_stream_t stream, const float* qkv, const
 int pangu_attn_windows_fwd(pangu_stream_t stream, const float* qkv, const float* esb, const float* mask,
                            long long mask_lon_stride, float* out, int n_lon, int types, int heads, int C);
 
+/* Backward of pangu_attn_windows_fwd: dout [rows][C] -> dqkv [rows][3C] (every row written), d_esb [types][heads][144][144]
+ * (overwritten: summed over the n_lon windows inside the kernel, no atomics).  The mask gets no gradient (layers.py:153-181 builds
+ * it from constants). */
+int pangu_attn_windows_bwd(pangu_stream_t stream, const float* qkv, const float* esb, const float* mask,
+                           long long mask_lon_stride, const float* dout, float* dqkv, float* d_esb, int n_lon, int types,
+                           int heads, int C);
+
 /* Backward of pangu_window_attn_fwd.  One workgroup per (window type, head) walks the nLon longitude windows
  * and keeps the bias gradient d_esb[t][head] = sum_l dS in registers (no atomics, written once).
  *   out, lse: the forward's outputs;  dout [N][C]: gradient w.r.t. out

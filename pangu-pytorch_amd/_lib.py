@@ -59,6 +59,7 @@ SIGNATURES = {
     "pangu_window_attn_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I],
     "pangu_window_attn_fwd_compact": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I],
     "pangu_attn_windows_fwd": [_P, _P, _P, _P, _c.c_longlong, _P, _I, _I, _I, _I],
+    "pangu_attn_windows_bwd": [_P, _P, _P, _P, _c.c_longlong, _P, _P, _P, _I, _I, _I, _I],
     "pangu_ln_residual_fwd": [_P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _F],
     "pangu_linear_ln_residual_fwd": [_P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _F],
     "pangu_downsample_ln_fwd": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I],

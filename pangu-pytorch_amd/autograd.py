@@ -102,6 +102,53 @@ class EarthBlockFn(torch.autograd.Function):
                 g["a1w"], g["a1b"], g["a2w"], g["a2b"], None, None, None, None)
 
 
+class AttentionWindowsFn(torch.autograd.Function):
+    """reference models/layers.py:360-421 (EarthAttention3D.forward taken on its own) on partitioned rows: xw (n_lon*types*144, C)
+    in window-slot order, esb (1, types, heads, 144, 144), mask None | (n_lon, types, 144, 144) | (types, 144, 144)."""
+
+    @staticmethod
+    def forward(ctx, xw, w1, b1, w2, b2, esb, mask, geom):
+        n_lon, types, heads = geom
+        qkv = ops.linear(xw, w1, b1)
+        o = ops.attention_windows(qkv, esb[0], mask, n_lon, types, heads)
+        ctx.save_for_backward(xw, qkv, o, w1, w2, esb, *([mask] if mask is not None else []))
+        ctx.geom = geom
+        return ops.linear(o, w2, b2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xw, qkv, o, w1, w2, esb, *rest = ctx.saved_tensors
+        mask = rest[0] if rest else None
+        n_lon, types, heads = ctx.geom
+        dy = dy.contiguous()
+        dw2, db2 = ops.linear_wgrad(dy, o)
+        do = ops.linear(dy, _wt(w2))
+        dqkv, desb = ops.attention_windows_bwd(qkv, esb[0], mask, do, n_lon, types, heads)
+        dw1, db1 = ops.linear_wgrad(dqkv, xw)
+        dx = ops.linear(dqkv, _wt(w1))
+        return dx, dw1, db1, dw2, db2, desb.unsqueeze(0), None, None
+
+
+class MlpFn(torch.autograd.Function):
+    """reference models/layers.py:264-270 (Mlp.forward taken on its own: linear1 -> exact-erf GELU -> linear2) on (M, C) rows."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        pre = torch.empty((x.shape[0], w1.shape[0]), dtype=x.dtype, device=x.device)
+        h = ops.linear(x, w1, b1, act=ops.ACT_GELU, aux=pre)
+        ctx.save_for_backward(x, pre, h, w1, w2)
+        return ops.linear(h, w2, b2)
+
+    @staticmethod
+    def backward(ctx, dm):
+        x, pre, h, w1, w2 = ctx.saved_tensors
+        dm = dm.contiguous()
+        dw2, db2 = ops.linear_wgrad(dm, h)
+        dpre = ops.linear(dm, _wt(w2), None, act=ops.ACT_GELU_BWD, aux=pre)
+        dw1, db1 = ops.linear_wgrad(dpre, x)
+        return ops.linear(dpre, _wt(w1)), dw1, db1, dw2, db2
+
+
 class PatchEmbedFn(torch.autograd.Function):
     """reference models/layers.py:40-93 for one sample; the raw fields get no gradient."""
 

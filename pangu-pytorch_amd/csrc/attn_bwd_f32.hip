@@ -146,16 +146,23 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_f32_kernel(
   auto slot_of = [&](int u) { return owner ? tid : NQ * 64 + (tid - NQ * 64) + u * 192; };
   auto request = [&](int l, auto& vfr, auto nk_tag) {
     constexpr int NK = decltype(nk_tag)::value;      // key tiles of this wave = chunk slots of this thread: 1 (owner) or 3 (helper)
+    // the slot -> (z, h, w) split of win_src_token is window-invariant: left to itself the compiler hoists it out of the window
+    // loop for every slot and keeps the pieces live across it -- in the SHIFTED instantiation (wrap-around terms) 17 registers
+    // over the 168 a 12-wave workgroup has, i.e. 13 scratch reloads per window (round 3).  Opaque slot numbers make it
+    // recompute them here, where the VALU is idle.
+    int lq_o = lq;
+    asm volatile("" : "+v"(lq_o));
 #pragma unroll
     for (int kk = 0; kk < NK; ++kk) {
-      const int tok = win_src_token(g, l, t, (kt0 + kk) * 16 + lq, SHIFTED);
+      const int tok = win_src_token(g, l, t, (kt0 + kk) * 16 + lq_o, SHIFTED);
       const float* src = (tok >= 0 ? qkv + (size_t)tok * C3 : qkv_bias) + 2 * C + hd * 32 + lg * 8;
       vfr[kk][0] = ldg4<NTH>(src);
       vfr[kk][1] = ldg4<NTH>(src + 4);
     }
 #pragma unroll
     for (int u = 0; u < NK; ++u) {
-      const int f = slot_of(u);
+      int f = slot_of(u);
+      asm volatile("" : "+v"(f));
       const int n = f >> 3, c4 = (f & 7) * 4;
       const int tok = win_src_token(g, l, t, n, SHIFTED);
       const float* src = tok >= 0 ? qkv + (size_t)tok * C3 : qkv_bias;
@@ -180,7 +187,8 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_f32_kernel(
     asm volatile("" : "+v"(lq), "+v"(lg));
 #pragma unroll
     for (int u = 0; u < NK; ++u) {
-      const int f = slot_of(u);
+      int f = slot_of(u);
+      asm volatile("" : "+v"(f));
       const int n = f >> 3, c4 = (f & 7) * 4;
       const int tok = win_src_token(g, l, t, n, SHIFTED);      // recomputed (the VALU is idle here) rather than kept across phase 2
       const bool real = tok >= 0;

@@ -121,13 +121,20 @@ __global__ __launch_bounds__(128 * WNW, 4) void gemm_ln_residual_f32_dma_kernel(
   const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(shortcut), 0, (int)(((size_t)(M - 1) * lds_sc + BN) * sizeof(float)), 0x00020000);
   constexpr float INV_C = 1.0f / BN;
+  // Register budget of this epilogue: 96 accumulator registers + the 128-VGPR cap of four workgroups per CU leave 32 for everything
+  // else, so the transposed rows of a 32-row group (48 registers) can only live in the registers its own accumulators free one
+  // 32 x 32 tile at a time, while the OTHER row group's 48 accumulators stay live: a few values go through scratch (round 3: 20-22
+  // registers; round 4, with the column-block loop outermost and bias / gamma / beta re-loaded per (row group, column block) instead
+  // of hoisted: 8-15), all of it outside the MFMA loop.  Measured alternative (round 4): two transposition passes (statistics, then
+  // normalise from the accumulators again) keep the accumulators live through both passes and spill 48-61.
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     f32x4 y[3][4];
     float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const int col = wn * 96 + j * 32 + ec;
+      int col = wn * 96 + j * 32 + ec;
+      asm volatile("" : "+v"(col));
       f32x4 bv = {0.f, 0.f, 0.f, 0.f};
       if (HAS_BIAS) bv = *reinterpret_cast<const f32x4*>(bias + col);
 #pragma unroll
@@ -151,6 +158,7 @@ __global__ __launch_bounds__(128 * WNW, 4) void gemm_ln_residual_f32_dma_kernel(
       }
     }
     __syncthreads();
+    float mean[4], rstd[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int rloc = i * 32 + er + 8 * it;
@@ -161,17 +169,21 @@ __global__ __launch_bounds__(128 * WNW, 4) void gemm_ln_residual_f32_dma_kernel(
         ts += st[0];
         tq += st[1];
       }
-      const float mean = ts * INV_C;
-      const float rstd = rsqrtf(fmaxf(tq * INV_C - mean * mean, 0.f) + LN_EPS);
-      const unsigned row = (unsigned)(m0 + wm * 64 + rloc);
+      mean[it] = ts * INV_C;
+      rstd[it] = rsqrtf(fmaxf(tq * INV_C - mean[it] * mean[it], 0.f) + LN_EPS);
+    }
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int col = wn * 96 + j * 32 + ec;
-        const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + col);
-        const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + col);
+    for (int j = 0; j < 3; ++j) {
+      int col = wn * 96 + j * 32 + ec;
+      asm volatile("" : "+v"(col));
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + col);
+      const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + col);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const unsigned row = (unsigned)(m0 + wm * 64 + i * 32 + er + 8 * it);
         const f32x4 sc = __builtin_bit_cast(
             f32x4, __builtin_amdgcn_raw_buffer_load_b128(s_rsrc, (int)((row * (unsigned)lds_sc + (unsigned)col) * 4u), 0, 0));
-        const f32x4 v = sc + branch_scale * ((y[j][it] - mean) * rstd * gm + bt);
+        const f32x4 v = sc + branch_scale * ((y[j][it] - mean[it]) * rstd[it] * gm + bt);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), c_rsrc,
                                                (int)((row * (unsigned)ldc + (unsigned)col) * 4u), 0, 0);
       }

@@ -8,7 +8,7 @@ import os
 import torch
 
 from . import ops
-from .autograd import DownSampleFn, EarthBlockFn, PatchEmbedFn, PatchRecoverFn, PatchRecoverHalvesFn, UpSampleFn
+from .autograd import DownSampleFn, EarthBlockFn, MlpFn, PatchEmbedFn, PatchRecoverFn, PatchRecoverHalvesFn, UpSampleFn
 
 
 def _train_path(module, *tensors):
@@ -44,6 +44,9 @@ _FUSE_LN = os.environ.get("PANGU_F32_FUSE_LN", "1") != "0"       # A/B knob: 0 =
 
 
 def mlp(m, x2d):
+    """Mlp.forward on its own (reference layers.py:264-270; the block never comes through here): differentiable."""
+    if _train_path(m, x2d):
+        return MlpFn.apply(x2d.contiguous(), m.linear1.weight, m.linear1.bias, m.linear2.weight, m.linear2.bias)
     h = ops.linear(x2d, m.linear1.weight, m.linear1.bias, act=ops.ACT_GELU)
     return ops.linear(h, m.linear2.weight, m.linear2.bias)
 

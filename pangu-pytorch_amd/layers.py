@@ -125,21 +125,25 @@ class EarthAttention3D(nn.Module):
         windows (as EarthSpecificBlock.forward :216-221 hands it over), mask None or (nLon, types, 144, 144) (gen_mask, :153-181)
         -> (nLon, types, 144, C).  EarthSpecificBlock does not come through here -- its kernels fold the partition into their
         addressing -- this is for callers that use the module on its own: linear1 and linear2 on the GEMM kernel, the core on
-        `pangu_attn_windows_fwd` (explicit mask tensor, every slot an ordinary token).  Inference only: under autograd train
-        the block (its backward is fused); a call that would need a gradient raises."""
+        `pangu_attn_windows_fwd` / `_bwd` (explicit mask tensor, every slot an ordinary token), differentiable like the
+        reference's module (autograd.AttentionWindowsFn)."""
         from . import ops
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("EarthAttention3D.forward(x_window, mask) is inference-only in the MI355X build: call it under "
-                                      "torch.no_grad(); training goes through EarthSpecificBlock (fused backward kernels)")
+        from .autograd import AttentionWindowsFn
         if x.dim() != 4 or x.shape[1] != self.type_of_windows or x.shape[2] != 144 or x.shape[3] != self.dim:
             raise RuntimeError(f"EarthAttention3D: expected (nLon, {self.type_of_windows}, 144, {self.dim}) windows, got {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise RuntimeError(f"EarthAttention3D (MI355X build) needs its input on a HIP device (got {x.device}); there is no CPU fallback")
         n_lon = x.shape[0]
         xw = x.to(torch.float32).contiguous().view(-1, self.dim)
+        m = None if mask is None else mask.detach().to(device=x.device, dtype=torch.float32).contiguous()
         with torch.cuda.device(x.device):
-            qkv = ops.linear(xw, self.linear1.weight, self.linear1.bias)
-            m = None if mask is None else mask.to(device=x.device, dtype=torch.float32).contiguous()
-            o = ops.attention_windows(qkv, self.earth_specific_bias[0], m, n_lon, self.type_of_windows, self.head_number)
-            y = ops.linear(o, self.linear2.weight, self.linear2.bias)
+            if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+                y = AttentionWindowsFn.apply(xw, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
+                                             self.earth_specific_bias, m, (n_lon, self.type_of_windows, self.head_number))
+            else:
+                qkv = ops.linear(xw, self.linear1.weight, self.linear1.bias)
+                o = ops.attention_windows(qkv, self.earth_specific_bias[0], m, n_lon, self.type_of_windows, self.head_number)
+                y = ops.linear(o, self.linear2.weight, self.linear2.bias)
         return y.view(x.shape)
 
     def _construct_index(self):

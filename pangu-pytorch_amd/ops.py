@@ -404,6 +404,27 @@ def attention_windows(qkv, esb, mask, n_lon, types, heads):
     return out
 
 
+def attention_windows_bwd(qkv, esb, mask, dout, n_lon, types, heads):
+    """Backward of `attention_windows`: -> (dqkv (rows, 3C), d_esb (types, heads, 144, 144)); the mask gets no gradient."""
+    lib = _lib.load()
+    M, C3 = qkv.shape
+    C = C3 // 3
+    if M != n_lon * types * 144 or tuple(esb.shape) != (types, heads, 144, 144) or tuple(dout.shape) != (M, C):
+        raise RuntimeError(f"attention_windows_bwd: qkv {tuple(qkv.shape)}, esb {tuple(esb.shape)}, dout {tuple(dout.shape)}")
+    stride = 0
+    if mask is not None:
+        if tuple(mask.shape) == (n_lon, types, 144, 144):
+            stride = types * 144 * 144
+        elif tuple(mask.shape) != (types, 144, 144):
+            raise RuntimeError(f"attention_windows_bwd: mask {tuple(mask.shape)}")
+    dqkv = torch.empty_like(qkv)
+    desb = torch.empty_like(esb)
+    _lib.check(lib.pangu_attn_windows_bwd(_stream(qkv), _chk(qkv, "qkv"), _chk(esb, "esb"),
+                                          _chk(mask, "mask") if mask is not None else None, stride, _chk(dout, "dout"),
+                                          dqkv.data_ptr(), desb.data_ptr(), n_lon, types, heads, C), "attn_windows_bwd")
+    return dqkv, desb
+
+
 def window_attention_bwd(qkv, qkv_bias, esb, out, lse, dout, Z, H, W, heads, shifted, desb_out=None):
     """-> (dqkv [N,3C], dqkv_bias [3C] (pad-slot part of linear1.bias' gradient), d_esb like esb; written into
     `desb_out` (contiguous fp32, esb.numel() elements) when given)."""

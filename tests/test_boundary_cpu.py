@@ -93,9 +93,9 @@ def test_subclassed_linear_is_refused():
         P.layers.assert_plain_tree(blk, "EarthSpecificBlock")
 
 
-def test_earth_attention_forward_refuses_autograd():
+def test_earth_attention_forward_checks_its_windows():
     att = P.layers.EarthAttention3D(192, 6, 0, (2, 6, 12))
-    with pytest.raises(NotImplementedError, match="inference-only"):
-        att(torch.zeros(1, 124, 144, 192), None)
     with torch.no_grad(), pytest.raises(RuntimeError, match="windows"):
         att(torch.zeros(1, 100, 144, 192), None)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):          # right shape, CPU tensor: refused at the first launch
+        att(torch.zeros(1, 124, 144, 192), None)

@@ -56,6 +56,51 @@ def test_earth_attention3d_forward_on_windows(P, golden_dir, C, roll):
         assert ((y2.cpu() - ref2).abs().max() / ref2.abs().max()).item() < 1e-4
 
 
+@pytest.mark.parametrize("C,roll", [(192, True), (384, False)])
+def test_earth_attention3d_module_backward(P, C, roll):
+    """The module on its own is differentiable like the reference's (layers.py:360-421 under autograd): gradients of the input
+    windows and of all five parameters == torch autograd over the oracle's restatement."""
+    st = cases.STAGES[C]
+    blk = P.layers.EarthSpecificBlock(C, 0.0, st["heads"], device="cuda").cuda().eval()
+    pre = cases.block_prefix(C, roll)
+    blk.load_state_dict({k: synth.synth_param(pre + k, s, "cuda") for k, s in cases.block_param_shapes(C).items()})
+    att = blk.attention
+    xw = cases.attention_window_input(C, 2, "cuda").requires_grad_(True)
+    mask = blk.gen_mask(torch.zeros(1, st["Z"], st["H"] + 5, 24, C, device="cuda")) if roll else None
+    y = att(xw, mask)
+    cot = cases.cotangent("attn_windows", y.shape, "cuda")
+    (y * cot).sum().backward()
+    p = {k: v.requires_grad_(True) for k, v in cases.block_params(C, roll).items()}
+    xr = xw.detach().cpu().requires_grad_(True)
+    names = ("attention.linear1.weight", "attention.linear1.bias", "attention.linear2.weight", "attention.linear2.bias",
+             "attention.earth_specific_bias")
+    ref = O.attention_windows(xr, *(p[pre + n] for n in names), mask.cpu() if roll else None)
+    (ref * cot.cpu()).sum().backward()
+    rel = lambda a, b: ((a.detach().cpu() - b).abs().max() / b.abs().max()).item()
+    assert rel(y, ref.detach()) < 1e-4 and rel(xw.grad, xr.grad) < 1e-4
+    for n in names:
+        q = dict(blk.named_parameters())[n]
+        assert q.grad is not None and rel(q.grad, p[pre + n].grad) < 1e-4, n
+
+
+def test_mlp_module_backward(P):
+    """`blk.linear(x)` (Mlp.forward on its own, reference layers.py:264-270) under autograd == torch on the same weights."""
+    C = 192
+    m = P.layers.Mlp(C, 0).cuda()
+    x = synth.uniform((3, 50, C), 5, 1.5).cuda().requires_grad_(True)
+    y = m(x)
+    cot = synth.uniform(tuple(y.shape), 6).cuda()
+    (y * cot).sum().backward()
+    xr = x.detach().clone().requires_grad_(True)
+    w1, b1, w2, b2 = (t.detach().clone().requires_grad_(True) for t in (m.linear1.weight, m.linear1.bias, m.linear2.weight, m.linear2.bias))
+    ref = torch.nn.functional.gelu(xr @ w1.t() + b1) @ w2.t() + b2
+    (ref * cot).sum().backward()
+    rel = lambda a, b: ((a - b).abs().max() / b.abs().max()).item()
+    assert rel(y.detach(), ref.detach()) < 1e-4 and rel(x.grad, xr.grad) < 1e-4
+    for q, r in ((m.linear1.weight, w1), (m.linear1.bias, b1), (m.linear2.weight, w2), (m.linear2.bias, b2)):
+        assert rel(q.grad, r.grad) < 1e-4
+
+
 def test_block_matches_module_pieces(P):
     """The block's fused path == the reference's own composition partition -> attention module -> reverse, with the module
     forward above in the middle (pad rows zero, as the block hands them over)."""

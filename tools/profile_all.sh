@@ -21,5 +21,5 @@ bash tools/pmc_issue_table.sh train bf16 > gpurun_out/${TAG}_train_bf16_issue_ta
 bash tools/pmc_issue_table.sh train f32 > gpurun_out/${TAG}_train_f32_issue_table.md 2>> gpurun_out/${TAG}_round.log
 bash tools/per_step_kernels.sh bf16 > gpurun_out/${TAG}_train_bf16_per_step.md 2>> gpurun_out/${TAG}_round.log
 bash tools/per_step_kernels.sh f32 > gpurun_out/${TAG}_train_f32_per_step.md 2>> gpurun_out/${TAG}_round.log
-PANGU_DIST_FORCE=1 timeout 600 python3 bench.py --no-bf16 --cpu-baseline none --steps 3 --warmup 1 > gpurun_out/${TAG}_rccl_1rank.json 2> gpurun_out/${TAG}_rccl_1rank.err
+RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29531 PANGU_DIST_FORCE=1 timeout 600 python3 bench.py --no-bf16 --cpu-baseline none --steps 3 --warmup 1 > gpurun_out/${TAG}_rccl_1rank.json 2> gpurun_out/${TAG}_rccl_1rank.err
 ls -la gpurun_out/${TAG}_* | head -40
