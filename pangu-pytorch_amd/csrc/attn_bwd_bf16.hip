@@ -150,7 +150,7 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_bf16_kernel(
   for (int i = tid; i < PANGU_WTOK * (PANGU_WTOK / 8); i += NT) {
     const int qn = i / (PANGU_WTOK / 8), c = i - qn * (PANGU_WTOK / 8);
     const u32x4 b = *reinterpret_cast<const u32x4*>(bias_tile + (size_t)qn * PANGU_WTOK + c * 8);
-    const unsigned o = L0 + L_BT + c * 8 * DS_LD + qn * 2;
+    const unsigned o = L0 + L_BT + c * 8 * DS_LD + ((((qn >> 2) ^ (2 * (c & 1))) << 3) | ((qn & 3) << 1));   // swizzled piece, see b_kqbt
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       *ldsp<u16>(o + (2 * e) * DS_LD) = (u16)(b[e] & 0xFFFFu);
@@ -163,9 +163,13 @@ __global__ __launch_bounds__(NT) void window_attn_bwd2_bf16_kernel(
   // d 0..15 / 16..31 of a row image, rows tb + 4lg + tq (tb a multiple of 16: the swizzle term does not see it)
   const unsigned b_trlo = opaque(L0 + L_IMG + kswz(4 * lg + tq, tp >> 1) + 8 * (tp & 1));
   const unsigned b_trhi = opaque(L0 + L_IMG + kswz(4 * lg + tq, 2 + (tp >> 1)) + 8 * (tp & 1));
-  const unsigned b_trds = opaque(L0 + L_DS + (4 * lg + tq) * DS_LD + wave * 32 + 8 * tp);   // dS: key rows, this wave's queries
-  const unsigned b_kqds = opaque(L0 + L_DS + kn * DS_LD + 8 * lg);     // [key kn][query 16i + 4lg ..] (+ 32 i)
-  const unsigned b_kqbt = opaque(L0 + L_BT + kn * DS_LD + 8 * lg);
+  // The [key][query] images have 288-byte rows (72 dwords = 8 mod 32 banks): the 16 lanes of a ds_write_b64 group (16 keys, one
+  // 8-byte piece each) landed on 4 bank pairs (4-way: 108 of ~500 LDS-array cycles per wave and window, round-4 bank model
+  // tools/lds_banks.py), the 32 lanes of a bias^T ds_read_b64 on 16 (2-way).  Swizzle of the 8-byte piece index inside a row:
+  // dS pieces ^ ((key >> 2) & 3), bias^T pieces ^ 2 ((key >> 3) & 1): writes, row reads and transposed reads all conflict-free.
+  const unsigned b_trds = opaque(L0 + L_DS + (4 * lg + tq) * DS_LD + wave * 32 + 8 * (tp ^ (lg & 3)));   // dS: key rows, this wave's queries
+  const unsigned b_kqds = opaque(L0 + L_DS + kn * DS_LD + 8 * (lg ^ ((lq >> 2) & 3)));     // [key kn][query 16i + 4lg ..] (+ 32 i)
+  const unsigned b_kqbt = opaque(L0 + L_BT + kn * DS_LD + 8 * (lg ^ (2 * (lq >> 3))));
   const unsigned b_row = opaque(L0 + L_IMG + kswz(lq, lg));            // row read of token 16x + lq, chunk lg (+ 1024 x)
   const unsigned b_ls = opaque(L0 + L_ROW + lg * 16);                  // lse_s / del_s quads of query tile i (+ 64 i)
   const unsigned b_db = opaque(L0 + L_DB + tid * 16);

@@ -28,11 +28,13 @@ class WeightShadow:
         self.jobs = {}           # key -> (mode, params, dst, idx, n0, n1, blocks, signature of the params)
         self.table = None        # (device int64 job table, keys in table order, total blocks, keys left out)
         self.bulk_epoch = ops._weights_epoch[0]
+        self.makers = {}         # key -> (params, make) of the copies that are NOT bulk-refresh jobs (padded casts): refresh_in_place
         self.fresh = {}          # key -> (epoch, param _version, param address) when an optimizer wrote that copy itself (train.HipAdam): skipped by the next refresh
 
     def clear(self):
         self.cache.clear()
         self.jobs.clear()
+        self.makers.clear()
         self.fresh.clear()
         self.table = None
 
@@ -127,7 +129,27 @@ class WeightShadow:
             self.table = None
         if mode is not None:
             self._record(key, mode, params, w, idx() if callable(idx) else idx)
+        if key not in self.jobs:
+            self.makers[key] = (params, make)
+        else:
+            self.makers.pop(key, None)
         return w
+
+    def refresh_in_place(self):
+        """Re-make EVERY cached copy now, INTO the tensors it already lives in -- for a captured training step
+        (train.GraphedTrainStep), whose graph holds the shadows' addresses and runs no Python that could notice a new optimizer
+        epoch: call after `optimizer.step()`.  The recorded jobs take the one-launch bulk refresh, the few others (padded casts)
+        an in-place copy."""
+        self.bulk_epoch = ops._weights_epoch[0]
+        if self.jobs:
+            self._bulk_refresh()
+        with torch.no_grad():
+            for key, (params, make) in list(self.makers.items()):
+                hit = self.cache.get(key)
+                if hit is None or key in self.jobs:
+                    continue
+                hit[1].copy_(make())
+                self.cache[key] = (tuple(_stamp(p) for p in params), hit[1])
 
     def get(self, p, pad_k=None):
         def make():

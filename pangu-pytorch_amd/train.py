@@ -228,6 +228,60 @@ def make_optimizer(model, lr=5e-6, weight_decay=3e-6):
     return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, fused=on_gpu)
 
 
+class GraphedTrainStep:
+    """OPT-IN: forward + loss + backward of one fixed-shape batch captured in a hipGraph, Adam stepped eagerly after each replay
+    (its bias corrections are host scalars that change every step; it is ONE launch).  For a model WITHOUT active stochastic depth
+    only (model.eval(), or every DropPath at rate 0): a captured step cannot skip a dropped branch -- it would have to compute it
+    and scale it by a zero read from device memory, as the reference does, which costs the ~10 % of block work that not computing
+    dropped branches saves.  Measured (tools/profile_train.py <dtype> <steps> <warmup> graph): the eager step is
+    not host-bound, so replaying it from a graph recovers next to nothing -- this class exists to make that a number.
+    The bf16 weight shadows the graph reads are re-made IN PLACE after every optimizer step (WeightShadow.refresh_in_place)."""
+
+    def __init__(self, model, optimizer, batch, statistics, maps, const_h, stats_last=None, warmup=2):
+        from .layers import DropPath
+        if model.training and any(isinstance(m, DropPath) and m.drop_prob > 0.0 for m in model.modules()):
+            raise RuntimeError("GraphedTrainStep: stochastic depth is active (model.train() with DropPath rates > 0): a captured step "
+                               "cannot skip dropped branches; call model.eval() or use train.train_step")
+        self.model, self.optimizer = model, optimizer
+        self.batch = [t.clone() for t in batch]
+        self.consts, self.stats_last = (statistics, maps, const_h), stats_last
+        dev = self.batch[0].device
+        with torch.cuda.device(dev):
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):            # outside capture: weight shadows, loss weights, allocator, lazy LDS attributes
+                    optimizer.zero_grad(set_to_none=True)
+                    self._fwd_bwd()
+            torch.cuda.current_stream().wait_stream(side)
+            optimizer.zero_grad(set_to_none=True)      # the gradients are (re-)allocated INSIDE the capture: static addresses
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.loss = self._fwd_bwd()
+
+    def _fwd_bwd(self):
+        inp, inp_s, tgt, tgt_s = self.batch
+        out, out_s = self.model(inp, inp_s, *self.consts)
+        if self.stats_last is not None:
+            tgt, tgt_s = norm_data(tgt, tgt_s, self.stats_last)
+        loss = weighted_l1_loss(out, out_s, tgt, tgt_s)
+        loss.backward()
+        return loss.detach()
+
+    def step(self, batch=None):
+        """Replay fwd + loss + bwd on `batch` (copied into the static buffers; None = the captured batch again), then one optimizer
+        step; returns the (static) loss tensor."""
+        if batch is not None:
+            for dst, src in zip(self.batch, batch):
+                dst.copy_(src)
+        self.graph.replay()
+        self.optimizer.step()
+        sh = getattr(self.model, "_shadow", None)
+        if sh is not None and sh.cache:
+            sh.refresh_in_place()
+        return self.loss
+
+
 def train_step(model, optimizer, batch, statistics, maps, const_h, stats_last=None, grad_sync=None):
     """One optimisation step (reference pangu_sample.py:45-77). batch = (input, input_surface, target, target_surface).
     `grad_sync` (optional callable) runs between backward and optimizer.step(): the data-parallel gradient

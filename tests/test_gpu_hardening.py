@@ -281,3 +281,39 @@ def test_bf16_shadows_follow_inplace_edit_after_hip_adam_step(P):
         m.invalidate_shadows()
         fresh = m(inp, inp_s, stats, maps, const_h)[0]
     assert torch.equal(out, fresh)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, BF])
+def test_graphed_train_step_matches_eager(P, dt):
+    """train.GraphedTrainStep (fwd + loss + bwd replayed from a hipGraph, Adam eager; DropPath off) == the eager train_step: same
+    losses over three optimisation steps (lr large enough that the weights move), and in bf16 the weight shadows the graph reads
+    are re-made in place after every step (a forward on freshly rebuilt shadows gives the same bits)."""
+    from pangu_pytorch_amd import train
+    inp, inp_s, stats, maps, const_h = cases.model_inputs("cuda")
+    tgt, tgt_s = cases.model_targets("cuda")
+    losses = {}
+    for how in ("eager", "graph"):
+        m = P.PanguModel(device="cuda").cuda().eval()
+        m.load_state_dict(synth.fill_state_dict(cases.model_param_shapes(), "cuda", spec="refinit"))
+        m.set_compute_dtype(dt)
+        opt = train.HipAdam([p for p in m.parameters()], lr=1e-4, shadow_of=m)
+        if how == "graph":
+            g = train.GraphedTrainStep(m, opt, (inp, inp_s, tgt, tgt_s), stats, maps, const_h)
+            losses[how] = [float(g.step()) for _ in range(3)]
+            if dt == BF:
+                with torch.no_grad():
+                    a = m(inp, inp_s, stats, maps, const_h)[0].clone()
+                    m.invalidate_shadows()
+                    b = m(inp, inp_s, stats, maps, const_h)[0]
+                assert torch.equal(a, b)
+        else:
+            losses[how] = [float(train.train_step(m, opt, (inp, inp_s, tgt, tgt_s), stats, maps, const_h)) for _ in range(3)]
+        del m, opt
+        torch.cuda.empty_cache()
+    print(dt, losses)
+    assert losses["eager"][2] < losses["eager"][0]                      # the steps really optimise
+    for a, b in zip(losses["eager"], losses["graph"]):
+        assert abs(a - b) < (2e-5 if dt == torch.float32 else 2e-3) * abs(a)
+    m = P.PanguModel(device="cuda").cuda().train()
+    with pytest.raises(RuntimeError, match="stochastic depth"):
+        train.GraphedTrainStep(m, train.make_optimizer(m), (inp, inp_s, tgt, tgt_s), stats, maps, const_h)

@@ -61,3 +61,22 @@ def test_vt_writes():
     for t in range(9):
         c, n = cycles("write_b64", lambda l: vt_off(l & 15, 16 * t + 4 * (l >> 4)))
         assert c <= 2 * n
+
+
+def test_attn_bwd_bf16_key_query_images():
+    """csrc/attn_bwd_bf16.hip: the [key][query] bf16 images (dS of the current window, bias^T), 288-byte rows, 8-byte pieces
+    swizzled inside a row (dS: ^ ((key >> 2) & 3), bias^T: ^ 2 ((key >> 3) & 1)).  lane = (lq = l & 15, lg = l >> 4)."""
+    LD = 288
+    for wave in range(9):
+        kn = lambda l: wave * 16 + (l & 15)
+        for i in range(9):
+            # phase 1: dS piece write of key kn, queries 16 i + 4 lg ..; bias^T piece read
+            assert conflict_free("write_b64", lambda l: kn(l) * LD + 8 * ((l >> 4) ^ (((l & 15) >> 2) & 3)) + 32 * i)
+            assert conflict_free("read_b64", lambda l: kn(l) * LD + 8 * ((l >> 4) ^ (2 * ((l & 15) >> 3))) + 32 * i)
+        for m in range(9):
+            # phase 2: transposed read of 4 key rows x 16 queries per 16-lane group: rows 16 m + 4 lg + tq, piece 4 wave + (tp ^ lg)
+            assert conflict_free("read_tr16", lambda l: (16 * m + 4 * (l >> 4) + ((l & 15) >> 2)) * LD + wave * 32 + 8 * ((l & 3) ^ ((l >> 4) & 3)))
+    # the swizzles are bijections of a row's 36 pieces and the reader finds what the writer stored
+    for key in range(144):
+        assert sorted((p ^ ((key >> 2) & 3)) for p in range(36)) == list(range(36))
+        assert sorted((p ^ (2 * ((key >> 3) & 1))) for p in range(36)) == list(range(36))

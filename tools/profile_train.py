@@ -16,17 +16,25 @@ from pangu_pytorch_amd import train  # noqa: E402
 which = sys.argv[1] if len(sys.argv) > 1 else "f32"           # f32 | bf16 | both
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 warm = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+mode = sys.argv[4] if len(sys.argv) > 4 else "droppath"      # droppath (the default step) | nodrop (eager, DropPath off) | graph (captured, DropPath off)
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 model = P.PanguModel(device=dev).to(dev).train()
+if mode != "droppath":
+    model.eval()            # stochastic depth off (the only thing eval() changes in this model): what a captured step requires
 inp, inp_s, stats, maps, const_h = bench.synthetic_inputs(dev, 1000)
 tgt, tgt_s, *_ = bench.synthetic_inputs(dev, 2000)
 opt = train.make_optimizer(model)
 batch = (inp, inp_s, tgt, tgt_s)
 for dt in ([torch.float32, torch.bfloat16] if which == "both" else [torch.bfloat16 if which == "bf16" else torch.float32]):
     model.set_compute_dtype(dt)
+    if mode == "graph":
+        gts = train.GraphedTrainStep(model, opt, batch, stats, maps, const_h)
+        one_step = lambda: gts.step()
+    else:
+        one_step = lambda: train.train_step(model, opt, batch, stats, maps, const_h)
     for _ in range(warm):
-        train.train_step(model, opt, batch, stats, maps, const_h)
+        one_step()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -34,7 +42,7 @@ for dt in ([torch.float32, torch.bfloat16] if which == "both" else [torch.bfloat
     host = 0.0
     for _ in range(steps):
         h0 = time.perf_counter()
-        loss = train.train_step(model, opt, batch, stats, maps, const_h)
+        loss = one_step()
         host += time.perf_counter() - h0
     b.record()
     torch.cuda.synchronize()
@@ -42,5 +50,5 @@ for dt in ([torch.float32, torch.bfloat16] if which == "both" else [torch.bfloat
         print("warm-up only")
         continue
     wall = (time.perf_counter() - t0) / steps * 1e3
-    print(f"{'bf16' if dt == torch.bfloat16 else 'f32'} train: wall {wall:.2f} ms/step, GPU (events) {a.elapsed_time(b) / steps:.2f} ms/step, "
+    print(f"{'bf16' if dt == torch.bfloat16 else 'f32'} train ({mode}): wall {wall:.2f} ms/step, GPU (events) {a.elapsed_time(b) / steps:.2f} ms/step, "
           f"host time spent issuing a step {host / steps * 1e3:.2f} ms, loss {float(loss):.4f}")
