@@ -127,18 +127,26 @@ __global__ __launch_bounds__(256, (TNN * TK <= 6) ? 4 : 3) void wgrad_f32_dma_ke
     }
   }
 
-  // dW tile: C/D layout col = lane&31 (k), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (n)
+  // dW tile: C/D layout col = lane&31 (k), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (n).  ONE running row pointer per 32 x 32 tile,
+  // made opaque per tile: left to itself the compiler forms all 144 element addresses (64-bit) up front, next to the 144 accumulator
+  // registers -- 65-66 registers through scratch in the <3,3> instantiation at its 168-VGPR cap (rounds 2-3)
+  float* tile0 = dW + ((size_t)(TWO_STAGE ? (size_t)split * N : 0) + n0 + wn * 32 * TNN + 4 * lh) * K + k0 + wk * 32 * TK + lr;
 #pragma unroll
   for (int j = 0; j < TK; ++j) {
-    const int kc = k0 + wk * 32 * TK + j * 32 + lr;
 #pragma unroll
-    for (int i = 0; i < TNN; ++i)
+    for (int i = 0; i < TNN; ++i) {
+      float* p = tile0 + (size_t)(i * 32) * K + j * 32;
+      asm volatile("" : "+v"(p));
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wn * 32 * TNN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (TWO_STAGE) dW[((size_t)split * N + n) * K + kc] = acc[i][j][r];      // dW = the workspace here
-        else atomicAdd(&dW[(size_t)n * K + kc], acc[i][j][r]);
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (TWO_STAGE) *p = acc[i][j][4 * q + e];                            // dW = the workspace here
+          else atomicAdd(p, acc[i][j][4 * q + e]);
+          p += (e < 3) ? K : 5 * K;                                            // rows 8q + e -> 8q + e + 1 ... -> 8(q + 1)
+        }
       }
+    }
   }
   if (want_db && (WG_BN == 128 || tid < WG_BN)) atomicAdd(&db[n0 + db_col], dbacc);
 }
