@@ -207,15 +207,15 @@ extern "C" int pangu_linear_wgrad_bf16_ws(pangu_stream_t stream, const void* dC,
   hipStream_t s = (hipStream_t)stream;
   const u16* d = (const u16*)dC;
   const u16* a = (const u16*)A;
-  // LDS-DMA kernel (three workgroups per CU) for the large products: +5-21 % at qkv / MLP shapes (>= 115 GFLOP); the small
-  // ones (proj, down/up-sampling, embed/recover: <= 77 GFLOP) end in the fp32 atomics of their tile sooner than the extra
-  // workgroups pay, and stay on the register-staged kernel (measured per shape, tools/bench_kernels.py wgrad_bf16).
+  // LDS-DMA kernel for the large products (tools/bench_kernels.py wgrad_bf16, tools/ablate_wgrad.py; round 4, with a workspace):
+  // -14...-24 % at the qkv / MLP / down- and up-sampling shapes (>= 77 GFLOP) and -5 % at the C = 384 projections (38 GFLOP, N a
+  // multiple of 384: one 12-wave tile column); the C = 192 projections and the patch embedding (38 GFLOP, N = 192: 4-wave tiles)
+  // end in their partial tiles sooner than the extra workgroups pay (0.119 against 0.104 ms) and stay on the register-staged
+  // kernel, like everything without a workspace below 100 GFLOP (fp32 atomic tail).
   constexpr int dma_target = 768;
-  // with a workspace the partial tiles leave with plain stores and a second launch sums them (no atomic tail): -5...-10 % at
-  // the qkv / MLP shapes, and the LDS-DMA kernel then also wins at the 77-GFLOP down/up-sampling shapes (not at the 38-GFLOP
-  // projections: 0.136 vs 0.108 ms at C = 192)
   const bool ws_ok = workspace != nullptr && workspace_bytes > 0 && (reinterpret_cast<size_t>(workspace) & 15) == 0;
-  if (2.0 * M * N * K >= (ws_ok ? 6.0e10 : 1.0e11)) {
+  const double flop = 2.0 * M * N * K;
+  if (flop >= (ws_ok ? 6.0e10 : 1.0e11) || (ws_ok && N % 384 == 0 && flop >= 3.0e10)) {
     const int rc = pangu_linear_wgrad_bf16_dma(s, d, lddc, a, lda, dW, db, M, N, K, dma_target, ws_ok ? workspace : nullptr,
                                                ws_ok ? (size_t)workspace_bytes : 0);
     if (rc != 1) return rc;

@@ -393,6 +393,26 @@ def test_linear_wgrad_bf16_model_size(P, M, N, K, strided):
     assert rel_err(db, dc.double().sum(0)) < 2e-4
 
 
+@pytest.mark.parametrize("M,N,K", [(131040, 1536, 384), (300000, 192, 1152), (260000, 576, 384)])
+def test_linear_wgrad_bf16_without_workspace(P, M, N, K):
+    """pangu_linear_wgrad_bf16 (no scratch buffer): the LDS-DMA kernels end in fp32 atomics on dW -- the 384 x 192 and 192 x 384
+    12-wave tiles and the 128 x 192 4-wave tile (N = 576: a half-empty last tile) -- and ADD into what dW / db already hold."""
+    from pangu_pytorch_amd import _lib
+    assert 2.0 * M * N * K >= 1.0e11
+    lib = _lib.load()
+    dc = synth.uniform((M, N), 65, device="cuda").to(BF)
+    a = synth.uniform((M, K), 66, device="cuda").to(BF)
+    dw = torch.full((N, K), 0.5, device="cuda")
+    db = torch.full((N,), -0.25, device="cuda")
+    _lib.check(lib.pangu_linear_wgrad_bf16(torch.cuda.current_stream().cuda_stream, dc.data_ptr(), N, a.data_ptr(), K,
+                                           dw.data_ptr(), db.data_ptr(), M, N, K), "linear_wgrad_bf16")
+    ref_w = torch.zeros((N, K), dtype=torch.float64, device="cuda")
+    for m0 in range(0, M, 32768):
+        ref_w += dc[m0:m0 + 32768].double().t() @ a[m0:m0 + 32768].double()
+    assert rel_err(dw - 0.5, ref_w) < 2e-4
+    assert rel_err(db + 0.25, dc.double().sum(0)) < 2e-4
+
+
 @pytest.mark.parametrize("C", [192, 384])
 def test_ln_residual_bwd_bf16(P, C):
     from pangu_pytorch_amd import ops_bf16 as ob

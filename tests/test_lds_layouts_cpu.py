@@ -80,3 +80,24 @@ def test_attn_bwd_bf16_key_query_images():
     for key in range(144):
         assert sorted((p ^ ((key >> 2) & 3)) for p in range(36)) == list(range(36))
         assert sorted((p ^ (2 * ((key >> 3) & 1))) for p in range(36)) == list(range(36))
+
+
+def _wgrad_swz(rowb, row, chunk):
+    mask = 2 * (row & 7) if rowb % 256 == 0 else 2 * ((row >> 1) & 3)
+    return row * rowb + ((chunk ^ mask) << 4)
+
+
+@pytest.mark.parametrize("rowb", [256, 384, 768])
+def test_wgrad_bf16_dma_slab_images(rowb):
+    """csrc/wgrad_bf16_dma.hip: token-major slabs of 32 rows x rowb bytes (dC at 2 / 3 / 6 wave rows, A at 2 / 4 wave columns),
+    16-B chunks XOR-swizzled on the DMA's source side.  Every transposing fragment read (lane 4q + p of a 16-lane group: token row
+    row0 + 4 lg + q, 8 bytes inside chunk col0 / 8 + (p >> 1)) is conflict-free, and the swizzle permutes the chunks of a row."""
+    nch = rowb // 16
+    for row in range(32):
+        assert sorted(_wgrad_swz(rowb, row, c) for c in range(nch)) == [row * rowb + 16 * c for c in range(nch)]
+    for row0 in (0, 16):
+        for col0 in range(0, rowb // 2, 16):
+            def addr(l):
+                lc, lg = l & 15, l >> 4
+                return _wgrad_swz(rowb, row0 + 4 * lg + (lc >> 2), (col0 >> 3) + ((lc & 3) >> 1)) + 8 * (lc & 1)
+            assert conflict_free("read_tr16", addr), (rowb, row0, col0)
