@@ -281,8 +281,9 @@ int pangu_patch_embed_gather_bf16(pangu_stream_t stream, const float* input, con
 int pangu_linear_wgrad_bf16(pangu_stream_t stream, const void* dC, int lddc, const void* A, int lda, float* dW,
                             float* db, int M, int N, int K);
 /* The same product with a caller-owned scratch buffer (16-B aligned device memory, contents irrelevant before and after):
- * when it holds one N x K fp32 tile per token slab (<= 80 MB at the model's shapes) the partial tiles are written there with
- * plain stores and summed into dW by a second launch instead of 75 MB of fp32 atomics; too small or NULL = the entry above. */
+ * when it holds one fp32 partial tile per resident workgroup (N rounded up to whole tiles x K per token slab: <= 80 MB at the
+ * model's shapes) the partial tiles are written there with plain stores (in MFMA register order) and summed into dW by a second
+ * launch instead of 75 MB of fp32 atomics; too small or NULL = the entry above. */
 int pangu_linear_wgrad_bf16_ws(pangu_stream_t stream, const void* dC, int lddc, const void* A, int lda, float* dW,
                                float* db, int M, int N, int K, float* workspace, long long workspace_bytes);
 int pangu_window_attn_bwd_bf16(pangu_stream_t stream, const void* qkv, const void* qkv_bias, const void* esb,
