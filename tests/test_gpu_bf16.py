@@ -658,7 +658,7 @@ def test_block_bf16_drift_within_2x_of_reference_autocast(P, golden_dir, C, roll
 def test_full_backward_smooth_bf16_refinit_vs_reference(P, golden_dir):
     """whole-model bf16 backward against the REFERENCE's fp32 autograd in the reference's initialisation
     regime (tests/golden/refinit.npz): the loss, the output, and every one of the 223 gradient tensors -- worst tensor bounded
-    at 5e-2 rel-L2 over its stored samples (the O(1) non-contractive golden weights need 0.35: they amplify, this regime
+    at 5.5e-2 rel-L2 over its stored samples (the O(1) non-contractive golden weights need 0.35: they amplify, this regime
     does not)."""
     g = np.load(os.path.join(golden_dir, "refinit.npz"))
     m = P.PanguModel(device="cuda").cuda().eval()
@@ -684,9 +684,9 @@ def test_full_backward_smooth_bf16_refinit_vs_reference(P, golden_dir):
         go = torch.as_tensor(g["model.out.samples"]).double()
         return loss.item(), ((out.detach().flatten()[pos].cpu().double() - go).norm() / go.norm()).item(), res
 
-    # bf16 worst-tensor sample error: 4.4e-2 / 5.0e-2 with the two equally accurate forward resampling kernels (median 1.17e-2 /
-    # 1.19e-2): the bound leaves that spread
-    for dt, tol_s, tol_n, tol_o in ((torch.float32, 2e-3, 1e-3, 1e-4), (BF, 6e-2, 2e-2, 1.5e-2)):
+    # bf16 worst-tensor sample error: 5.02e-2 (median 1.19e-2) with the 16-B resampling LayerNorm kernels, which are the only arm
+    # since round 4 (compile-time constants in csrc/rowops_bf16.hip; the equally accurate generic kernels gave 4.4e-2 / 1.17e-2)
+    for dt, tol_s, tol_n, tol_o in ((torch.float32, 2e-3, 1e-3, 1e-4), (BF, 5.5e-2, 2e-2, 1.5e-2)):
         loss, oerr, res = run(dt)
         worst_s, worst_n = max(res), max((r[1], r[2]) for r in res)
         med = sorted(r[0] for r in res)[len(res) // 2]
