@@ -83,9 +83,10 @@ __device__ inline unsigned tr_addr(int col0, int lg, int lc) {
 
 // WB_M = tokens per K-step (32), S = ring slots.  Measured and dropped at 2 x 2: 64-token steps at two workgroups per CU (no
 // better than the register-staged kernel), four workgroups per CU (128-VGPR cap: spills in the K loop, 3x slower).
-// TWO_STAGE: the workgroup's partial tile goes to its token slab's slice of a workspace with PLAIN stores (free next to the
-// MFMAs: the stamps of the atomic form show 15-50 % of the kernel in its fp32 atomic tail -- 75 MB of adds per launch at the
-// chip's 1.3 TB/s atomic rate) and wgrad_reduce_kernel sums the slices into dW.
+// TWO_STAGE: the workgroup's partial tile goes to its token slab's slice of a workspace with PLAIN stores, in MFMA register
+// order (the atomic form spends 15-50 % of the kernel in its fp32 atomic tail: 75 MB of adds per launch at the chip's ~1.2 TB/s
+// atomic rate, XCD-private lines or not -- tools/ubench_xcd_atomics.hip; the same bytes as stores: 14 us) and
+// wgrad_reduce_tiles_kernel sums the slices into dW.
 template <int WB_M, int NWN, int NWK, int S, int MIN_WGS, bool TWO_STAGE>
 __global__ __launch_bounds__(64 * NWN * NWK, MIN_WGS) void wgrad_bf16_dma_kernel(
     const u16* __restrict__ dC, int lddc, const u16* __restrict__ A, int lda, float* __restrict__ dW,
