@@ -22,8 +22,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 FWD_GFLOP = 8421.2          # SURVEY.md §8(a) ledger: dense-contraction GFLOP per forward step on the reference's PADDED shapes
 FWD_GFLOP_EXEC = 8302.3     # executed here: the QKV / output projections skip the zero-pad rows (4 x 4.25 + 12 x 8.49 GFLOP less)
 XGMI_LINK_GBS = 153.0       # one xGMI link, one direction (7 links per GPU, point to point)
@@ -34,8 +32,58 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0
 SHARED_SOURCES = ["common.h", os.path.join("..", "..", "include", "pangu_hip.h")]      # hashed with every kernel family (tools/pmc_to_json.py too)
 
 
+# executed dense-contraction GFLOP of ONE residual branch of one block, forward (projections on the unpadded tokens, the
+# attention core on the padded windows): what a DropPath-dropped branch does NOT execute (layers.py:250-251)
+_N0, _NP0, _N1, _NP1 = 521280, 535680, 131040, 138240
+BRANCH_GFLOP = {192: (2e-9 * _N0 * 192 * 576 + 4e-9 * _NP0 * 144 * 192 + 2e-9 * _N0 * 192 * 192, 4e-9 * _N0 * 192 * 768),
+                384: (2e-9 * _N1 * 384 * 1152 + 4e-9 * _NP1 * 144 * 384 + 2e-9 * _N1 * 384 * 384, 4e-9 * _N1 * 384 * 1536)}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", choices=("auto", "sample", "full", "none"), default="auto",
+                    help="sample: oracle block pairs on a half-longitude slice, extrapolated (~15 s); full: also the oracle's whole "
+                         "forward once (45 s on a 256-core host, minutes on 8 cores); auto = full on hosts with >= 32 cores")
+    ap.add_argument("--no-bf16", action="store_true", help="skip the secondary bf16 forward measurement")
+    ap.add_argument("--no-train", action="store_true", help="skip the secondary DDP training-step measurement")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the reference-call-convention timings (grad-enabled eval forward, the reference's own loop body)")
+    ap.add_argument("--train-steps", type=int, default=6)
+    ap.add_argument("--grad-sync", choices=("all_reduce", "reduce_scatter"), default="all_reduce",
+                    help="the collective of dist.FlatGradSync (N > 1): bucketed all_reduce(AVG), or reduce_scatter + all_gather per bucket")
+    return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: THIS process (which has not touched the GPU -- torch is
+    not even imported yet) starts `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a CHILD
+    process, relays rank 0's JSON line and the child's return code.  No exec of a GPU-initialised process anywhere."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)      # stderr passes through
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    for ln in r.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    return r.returncode if (r.returncode != 0 or lines) else 1
+
+
 def cpu_baseline():
     """Time the CPU oracle on a half-longitude slice of each stage (10-20 s of CPU work) and extrapolate to one forward step."""
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))      # the ONLY place bench.py touches oracle/: the CPU baseline leg
     import cases
     import pangu_oracle as O
@@ -82,6 +130,7 @@ def cpu_baseline():
 def cpu_baseline_full(threads):
     """The CPU oracle's WHOLE forward (oracle/pangu_oracle.forward, the restatement of reference pangu_model.py:50-87) timed
     once on this host with `threads` threads, on the bench's synthetic shapes."""
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cases
     import pangu_oracle as O
@@ -136,6 +185,7 @@ def pmc_train(tag):
 def synthetic_inputs(dev, seed):
     """One synthetic ERA5-shaped sample, resident in HBM: upper-air (1,5,13,721,1440), surface (1,4,721,1440), O(1)
     values, non-trivial normalisation statistics, the three constant maps and const_h (reference pangu_model.py:60-66)."""
+    import torch
     g = torch.Generator(device=dev).manual_seed(seed)
     u = lambda shape, scale=1.0, shift=0.0: (torch.rand(shape, generator=g, device=dev) * 2 - 1) * scale + shift
     inp, inp_s = u((1, 5, 13, 721, 1440)), u((1, 4, 721, 1440))
@@ -144,24 +194,13 @@ def synthetic_inputs(dev, seed):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline", choices=("auto", "sample", "full", "none"), default="auto",
-                    help="sample: oracle block pairs on a half-longitude slice, extrapolated (~15 s); full: also the oracle's whole "
-                         "forward once (45 s on a 256-core host, minutes on 8 cores); auto = full on hosts with >= 32 cores")
-    ap.add_argument("--no-bf16", action="store_true", help="skip the secondary bf16 forward measurement")
-    ap.add_argument("--no-train", action="store_true", help="skip the secondary DDP training-step measurement")
-    ap.add_argument("--train-steps", type=int, default=6)
-    args = ap.parse_args()
-
+    args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))          # plain `python bench.py --gpus N`: spawn the N ranks as a child process
+    import torch
     n_dev = torch.cuda.device_count()
     local_rank = local_rank % max(n_dev, 1)      # (functional tests may run several ranks on one GPU with gloo)
     torch.cuda.set_device(local_rank)
@@ -299,7 +338,7 @@ def main():
         model.train()
         tgt, tgt_s, *_ = synthetic_inputs(dev, seed=2000 + rank)      # synthetic targets of the input's shape
         opt = train.make_optimizer(model)      # Adam(lr=5e-6, weight_decay=3e-6), reference finetune_fully.py:121
-        sync = FlatGradSync(model, force_collective=True) if dist is not None else None
+        sync = FlatGradSync(model, force_collective=True, mode=args.grad_sync) if dist is not None else None
         batch = (inp, inp_s, tgt, tgt_s)
         exposed = []      # (event before finish(), event after): GPU time the compute stream spends waiting for the buckets
 
@@ -309,20 +348,31 @@ def main():
             sync.finish()
             b.record()
             exposed.append((a, b))
+        from pangu_pytorch_amd.layers import DropPath
+        dps = [(blk.attention.dim, blk.drop_path) for layer in model.layers for blk in layer.blocks if isinstance(blk.drop_path, DropPath)]
+
+        def dropped_gflop(before):
+            """Forward GFLOP the DropPath-dropped branches of the steps since `before` did NOT execute (per-branch counters)."""
+            return sum((d.n_dropped_branch[0] - b[0]) * BRANCH_GFLOP[C][0] + (d.n_dropped_branch[1] - b[1]) * BRANCH_GFLOP[C][1]
+                       for (C, d), b in zip(dps, before))
         for tag, dt in (("ddp_train", torch.float32), ("ddp_train_bf16", torch.bfloat16)):
             try:
                 model.set_compute_dtype(dt)
-                torch.manual_seed(1234 + rank)            # DropPath draws (host RNG)
+                torch.manual_seed(1234 + rank)            # DropPath draws (host RNG): tools/profile_train.py seeds the same way
                 torch.cuda.reset_peak_memory_stats()
                 for _ in range(2):                        # untimed: builds the weight shadows / Adam state, then one steady-state step
                     train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=grad_sync if sync else None)
                 lsync()
                 del exposed[:]
+                drops0 = [tuple(d.n_dropped_branch) for _, d in dps]
                 t1 = time.perf_counter()
                 for _ in range(args.train_steps):
                     loss = train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=grad_sync if sync else None)
                 lsync()
                 t_train = time.perf_counter() - t1
+                skipped = dropped_gflop(drops0) / args.train_steps            # forward GFLOP per step that was NOT executed
+                n_drop = sum(d.n_dropped_branch[0] + d.n_dropped_branch[1] - b[0] - b[1] for (_, d), b in zip(dps, drops0))
+                exec_gflop = 3.0 * (FWD_GFLOP_EXEC - skipped)                 # fwd + bwd = 3 x forward (SURVEY 8(d))
                 what = ("fwd+bwd+bucketed grad all-reduce (RCCL, issued from the backward hooks)+Adam" if sync else
                         "fwd+bwd+Adam; ONE rank: no collective and no flat gradient buffer exist (see ddp_model for the all-reduce)")
                 train_res[tag] = {
@@ -331,21 +381,40 @@ def main():
                     "value": world * args.train_steps / t_train, "ms_per_step": t_train / args.train_steps * 1e3,
                     "steps": args.train_steps, "loss": float(loss),
                     "peak_mem_gb": torch.cuda.max_memory_allocated() / 2**30,
-                    "model_tflops": 3 * FWD_GFLOP_EXEC / (t_train / args.train_steps * 1e3)}
-                # roofline block of the training step: bytes per step from the committed PMC table, both fractions
+                    "model_tflops": exec_gflop / (t_train / args.train_steps * 1e3),
+                    "dropped_branches_in_timed_steps": n_drop}
+                # the same step with stochastic depth OFF (every branch computed: the full 3 x forward ledger), timed beside it
+                saved_p = [d.drop_prob for _, d in dps]
+                for _, d in dps:
+                    d.drop_prob = 0.0
+                train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=grad_sync if sync else None)
+                lsync()
+                t2 = time.perf_counter()
+                n_off = max(2, args.train_steps // 2)
+                for _ in range(n_off):
+                    train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=grad_sync if sync else None)
+                lsync()
+                t_off = (time.perf_counter() - t2) / n_off
+                for (_, d), pr in zip(dps, saved_p):
+                    d.drop_prob = pr
+                # roofline block of the training step: EXECUTED work of the timed steps; bytes per step from the committed PMC table
                 pm, pm_stale, pm_commit = pmc_train("bf16" if dt == torch.bfloat16 else "f32")
                 t_s = t_train / args.train_steps
-                flop = 3 * FWD_GFLOP_EXEC * 1e9
+                flop = exec_gflop * 1e9
+                full = 3 * FWD_GFLOP_EXEC * 1e9
                 peak = PEAK_BF16_MFMA_TFLOPS if dt == torch.bfloat16 else PEAK_F32_MFMA_TFLOPS
                 train_res[tag]["roofline"] = {
-                    "algorithmic_flop_per_step": flop, "mfma_peak": peak, "mfma_frac": flop / t_s / 1e12 / peak,
+                    "executed_flop_per_step": flop, "mfma_peak": peak, "mfma_frac": flop / t_s / 1e12 / peak,
+                    "droppath_skipped_flop_per_step": 3 * skipped * 1e9,
+                    "droppath_off": {"ms_per_step": t_off * 1e3, "flop_per_step": full, "mfma_frac": full / t_off / 1e12 / peak,
+                                     "steps": n_off},
                     "hbm_bytes_per_step": pm["hbm_bytes_per_step"] if pm else None,
                     "hbm_frac_of_8TBps": pm["hbm_bytes_per_step"] / t_s / 1e9 / PEAK_HBM_GBS if pm else None,
                     "hbm_frac_of_achievable_6.29TBps": pm["hbm_bytes_per_step"] / t_s / 1e9 / ACHIEVABLE_HBM_GBS if pm else None,
                     "bound": ("hbm" if pm and pm["hbm_bytes_per_step"] / PEAK_HBM_GBS / 1e9 > flop / peak / 1e12 else "mfma"),
                     "traffic_stale": pm_stale, "traffic_commit": pm_commit,
                     "traffic_unit": "HBM bytes per step = sum over all kernels of one step (FETCH_SIZE x2 + WRITE_SIZE; rocprofv3 --pmc "
-                                    "passes of tools/profile_train.py -> profiles/pmc_train.json)"}
+                                    "passes of tools/profile_train.py, same DropPath seed as this loop -> profiles/pmc_train.json)"}
                 if sync:
                     train_res[tag]["exposed_allreduce_ms_per_step"] = sum(a.elapsed_time(b) for a, b in exposed) / max(len(exposed), 1)
                     train_res[tag]["grad_copy_fallback_mib"] = sync.copied_bytes / 2**20
@@ -359,11 +428,74 @@ def main():
                     train_res[tag] = {"error": "another rank failed this section"}
                     break
                 if ok:
-                    train_res[tag].update(ms_per_step=t[0].item(), value=world / (t[0].item() * 1e-3),
-                                          model_tflops=3 * FWD_GFLOP_EXEC / t[0].item())
+                    train_res[tag].update(ms_per_step=t[0].item(), value=world / (t[0].item() * 1e-3))
                 else:
                     break
         model.set_compute_dtype(torch.float32)
+        if sync is not None:
+            sync.remove()
+        del opt, sync
+
+    # ---- the reference's OWN call conventions, timed (no collectives in here): what a maintainer gets from dropping the model in
+    # without touching the scripts
+    extras = None
+    if not args.no_extras:
+        extras = {}
+        try:
+            from pangu_pytorch_amd import train
+            n_x = max(3, args.steps // 4)
+            # (a) test() of models/pangu_sample.py:197-202: model.eval() and NO torch.no_grad() -> the autograd (activation-saving)
+            # forward runs; the graph is dropped with the outputs
+            model.eval()
+            fe = {"note": "model.eval() with grads ENABLED (reference models/pangu_sample.py:197-202 calls the model without no_grad): "
+                          "the activation-saving training forward runs; wrap test() in torch.no_grad() to get the headline"}
+            for key, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+                model.set_compute_dtype(dt)
+                for _ in range(2):
+                    o = model(inp, inp_s, stats, maps, const_h)
+                    del o
+                lsync()
+                t1 = time.perf_counter()
+                for _ in range(n_x):
+                    o = model(inp, inp_s, stats, maps, const_h)
+                    del o
+                lsync()
+                fe[key] = (time.perf_counter() - t1) / n_x * 1e3
+            extras["forward_grad_enabled_eval_ms"] = fe
+            # (b) the loop body of models/pangu_sample.py:45-77 as written there: optimizer.zero_grad(); model.train(); forward;
+            # torch-op weighted L1; loss.backward(); optimizer.step() with torch.optim.Adam's defaults (finetune_fully.py:121)
+            tgt, tgt_s, *_ = synthetic_inputs(dev, seed=2000 + rank)
+            rl = {"note": "reference loop body unchanged: torch-op L1 loss + torch.optim.Adam(lr=5e-6, weight_decay=3e-6) (default "
+                          "foreach implementation), DropPath on, dropped branches handed ZERO gradients (ops default 'zeros')"}
+            for key, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+                model.set_compute_dtype(dt)
+                opt_ref = torch.optim.Adam(model.parameters(), lr=5e-6, weight_decay=3e-6)
+                torch.manual_seed(4321 + rank)
+
+                def ref_step():
+                    opt_ref.zero_grad()
+                    model.train()
+                    o, o_s = model(inp, inp_s, stats, maps, const_h)
+                    loss = train._weighted_l1_loss_torch(o, o_s, tgt, tgt_s)
+                    loss.backward()
+                    opt_ref.step()
+                    return loss
+                for _ in range(2):
+                    ref_step()
+                lsync()
+                t1 = time.perf_counter()
+                for _ in range(n_x):
+                    loss = ref_step()
+                lsync()
+                rl[key] = (time.perf_counter() - t1) / n_x * 1e3
+                rl[key + "_loss"] = float(loss.detach())
+                del opt_ref, loss
+                model.zero_grad(set_to_none=True)
+            extras["reference_loop_step_ms"] = rl
+        except Exception as e:      # secondary metrics must never take the headline line down
+            extras["error"] = repr(e)[:300]
+        model.set_compute_dtype(torch.float32)
+        model.eval()
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -410,12 +542,16 @@ def main():
         if bf16_res is not None:
             res["bf16_forward"] = bf16_res
         res.update(train_res)
+        if extras:
+            res.update(extras)
         # the metric's second half ("DDP samples/sec at 1/2/4/8") as TOP-LEVEL keys: measured in this very run by all `world` ranks
         # (fwd + bwd + the bucketed gradient all-reduce issued from the backward hooks + Adam; max-over-ranks step time)
         dd = {"unit": "samples/s", "measured": True, "ranks": world,
               "rccl_ranks": world if (dist is not None and backend == "nccl") else 0,
               "backend": (backend if dist is not None else None),
-              "collective": ("bucketed all_reduce(AVG) of the flat fp32 gradient buffer, overlapped with backward" if dist is not None
+              "collective": ((("bucketed all_reduce(AVG)" if args.grad_sync == "all_reduce" else
+                               "bucketed reduce_scatter(AVG) + all_gather, in place,") +
+                              " of the flat fp32 gradient buffer, overlapped with backward") if dist is not None
                              else "none (one rank: no process group)")}
         for tag, key in (("ddp_train", "fp32"), ("ddp_train_bf16", "bf16")):
             tr_ = train_res.get(tag)

@@ -233,6 +233,14 @@ int pangu_window_attn_qkv_fwd_bf16(pangu_stream_t stream, const void* x, int ldx
                                    const void* esb, void* out, float* lse, int Z, int H, int W, int C, int heads,
                                    int shifted);
 
+/* The same operator (same arguments, same result) in its LONGITUDE-WALKING form: one persistent workgroup per (window type,
+ * head) keeps that head's 96 linear1 rows in LDS (and, variant % 10 == 1, the wave's Earth-specific bias rows in registers) and
+ * walks the nLon longitude windows that share them (reference layers.py:306-311: one bias per (type, head), broadcast over
+ * longitude, :395).  variant = 10 * pipelines + bias_mode: 40, 30, 20 (bias rows re-read from L2 per window), 21, 11 (resident). */
+int pangu_window_attn_qkv_walk_fwd_bf16(pangu_stream_t stream, const void* x, int ldx, const void* w_qkv, const float* b_qkv,
+                                        const void* esb, void* out, float* lse, int Z, int H, int W, int C, int heads,
+                                        int shifted, int variant);
+
 int pangu_ln_residual_fwd_bf16(pangu_stream_t stream, const void* y, const void* shortcut, int lds, const float* gamma,
                                const float* beta, void* out, int ldo, int N, int C, float branch_scale);
 /* Projection + post-norm residual in one launch (inference path of layers.py:250-251):

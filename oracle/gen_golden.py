@@ -1,6 +1,6 @@
 """Generate golden vectors by running the REFERENCE itself (build container only; needs /root/reference).
 
-TEST INFRASTRUCTURE. Usage:  python oracle/gen_golden.py [index] [blocks] [layers] [model] [model_bwd] [model_bwd_smooth] [extras] [rollout2] [keys_table] [refinit] [attn_windows]
+TEST INFRASTRUCTURE. Usage:  python oracle/gen_golden.py [index] [blocks] [layers] [model] [model_bwd] [model_bwd_smooth] [extras] [rollout2] [rollout7] [keys_table] [refinit] [attn_windows]
 Outputs small fixtures (fingerprints: samples + sums, index tensors, packed masks) under tests/golden/.
 Inputs and parameters are closed-form (oracle/synth.py), so tests regenerate them bit-identically.
 """
@@ -286,7 +286,7 @@ def stats_last_of(stats):
     return s_mean.view(1, 4, 1, 1), s_std.view(1, 4, 1, 1), rev(u_mean), rev(u_std)
 
 
-def gen_rollout(L, M, steps=2):
+def gen_rollout(L, M, steps=2, name="rollout2.npz"):
     """`steps` chained REFERENCE forwards: the loop of inference/inference_singleOutput.py:97-105 (output of one 24 h
     step = input of the next) with the torch model's normalised outputs taken back to physical units by normBackData
     (era5_data/utils_data.py:324-330; era5_data cannot be imported here, its 2-line body is restated)."""
@@ -306,7 +306,7 @@ def gen_rollout(L, M, steps=2):
         sf = out_s * s_std + s_mean                  # :328
     d.update(cases.summarize(up, "rollout.final_upper"))
     d.update(cases.summarize(sf, "rollout.final_surface"))
-    save("rollout2.npz", d)
+    save(name, d)
 
 
 def gen_keys_table(L, M):
@@ -373,6 +373,8 @@ if __name__ == "__main__":
         gen_keys_table(L, M)
     if "rollout2" in what:
         gen_rollout(L, M, steps=2)
+    if "rollout7" in what:      # BASELINE configs[4]: all seven 24 h steps of the week-long rollout, fingerprints per step
+        gen_rollout(L, M, steps=7, name="rollout7.npz")
     if "refinit" in what:
         gen_refinit(L, M)
     if "attn_windows" in what:

@@ -237,6 +237,9 @@ class PatchRecoverFnBF16(torch.autograd.Function):
         sg = ctx.skip_grad
         if sg is not None and sg[1] and ctx.needs_input_grad[0]:
             sg[0], d_skip = d_skip, None          # the down-sampling backward adds it in its own pass (DownSampleFnBF16)
+            # (if autograd pruned that node -- `torch.autograd.grad(loss, inputs=[layer-3 parameters])` -- nothing consumes the
+            # slot: it is emptied when this backward pass ends instead of pinning 200-400 MB until the next forward)
+            torch.autograd.Variable._execution_engine.queue_callback(lambda sg=sg: sg.__setitem__(0, None))
         return d_skip, d_x, dcw.reshape(cw.shape), dcb, dsw.reshape(sw.shape), dsb, None, None, None
 
 

@@ -79,9 +79,17 @@ class FlatGradSync:
     usage:   sync = FlatGradSync(model);   loss.backward();   sync.finish();   optimizer.step()
     """
 
-    def __init__(self, model, process_group=None, buckets=None, average=True, force_collective=False):
+    def __init__(self, model, process_group=None, buckets=None, average=True, force_collective=False, mode="all_reduce"):
+        """mode: "all_reduce" (default: one all_reduce(AVG) per bucket) or "reduce_scatter" (per bucket a reduce_scatter(AVG) into
+        this rank's 1/world shard followed by an all_gather of the shards, both in place in the flat buffer: on the fully connected
+        xGMI mesh every peer link carries 1/world of the bucket in each phase -- SURVEY section 5 -- instead of a ring's whole
+        bucket over one link; same result, selectable so the first multi-GPU run can A/B the two)."""
+        if mode not in ("all_reduce", "reduce_scatter"):
+            raise ValueError("FlatGradSync mode: 'all_reduce' or 'reduce_scatter'")
+        self.mode = mode
         self.group = process_group
         self.world = tdist.get_world_size(process_group) if tdist.is_initialized() else 1
+        self.rank = tdist.get_rank(process_group) if tdist.is_initialized() else 0
         self.average = average
         self.force = force_collective      # issue the collectives on a 1-rank group too (exercises the RCCL path)
         params = [p for p in model.parameters() if p.requires_grad]
@@ -90,9 +98,13 @@ class FlatGradSync:
         buckets = [b for b in buckets if b]
         assert sum(len(b) for b in buckets) == len(params), "buckets must cover every trainable parameter once"
         dev, dtype = params[0].device, params[0].dtype
-        total = sum(p.numel() for p in params)
+        # every bucket's length is a multiple of 4 * world elements (zero padding at its end): 16-B aligned bucket starts and, in
+        # "reduce_scatter" mode, equal 16-B aligned shards per rank
+        quantum = 4 * max(self.world, 1)
+        padded = lambda n: (n + quantum - 1) // quantum * quantum
+        total = sum(padded(sum(p.numel() for p in b)) for b in buckets)
         self.flat = torch.zeros(total, dtype=dtype, device=dev)
-        self.buckets = []          # (start, end, [(param, view)])
+        self.buckets = []          # (start, end incl. padding, [(param, view)])
         off = 0
         self._slot = {}
         for bi, b in enumerate(buckets):
@@ -103,6 +115,7 @@ class FlatGradSync:
                 views.append((p, v))
                 self._slot[p] = (bi, v)
                 off += p.numel()
+            off = start + padded(off - start)
             self.buckets.append((start, off, views))
         self._pending = [len(b[2]) for b in self.buckets]
         self._fired = set()
@@ -116,7 +129,9 @@ class FlatGradSync:
         if self._cuda:
             from . import ops
             self._ops = ops
-            ops.register_grad_slots({p: v for p, (_, v) in self._slot.items() if p.dim() == 5}, owner=self)
+            # (5-D: the bias tables the attention backward writes whole; the other matrices' slots are there for the explicit
+            # zeros of a DropPath-dropped branch, ops.fill_dropped_grads: zeroed in place instead of a zeros tensor + a copy)
+            ops.register_grad_slots({p: v for p, (_, v) in self._slot.items() if p.dim() >= 2}, owner=self)
         self.copied_bytes = 0      # bytes moved by the copy fallback since construction (diagnostic)
 
     # -- per-parameter hook: move the fresh gradient into its flat slot; launch every bucket that became complete
@@ -142,6 +157,20 @@ class FlatGradSync:
             return
         start, end, _ = self.buckets[bi]
         chunk = self.flat[start:end]
+        if self.mode == "reduce_scatter":
+            n = (end - start) // self.world
+            shard = chunk[self.rank * n:(self.rank + 1) * n]
+            if self._gloo:      # gloo runs async works on a thread pool, not in issue order: the two phases synchronously (tests only)
+                tdist.reduce_scatter_tensor(shard, chunk, op=tdist.ReduceOp.SUM, group=self.group)
+                if self.average:
+                    shard.div_(self.world)
+                tdist.all_gather_into_tensor(chunk, shard, group=self.group)
+                return
+            op = tdist.ReduceOp.AVG if self.average else tdist.ReduceOp.SUM
+            # RCCL executes a communicator's collectives in issue order on its own stream: the gather follows the scatter
+            self._works.append((tdist.reduce_scatter_tensor(shard, chunk, op=op, group=self.group, async_op=True), None))
+            self._works.append((tdist.all_gather_into_tensor(chunk, shard, group=self.group, async_op=True), None))
+            return
         if self.average and not self._gloo:
             self._works.append((tdist.all_reduce(chunk, op=tdist.ReduceOp.AVG, group=self.group, async_op=True), None))
         else:   # gloo has no AVG: SUM then divide (exactly gather_grad's arithmetic)

@@ -30,14 +30,21 @@ class DropPath(nn.Module):
         super().__init__()
         self.drop_prob = float(drop_prob)
         self.n_dropped = 0           # branches dropped so far (diagnostic)
+        self.n_dropped_branch = [0, 0]      # ... split by branch: [attention (layers.py:250), MLP (:251)]; bench.py prices the
+                                            # work a training step really executed with these
+        self._calls = 0
 
     def sample_scale(self, training):
+        """The per-sample factor of the next residual branch; a block draws twice per sample, attention branch first."""
+        which = self._calls & 1
+        self._calls += 1
         if not training or self.drop_prob == 0.0:
             return 1.0
         keep = 1.0 - self.drop_prob
         if torch.rand(()).item() < keep:
             return 1.0 / keep
         self.n_dropped += 1
+        self.n_dropped_branch[which] += 1
         return 0.0
 
     def extra_repr(self):
@@ -59,14 +66,15 @@ def assert_plain_tree(root, what):
                         PatchEmbedding_pretrain, Mlp, EarthAttention3D, EarthSpecificBlock, EarthSpecificLayer, DownSample, UpSample,
                         PatchRecovery_pretrain})
     for m in root.modules():
-        if (m._forward_hooks or m._forward_pre_hooks or type(m) not in allowed) and m is not root:
+        if m is not root and (m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks
+                              or type(m) not in allowed):
             break
     else:
         return
     name = next(n for n, q in root.named_modules() if q is m)
     if type(m) in allowed:
-        raise RuntimeError(f"{what} (MI355X build): sub-module '{name}' carries forward hooks, but its forward is never called "
-                           "(the HIP kernels read the parameters directly): the hook would be ignored")
+        raise RuntimeError(f"{what} (MI355X build): sub-module '{name}' carries forward hooks or backward hooks, but its forward is "
+                           "never called (the HIP kernels read the parameters directly): the hook would be ignored")
     raise RuntimeError(f"{what} (MI355X build): sub-module '{name}' is {type(m).__module__}.{type(m).__name__}, not the plain "
                        "module the kernels read their parameters from; a wrapper's own arithmetic (LoRA adapters, "
                        "parametrizations) would be bypassed and e.g. train nothing")
@@ -96,6 +104,10 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(dropout_rate)
 
     def forward(self, x):
+        assert_plain_tree(self, "Mlp")
+        if self.drop.p > 0.0 and self.training:
+            raise RuntimeError("Mlp (MI355X build): dropout_rate > 0 in train() mode is not implemented by the kernels (the "
+                               "reference's model builds every Mlp with rate 0, layers.py:143)")
         shp = x.shape
         return fused.mlp(self, x.reshape(-1, shp[-1])).reshape(shp)
 
@@ -109,6 +121,7 @@ class EarthAttention3D(nn.Module):
         self.device = device
         self.linear1 = nn.Linear(dim, dim * 3, bias=True)
         self.linear2 = nn.Linear(dim, dim)
+        self.dropout_rate = float(dropout_rate)                # reference layers.py:284 (nn.Dropout; the model passes 0)
         self.head_number = heads
         self.dim = dim
         self.scale = (dim // heads) ** -0.5
@@ -129,6 +142,10 @@ class EarthAttention3D(nn.Module):
         reference's module (autograd.AttentionWindowsFn)."""
         from . import ops
         from .autograd import AttentionWindowsFn
+        assert_plain_tree(self, "EarthAttention3D")
+        if getattr(self, "dropout_rate", 0.0) > 0.0 and self.training:
+            raise RuntimeError("EarthAttention3D (MI355X build): dropout_rate > 0 in train() mode is not implemented by the kernels "
+                               "(the reference's model builds every attention with rate 0, layers.py:144)")
         if x.dim() != 4 or x.shape[1] != self.type_of_windows or x.shape[2] != 144 or x.shape[3] != self.dim:
             raise RuntimeError(f"EarthAttention3D: expected (nLon, {self.type_of_windows}, 144, {self.dim}) windows, got {tuple(x.shape)}")
         if not x.is_cuda:

@@ -97,11 +97,15 @@ def _rows(t, name):
     return t.data_ptr(), t.stride(0)
 
 
-# What a block's backward returns for the parameters of a DropPath-dropped branch (the branch is not computed here; in the
-# reference it is computed and multiplied by zero, layers.py:250-251, so autograd hands the optimizer ZERO gradients there):
-# "none" (default: train.train_step / HipAdam.step(missing_as_zero=True) give those parameters the zero-gradient step without
-# materialising zeros) or "zeros" (explicit zero tensors: exact reference semantics under ANY optimizer / foreign training loop).
-_dropped_grads = "none"
+# What a block's backward returns for the parameters of a DropPath-dropped branch.  The branch is not computed here; in the
+# reference it is computed and multiplied by zero (layers.py:250-251), so autograd hands the optimizer ZERO gradients there and
+# e.g. `torch.optim.Adam` still steps those parameters (weight decay, moment decay, `step` advanced).
+#   "zeros" (DEFAULT since round 5: the reference's semantics under ANY optimizer / training loop -- the drop-in contract of
+#           models/pangu_sample.py:45-77 is "unchanged"): explicit zero tensors (the 62-MB bias table's zeros are written
+#           straight into its flat data-parallel slot when there is one),
+#   "none"  what train.train_step selects around its own backward: it gives those parameters the zero-gradient step itself
+#           (HipAdam.step(missing_as_zero=True), dist.FlatGradSync) without materialising zeros.
+_dropped_grads = "zeros"
 
 
 def set_dropped_branch_grads(mode):
@@ -111,12 +115,37 @@ def set_dropped_branch_grads(mode):
     _dropped_grads = mode
 
 
+class dropped_branch_grads:
+    """`with ops.dropped_branch_grads("none"): loss.backward()` -- the policy for the backward passes run inside the context
+    (process-wide, like the setter; backward runs on autograd's threads, so a thread-local would not reach it)."""
+
+    def __init__(self, mode):
+        if mode not in ("none", "zeros"):
+            raise ValueError("dropped_branch_grads: 'none' or 'zeros'")
+        self.mode = mode
+
+    def __enter__(self):
+        global _dropped_grads
+        self.prev, _dropped_grads = _dropped_grads, self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global _dropped_grads
+        _dropped_grads = self.prev
+
+
 def fill_dropped_grads(g, like):
     """g: name -> gradient or None; like: name -> parameter of that shape.  Under the "zeros" policy every None becomes zeros."""
     if _dropped_grads == "zeros":
         for k, p in like.items():
             if g.get(k) is None:
-                g[k] = torch.zeros_like(p)
+                # matrices (`like` holds the parameter itself for every >= 2-D entry; vectors are shape stand-ins): with a
+                # dist.FlatGradSync registered, zero the parameter's flat-buffer slot in place (no zeros tensor, no copy pass)
+                slot = grad_slot(p) if p.dim() >= 2 else None
+                if slot is not None:
+                    g[k] = slot.zero_().view(p.shape)
+                else:
+                    g[k] = torch.zeros_like(p)
     return g
 
 
@@ -208,12 +237,26 @@ def grad_slot(param):
 
 _PASS_ARENA_NUMEL = 28 << 20      # fp32 elements: every atomically accumulated gradient buffer of one backward pass of the
                                   # model (16 blocks x (12 C^2 + 16 C) + the resampling / embedding / recovery weights = 24 M) fits
-_pass_arena = None                # [flat fp32 zeros, used elements] while a backward pass is running
+# One arena per (device, autograd thread): autograd runs one worker thread per device, so two models on two GPUs driven from one
+# process run their backward passes concurrently and must not see each other's arena (the single global then thrashed,
+# a fresh 112-MB fill per buffer).  Every arena carries the id of the backward pass (autograd graph task) it was made in: an
+# arena left armed by a backward that RAISED (its release callback never ran) is never handed to a later pass -- in particular
+# not to a GraphedTrainStep capture, whose graph would otherwise accumulate onto a buffer zeroed outside the capture.
+_pass_arenas = {}                 # (device index, thread id) -> [flat fp32 zeros, used elements, graph task id]
 
 
-def _release_pass_arena():
-    global _pass_arena
-    _pass_arena = None
+def _release_pass_arena(key):
+    _pass_arenas.pop(key, None)
+
+
+def reset_pass_arenas():
+    """Drop every arena (train.GraphedTrainStep calls this before capturing; harmless at any time outside a backward pass)."""
+    _pass_arenas.clear()
+
+
+def _graph_task_id():
+    f = getattr(torch._C, "_current_graph_task_id", None)
+    return f() if f is not None else -1
 
 
 def _zeros(shape, device):
@@ -221,20 +264,25 @@ def _zeros(shape, device):
     an autograd backward pass they are 16-B aligned slices of ONE buffer zeroed by ONE fill at its first use (112 MB: ~25 us)
     and dropped by an end-of-backward callback -- the per-buffer fills were 27 launches per training step (round 3: one per
     block).  Outside a backward pass (direct op calls, tests) a plain torch.zeros."""
-    global _pass_arena
+    import functools
+    import threading
     n = 1
     for d in shape:
         n *= int(d)
     dev = torch.device(device)
-    a = _pass_arena
-    if a is None or a[0].device != dev or a[1] + n > a[0].numel():
-        if n > _PASS_ARENA_NUMEL // 4:
-            return torch.zeros(shape, dtype=torch.float32, device=dev)
+    if dev.index is None and dev.type == "cuda":
+        dev = torch.device("cuda", torch.cuda.current_device())
+    task = _graph_task_id()
+    if task < 0 or n > _PASS_ARENA_NUMEL // 4:      # not inside a backward pass / too large for the arena
+        return torch.zeros(shape, dtype=torch.float32, device=dev)
+    key = (dev.index, threading.get_ident())
+    a = _pass_arenas.get(key)
+    if a is None or a[2] != task or a[0].device != dev or a[1] + n > a[0].numel():
         try:
-            torch.autograd.Variable._execution_engine.queue_callback(_release_pass_arena)
+            torch.autograd.Variable._execution_engine.queue_callback(functools.partial(_release_pass_arena, key))
         except RuntimeError:      # not inside a backward pass
             return torch.zeros(shape, dtype=torch.float32, device=dev)
-        a = _pass_arena = [torch.zeros((_PASS_ARENA_NUMEL,), dtype=torch.float32, device=dev), 0]
+        a = _pass_arenas[key] = [torch.zeros((_PASS_ARENA_NUMEL,), dtype=torch.float32, device=dev), 0, task]
     t = a[0][a[1]:a[1] + n].view(shape)
     a[1] += (n + 3) & ~3
     return t
@@ -325,6 +373,14 @@ def linear_ln_residual(a, weight, bias, shortcut, gamma, beta, out=None, branch_
 
 _WGRAD_WS_BYTES = 96 << 20
 _wgrad_ws = {}      # (device, stream) -> fp32 scratch buffer of the two-stage weight-gradient reduction (shared with ops_bf16)
+
+
+def release_stream_workspaces(stream=None):
+    """Drop the scratch buffers keyed by `stream` (a torch.cuda.Stream about to go away: its handle may be recycled), or all of
+    them (stream=None; the next launch on a stream allocates its buffer again).  train.GraphedTrainStep calls this around its
+    capture: a buffer allocated while capturing lives in THAT graph's memory pool and must not be handed to anything else."""
+    for key in [k for k in _wgrad_ws if stream is None or k[1] == stream.cuda_stream]:
+        del _wgrad_ws[key]
 
 
 def wgrad_workspace(device):

@@ -255,9 +255,16 @@ class GraphedTrainStep:
                     self._fwd_bwd()
             torch.cuda.current_stream().wait_stream(side)
             optimizer.zero_grad(set_to_none=True)      # the gradients are (re-)allocated INSIDE the capture: static addresses
+            from . import ops
+            ops.reset_pass_arenas()                    # never a zero buffer filled outside the capture (e.g. left by a failed backward)
+            ops.release_stream_workspaces()            # the capture allocates its own weight-gradient scratch, inside its own pool
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.loss = self._fwd_bwd()
+            ops.release_stream_workspaces()            # ... which stays this graph's: nothing else may be handed a pointer into the pool
+        # the graph writes THESE gradient tensors; `optimizer.zero_grad(set_to_none=True)` between replays (the usual loop idiom)
+        # detaches them from the parameters, and HipAdam would then skip every parameter silently: step() re-attaches them
+        self._grads = [(p, p.grad) for group in optimizer.param_groups for p in group["params"] if p.grad is not None]
 
     def _fwd_bwd(self):
         inp, inp_s, tgt, tgt_s = self.batch
@@ -275,6 +282,9 @@ class GraphedTrainStep:
             for dst, src in zip(self.batch, batch):
                 dst.copy_(src)
         self.graph.replay()
+        for p, g in self._grads:            # (see __init__: a zero_grad(set_to_none=True) in the caller's loop detached them)
+            if p.grad is not g:
+                p.grad = g
         self.optimizer.step()
         sh = getattr(self.model, "_shadow", None)
         if sh is not None and sh.cache:
@@ -292,7 +302,11 @@ def train_step(model, optimizer, batch, statistics, maps, const_h, stats_last=No
     if stats_last is not None:
         tgt, tgt_s = norm_data(tgt, tgt_s, stats_last)
     loss = weighted_l1_loss(out, out_s, tgt, tgt_s)
-    loss.backward()
+    from . import ops
+    # the three arms below hand the parameters of a DropPath-dropped branch their zero-gradient step themselves: the backward need
+    # not materialise the zeros (ops.dropped_branch_grads: "zeros" is the default for any OTHER loop, the reference's semantics)
+    with ops.dropped_branch_grads("none"):
+        loss.backward()
     if grad_sync is not None:
         grad_sync()
         optimizer.step()

@@ -1,5 +1,5 @@
 """Worker of tests/test_gpu_dp2.py: one rank of an N-rank data-parallel training step of the REAL model on one GPU
-(gloo backend, all ranks share cuda:0).  Usage: torchrun --nproc-per-node N dp2_worker.py <out_dir> <dtype>"""
+(gloo backend, all ranks share cuda:0).  Usage: torchrun --nproc-per-node N dp2_worker.py <out_dir> <dtype> [all_reduce|reduce_scatter]"""
 import os
 import sys
 
@@ -42,7 +42,7 @@ def main():
     model = P.PanguModel(device="cuda").cuda().train()            # train(): DropPath ON (rates up to 0.2)
     model.load_state_dict(synth.fill_state_dict(cases.model_param_shapes(), "cuda"))
     model.set_compute_dtype(dtype)
-    sync = D.FlatGradSync(model)
+    sync = D.FlatGradSync(model, mode=sys.argv[3] if len(sys.argv) > 3 else "all_reduce")
     launches = []                       # bucket indices in the order this rank issued their collectives
     launch = sync._launch
     sync._launch = lambda bi: (launches.append(bi), launch(bi))[1]
@@ -56,7 +56,8 @@ def main():
     info = {"copied_bytes": sync.copied_bytes, "flat_bytes": total, "launched_in_backward": sync.launched_in_backward,
             "buckets": len(sync.buckets), "dropped_branches": dropped, "pattern": pattern,
             "order": [names[id(b[2][0][0])] for b in sync.buckets][:3], "launches": launches, "world": world,
-            "peak_gb": torch.cuda.max_memory_allocated() / 2**30}
+            "peak_gb": torch.cuda.max_memory_allocated() / 2**30, "mode": sync.mode,
+            "offsets": {names[id(p)]: sync._slot[p][1].storage_offset() for p in model.parameters()}}      # (buckets are padded)
     torch.save(info, os.path.join(out_dir, f"dp_info_r{rank}.pt"))
     if rank == 0:
         torch.save({"flat": sync.flat.cpu(), "info": info}, os.path.join(out_dir, "dp2.pt"))

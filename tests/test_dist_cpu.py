@@ -57,7 +57,7 @@ class _Tiny(torch.nn.Module):
         return self._output_layer(x)
 
 
-def _worker(rank, world, port, drop_on_rank1, q):
+def _worker(rank, world, port, drop_on_rank1, q, mode="all_reduce"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import pangu_pytorch_amd as P
@@ -66,7 +66,7 @@ def _worker(rank, world, port, drop_on_rank1, q):
     assert D.get_dist_info() == (rank, world)
     torch.manual_seed(0)
     model = _Tiny()
-    sync = D.FlatGradSync(model)
+    sync = D.FlatGradSync(model, mode=mode)
     assert len(sync.buckets) == 5           # output, L1.B0, L0.B1, L0.B0, input  (reverse execution order)
     xs = torch.randn(world, 5, 6, generator=torch.Generator().manual_seed(1))
     for step in range(2):                   # second step exercises grads-as-views accumulation
@@ -92,12 +92,14 @@ def _worker(rank, world, port, drop_on_rank1, q):
     torch.distributed.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode", ["all_reduce", "reduce_scatter"])
 @pytest.mark.parametrize("drop", [False, True])
-def test_flat_grad_sync_matches_single_process_mean(drop):
+def test_flat_grad_sync_matches_single_process_mean(drop, mode):
+    """Both collectives of FlatGradSync (bucketed all_reduce; reduce_scatter + all_gather in place)."""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, drop, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, drop, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     got = {k: torch.from_numpy(v) for k, v in q.get(timeout=120).items()}

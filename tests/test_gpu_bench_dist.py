@@ -41,3 +41,41 @@ def test_bench_two_ranks_emits_ddp_keys():
     assert d["ddp_model"]["measured"] is False
     assert all(v["measured"] is False for v in d["ddp_model"]["allreduce_ms"].values())
     assert d["ddp_train"]["value"] == dd["fp32"]["value"]
+
+
+def test_bench_gpus2_plain_invocation_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (the way the driver invokes the N = 1 line): the
+    parent -- which never touches the GPU -- starts the two ranks under torch.distributed.run as a child process and relays rank
+    0's JSON line and return code.  gloo + one GPU here; on an N-GPU node the same command runs N RCCL ranks."""
+    assert torch.cuda.is_available()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PANGU_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--train-steps", "1",
+           "--no-bf16", "--no-cpu-baseline", "--no-extras", "--grad-sync", "reduce_scatter"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["config"]["parallelism"] == "dp2"
+    dd = d["ddp_samples_per_s"]
+    assert dd["measured"] is True and dd["ranks"] == 2 and "reduce_scatter" in dd["collective"]
+    for key in ("fp32", "bf16"):
+        assert "error" not in dd[key] and dd[key]["value"] > 0, dd[key]
+    # the training roofline prices EXECUTED work (DropPath-dropped branches are not counted) and carries a DropPath-off step
+    for tag in ("ddp_train", "ddp_train_bf16"):
+        rf = d[tag]["roofline"]
+        assert rf["executed_flop_per_step"] <= rf["droppath_off"]["flop_per_step"]
+        assert rf["executed_flop_per_step"] + rf["droppath_skipped_flop_per_step"] == pytest.approx(rf["droppath_off"]["flop_per_step"], rel=1e-9)
+        assert rf["droppath_off"]["ms_per_step"] > 0
+
+
+def test_bench_failure_of_the_child_is_relayed():
+    """The self-launching parent returns the child's failure (an impossible backend here) instead of a fake line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PANGU_DIST_BACKEND="no_such_backend")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-train", "--no-bf16",
+           "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

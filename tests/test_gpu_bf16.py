@@ -266,6 +266,39 @@ def test_window_attention_qkv_fused_bf16(P, C, shifted):
     assert rel_err(got, two) < ROUND
 
 
+@pytest.mark.parametrize("variant", [40, 30, 20, 21, 11])
+@pytest.mark.parametrize("C", [192, 384])
+@pytest.mark.parametrize("shifted", [False, True])
+def test_window_attention_qkv_walk_bf16(P, C, shifted, variant):
+    """The longitude-walking form of the fused QKV attention (csrc/attn_walk_bf16.hip: one persistent workgroup per (window type,
+    head), linear1's rows resident in LDS, `variant // 10` window pipelines of three waves, variant % 10 == 1: bias rows resident
+    in registers -- reference layers.py:306-311,395: one bias per (type, head), broadcast over longitude) on SEVEN longitude
+    windows (every pipeline walks more than one window and they take unequal shares) == the oracle on the same bf16-rounded
+    operands, and == the (window, head) kernel bit for bit on the attention output (same tile code, same operand values)."""
+    from pangu_pytorch_amd import ops_bf16 as ob
+    st = cases.STAGES[C]
+    Z, H, W, heads = st["Z"], st["H"], 84, st["heads"]
+    N = Z * H * W
+    x = synth.uniform((N, C), 35, 1.5).to(BF)
+    w = synth.uniform((3 * C, C), 36, 1.5 / C ** 0.5).to(BF)
+    b = synth.uniform((3 * C,), 37, 0.5)
+    esb = synth.uniform((1, st["types"], heads, 144, 144), 38, 0.5).to(BF)
+    base, base_lse = ob.window_attention_qkv(x.cuda(), w.cuda(), b.cuda(), esb[0].cuda(), Z, H, W, heads, shifted, want_lse=True, variant=0)
+    got, lse = ob.window_attention_qkv(x.cuda(), w.cuda(), b.cuda(), esb[0].cuda(), Z, H, W, heads, shifted, want_lse=True, variant=variant)
+    torch.cuda.synchronize()
+    # q, k, v: the same MFMA chain over the same 32-channel steps, bias added after the chain instead of as its initial value
+    # (one fp32 rounding apart before the bf16 rounding of q / k / v): bf16-rounding-level agreement with the other kernel
+    assert rel_err(got, base) < ROUND and rel_err(lse, base_lse) < 2e-3
+    if variant in (40, 21):      # and against the oracle (the pad rows' q/k/v from the bf16-rounded bias, layers.py:192)
+        qkv = (x.double() @ w.double().t() + b.double()).to(BF)
+        ref, ref_lse = O.window_attention_core(qkv.float()[None], b.to(BF).float(), esb.float(), Z, H, W, heads, shifted)
+        assert rel_err(got, ref[0]) < ROUND
+        assert rel_err(lse, ref_lse[0]) < 2e-3
+    # every launch of the same inputs gives the same bits (the pipelines' rendezvous orders all LDS traffic)
+    again, _ = ob.window_attention_qkv(x.cuda(), w.cuda(), b.cuda(), esb[0].cuda(), Z, H, W, heads, shifted, want_lse=True, variant=variant)
+    assert torch.equal(again, got)
+
+
 @pytest.mark.parametrize("C", [192, 384])
 def test_ln_residual_bf16(P, C):
     from pangu_pytorch_amd import ops_bf16 as ob

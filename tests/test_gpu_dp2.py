@@ -22,12 +22,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("dtype,world", [("f32", 2), ("bf16", 2), ("bf16", 4)])
-def test_n_rank_train_step_matches_single_process_mean(tmp_path, dtype, world):
-    """world 4: four ranks of the bf16 model on one GPU (4 x 37 GB), DropPath on."""
+@pytest.mark.parametrize("dtype,world,mode", [("f32", 2, "all_reduce"), ("bf16", 2, "all_reduce"), ("bf16", 4, "all_reduce"),
+                                              ("bf16", 2, "reduce_scatter"), ("bf16", 4, "reduce_scatter")])
+def test_n_rank_train_step_matches_single_process_mean(tmp_path, dtype, world, mode):
+    """world 4: four ranks of the bf16 model on one GPU (4 x 37 GB), DropPath on.  mode:
+    FlatGradSync's bucketed all_reduce, or reduce_scatter + all_gather per bucket in place."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "helpers", "dp2_worker.py"), str(tmp_path), dtype]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "helpers", "dp2_worker.py"), str(tmp_path), dtype, mode]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     got = torch.load(os.path.join(tmp_path, "dp2.pt"))
@@ -53,22 +55,23 @@ def test_n_rank_train_step_matches_single_process_mean(tmp_path, dtype, world):
     assert all(i["launches"] == list(range(20)) and i["launched_in_backward"] == 20 for i in per_rank), \
         [(i["launches"], i["launched_in_backward"]) for i in per_rank]
     assert len({tuple(map(tuple, i["pattern"])) for i in per_rank}) > 1      # the ranks did draw different DropPath patterns
+    assert info["mode"] == mode
+    names = {id(p): n for n, p in model.named_parameters()}
+    offs = info["offsets"]                      # parameter name -> offset in the flat buffer (bucket ends are zero-padded)
     mean = torch.zeros_like(flat)
     for rank in range(world):
         model.zero_grad(set_to_none=True)
         W.one_backward(model, rank)
-        off = 0
         for p in order:
+            off = offs[names[id(p)]]
             g = p.grad.float().flatten().cpu() if p.grad is not None else torch.zeros(p.numel())
             mean[off:off + p.numel()] += g / world
-            off += p.numel()
     # identical kernels on both sides; the weight-gradient kernels accumulate with fp32 atomics (order-dependent last bits)
-    names = {id(p): n for n, p in model.named_parameters()}
-    off, worst = 0, []
+    worst = []
     for p in order:
+        off = offs[names[id(p)]]
         d = (flat[off:off + p.numel()] - mean[off:off + p.numel()]).abs().max().item()
         worst.append((d, names[id(p)], mean[off:off + p.numel()].abs().max().item(), flat[off:off + p.numel()].abs().max().item()))
-        off += p.numel()
     worst.sort(reverse=True)
     print("dp2 worst parameters (abs err, name, max |mean|, max |flat|):", worst[:4])
     err = (flat - mean).abs().max().item() / mean.abs().max().item()
@@ -120,7 +123,7 @@ def test_flat_grad_sync_batch2_matches_per_sample_mean(dtype):
         train.weighted_l1_loss(out, out_s, cat(s0[2], s1[2]), cat(s0[3], s1[3])).backward()
         sync.finish()
         torch.cuda.synchronize()
-        got = sync.flat.cpu()
+        got = torch.cat([sync._slot[p][1].flatten() for p in order]).cpu()      # (bucket ends of the flat buffer are padded)
     finally:
         sync.remove()
     # per bias table (the slot-written tensors) and overall
