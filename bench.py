@@ -53,6 +53,9 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the reference-call-convention timings (grad-enabled eval forward, the reference's own loop body)")
     ap.add_argument("--train-steps", type=int, default=6)
+    ap.add_argument("--rehearse-collective", action="store_true",
+                    help="N = 1 only: time the training step again with a traffic generator standing in for the bucketed all-reduce "
+                         "(dist.FlatGradSync(rehearse=..): per bucket two device-to-device copies on a side stream, 32 workgroups)")
     ap.add_argument("--grad-sync", choices=("all_reduce", "reduce_scatter"), default="all_reduce",
                     help="the collective of dist.FlatGradSync (N > 1): bucketed all_reduce(AVG), or reduce_scatter + all_gather per bucket")
     return ap.parse_args()
@@ -415,6 +418,29 @@ def main():
                     "traffic_stale": pm_stale, "traffic_commit": pm_commit,
                     "traffic_unit": "HBM bytes per step = sum over all kernels of one step (FETCH_SIZE x2 + WRITE_SIZE; rocprofv3 --pmc "
                                     "passes of tools/profile_train.py, same DropPath seed as this loop -> profiles/pmc_train.json)"}
+                if args.rehearse_collective and sync is None:
+                    # the same step with a flat gradient buffer and, per bucket, a traffic generator on a side stream where the
+                    # RCCL all-reduce would run: how much the overlapped collective slows the backward kernels (an upper bound)
+                    reh = {}
+                    for name, kw in (("flat_buffer_no_traffic", None), ("traffic_32wg_x2", {"workgroups": 32, "passes": 2}),
+                                     ("traffic_64wg_x2", {"workgroups": 64, "passes": 2})):
+                        fs = FlatGradSync(model, rehearse=kw)
+                        torch.manual_seed(1234 + rank)
+                        for _ in range(2):
+                            train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=fs.finish)
+                        lsync()
+                        t3 = time.perf_counter()
+                        for _ in range(args.train_steps):
+                            train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=fs.finish)
+                        lsync()
+                        reh[name] = (time.perf_counter() - t3) / args.train_steps * 1e3
+                        fs.remove()
+                        model.zero_grad(set_to_none=True)
+                        del fs
+                    reh["note"] = ("ms per step, DropPath on, same seed; traffic = per bucket 2 x (read + write) of the bucket by a copy kernel "
+                                   "confined to N workgroups on a side stream, released when the bucket's last gradient exists; the "
+                                   "optimizer waits for it")
+                    train_res[tag]["allreduce_rehearsal_ms_per_step"] = reh
                 if sync:
                     train_res[tag]["exposed_allreduce_ms_per_step"] = sum(a.elapsed_time(b) for a, b in exposed) / max(len(exposed), 1)
                     train_res[tag]["grad_copy_fallback_mib"] = sync.copied_bytes / 2**20

@@ -145,6 +145,15 @@ int pangu_linear_ln_residual_fwd(pangu_stream_t stream, const float* A, int lda,
                                  const float* shortcut, int lds, const float* gamma, const float* beta, float* out, int ldo,
                                  int M, int N, int K, float branch_scale);
 
+/* The whole MLP branch of a block in ONE launch, fp32 inference (reference layers.py:251 with :264-270 inside):
+ *   out[M,C] = x[M,C] + branch_scale * (LayerNorm(GELU(x @ W1^T + b1) @ W2^T + b2) * gamma + beta)
+ * W1 [4C][C], b1 [4C], W2 [C][4C], b2 [C] in the reference's torch layouts (read in place: nothing is packed); x / out row strides
+ * ldx / ldo (multiples of 4); C = 192 (the stage-0 / stage-3 width).  The (M x 4C) hidden activation stays on chip.  Replaces pangu_linear_fwd
+ * (PANGU_ACT_GELU) + pangu_linear_ln_residual_fwd. */
+int pangu_mlp_ln_residual_fwd(pangu_stream_t stream, const float* x, int ldx, const float* w1, const float* b1, const float* w2,
+                              const float* b2, const float* gamma, const float* beta, float* out, int ldo, int M, int C,
+                              float branch_scale);
+
 /* Backward of the LayerNorm branch of pangu_ln_residual_fwd (the shortcut's gradient is dout itself):
  *   dy [N][C] overwritten;  dgamma[C], dbeta[C] ACCUMULATED (atomics).  dout may be row-strided (lddo). */
 int pangu_ln_residual_bwd(pangu_stream_t stream, const float* dout, int lddo, const float* y, const float* gamma,
@@ -340,6 +349,11 @@ int pangu_weighted_l1_loss_bwd(pangu_stream_t stream, const float* out, const fl
  *   at different step counts)   [7] first block (4096 elements per block); row n_jobs: sentinel, [7] = total_blocks. */
 int pangu_adam_step_multi(pangu_stream_t stream, const void* jobs, int n_jobs, long long total_blocks, double lr, double beta1,
                           double beta2, double weight_decay, double eps, float bias_correction1, float bias_correction2_sqrt);
+
+/* Rehearsal tool (not on the product path): copy `bytes` (multiple of 16, 16-B aligned pointers) device to device with a grid of
+ * exactly `workgroups` 256-thread workgroups -- the HBM traffic / CU footprint of a collective on its own stream, for measuring how
+ * much a bucketed gradient all-reduce (reference era5_data/utils_dist.py:125-134 semantics) slows the backward kernels it overlaps. */
+int pangu_traffic_copy(pangu_stream_t stream, const void* src, void* dst, long long bytes, int workgroups);
 
 #ifdef __cplusplus
 }

@@ -63,11 +63,13 @@ SIGNATURES = {
     "pangu_attn_windows_bwd": [_P, _P, _P, _P, _c.c_longlong, _P, _P, _P, _I, _I, _I, _I],
     "pangu_ln_residual_fwd": [_P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _F],
     "pangu_linear_ln_residual_fwd": [_P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _F],
+    "pangu_mlp_ln_residual_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F],
     "pangu_downsample_ln_fwd": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I],
     "pangu_upsample_ln_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I],
     "pangu_patch_embed_gather": [_P] * 11 + [_I, _I],
     "pangu_patch_recover_scatter": [_P, _P, _P, _P, _P, _I, _I],
     "pangu_patch_recover_scatter_denorm": [_P] * 11 + [_I, _I],
+    "pangu_traffic_copy": [_P, _P, _P, _c.c_longlong, _I],
 }
 _RESTYPES = {"pangu_error_string": _c.c_char_p, "pangu_weighted_l1_loss_blocks": _c.c_longlong}
 

@@ -73,7 +73,6 @@ __global__ __launch_bounds__(192 * G) void window_attn_qkv_walk_bf16_kernel(cons
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pipe = wave / 3, wg = wave - 3 * pipe;
-  const int lq = lane & 15, lg = lane >> 4;
   const u16* bias_tile = esb + (size_t)pair * PANGU_WTOK * PANGU_WTOK;
   unsigned char* const Ks = imgs + pipe * WALK_IMG;
   unsigned char* const Vt = Ks + PANGU_WTOK * 64;
@@ -99,7 +98,7 @@ __global__ __launch_bounds__(192 * G) void window_attn_qkv_walk_bf16_kernel(cons
   if (tid < G) ctrs[tid] = 0u;
 
   bool zcut = false, hcut = false;
-  unsigned long long kz_bits = 0ull, kh_bits = 0ull;
+  unsigned long long kz_bits_c = 0ull, kh_bits_c = 0ull;
   if (SHIFTED) {
     const int zwin = t / g.nHw, hwin = t - zwin * g.nHw;
     zcut = zwin == g.nZw - 1;
@@ -108,22 +107,32 @@ __global__ __launch_bounds__(192 * G) void window_attn_qkv_walk_bf16_kernel(cons
     for (int j = 0; j < 9; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int kn = key_of(j, lg * 4 + r);
-        if (kn >= 72) kz_bits |= 1ull << (4 * j + r);
-        if (((kn / 12) % 6) < 3) kh_bits |= 1ull << (4 * j + r);
+        const int kn = key_of(j, (lane >> 4) * 4 + r);
+        if (kn >= 72) kz_bits_c |= 1ull << (4 * j + r);
+        if (((kn / 12) % 6) < 3) kh_bits_c |= 1ull << (4 * j + r);
       }
   }
   const int tile0 = 3 * wg;
   BiasRow br[BIAS ? 3 : 1];
   if (BIAS) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) br[BIAS ? i : 0] = load_bias_row(bias_tile, (tile0 + i) * 16 + lq, lg);
+    for (int i = 0; i < 3; ++i) br[BIAS ? i : 0] = load_bias_row(bias_tile, (tile0 + i) * 16 + (lane & 15), lane >> 4);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   unsigned target = 0u;
+  const int lane_c = lane;
   for (int l = pipe; l < g.nLon; l += G) {
+    // Against the optimiser: everything below that depends only on the lane and the window TYPE is invariant over the walk (LDS
+    // fragment addresses, the 36 x 3 mask predicates of the shifted tiles as 64-bit lane masks, ..) and would be hoisted out of it
+    // into ~60 VGPRs + ~170 SGPRs that then spill; the lane id and the mask bits are made opaque once per window instead
+    int lane_w = lane_c;
+    asm volatile("" : "+v"(lane_w));
+    const int lq = lane_w & 15, lg = lane_w >> 4;
+    unsigned kz_lo = (unsigned)kz_bits_c, kz_hi = (unsigned)(kz_bits_c >> 32), kh_lo = (unsigned)kh_bits_c, kh_hi = (unsigned)(kh_bits_c >> 32);
+    asm volatile("" : "+v"(kz_lo), "+v"(kz_hi), "+v"(kh_lo), "+v"(kh_hi));
+    const unsigned long long kz_bits = ((unsigned long long)kz_hi << 32) | kz_lo, kh_bits = ((unsigned long long)kh_hi << 32) | kh_lo;
     // ---- the wave's 48 window rows: source tokens (closed form) and the byte offsets of their 16-B fragment pieces
     int qtok[3];
     unsigned xoff[3];
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(192 * G) void window_attn_qkv_walk_bf16_kernel(cons
     for (int rt = 0; rt < 6; ++rt)
 #pragma unroll
       for (int i = 0; i < 3; ++i) acc[rt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int PD = 2;                          // x fragments requested PD K-steps ahead of their MFMAs
+    constexpr int PD = G >= 3 ? 1 : 2;             // x fragments requested PD K-steps ahead of their MFMAs (168 registers at G >= 3)
     bf16x8 fx[PD + 1][3];
 #pragma unroll
     for (int ks = 0; ks < PD; ++ks)

@@ -79,7 +79,8 @@ class FlatGradSync:
     usage:   sync = FlatGradSync(model);   loss.backward();   sync.finish();   optimizer.step()
     """
 
-    def __init__(self, model, process_group=None, buckets=None, average=True, force_collective=False, mode="all_reduce"):
+    def __init__(self, model, process_group=None, buckets=None, average=True, force_collective=False, mode="all_reduce",
+                 rehearse=None):
         """mode: "all_reduce" (default: one all_reduce(AVG) per bucket) or "reduce_scatter" (per bucket a reduce_scatter(AVG) into
         this rank's 1/world shard followed by an all_gather of the shards, both in place in the flat buffer: on the fully connected
         xGMI mesh every peer link carries 1/world of the bucket in each phase -- SURVEY section 5 -- instead of a ring's whole
@@ -87,6 +88,11 @@ class FlatGradSync:
         if mode not in ("all_reduce", "reduce_scatter"):
             raise ValueError("FlatGradSync mode: 'all_reduce' or 'reduce_scatter'")
         self.mode = mode
+        # rehearse = {"workgroups": n, "passes": k} (ONE rank only; measurement aid, bench.py --rehearse-collective): every bucket
+        # launch also starts k device-to-device copies of the bucket on a side stream, each confined to n workgroups -- the HBM
+        # traffic and CU footprint a real RCCL all-reduce of that bucket would put next to the remaining backward kernels
+        self.rehearse = dict(rehearse) if rehearse else None
+        self._side = None
         self.group = process_group
         self.world = tdist.get_world_size(process_group) if tdist.is_initialized() else 1
         self.rank = tdist.get_rank(process_group) if tdist.is_initialized() else 0
@@ -153,6 +159,20 @@ class FlatGradSync:
             self._next += 1
 
     def _launch(self, bi):
+        if self.rehearse is not None and self.world == 1 and self._cuda:
+            from . import _lib
+            start, end, _ = self.buckets[bi]
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.flat.device)
+                self._scratch = torch.empty_like(self.flat)
+            ev = torch.cuda.Event()
+            ev.record()                                     # the bucket's gradients are complete on the compute stream
+            self._side.wait_event(ev)
+            nbytes = (end - start) * self.flat.element_size()
+            for _ in range(int(self.rehearse.get("passes", 2))):
+                _lib.check(_lib.load().pangu_traffic_copy(self._side.cuda_stream, self.flat[start:end].data_ptr(),
+                                                          self._scratch[start:end].data_ptr(), nbytes,
+                                                          int(self.rehearse.get("workgroups", 32))), "traffic_copy")
         if self.world == 1 and not self.force:
             return
         start, end, _ = self.buckets[bi]
@@ -186,6 +206,8 @@ class FlatGradSync:
                     v.zero_()
                     p.grad = v
             self._launch(bi)
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)      # the optimizer waits for the rehearsal "collectives" as it would for RCCL's
         for work, chunk in self._works:
             work.wait()
             if chunk is not None:

@@ -41,6 +41,7 @@ def _tok2d(x):
 
 
 _FUSE_LN = os.environ.get("PANGU_F32_FUSE_LN", "1") != "0"       # A/B knob: 0 = separate GEMM + LN-residual launches
+_FUSE_MLP = os.environ.get("PANGU_F32_FUSE_MLP", "1") != "0"     # A/B knob: 0 = MLP-up + GELU and MLP-down + LN as two launches
 
 
 def mlp(m, x2d):
@@ -102,7 +103,10 @@ def earth_block(blk, x, Z, H, W, roll, out=None):
     # of layer 0 / 3 on the autograd path; a partially frozen fine-tune (nothing upstream of this block trains) lands here
     o2 = None if out is None else (out if out.dim() == 2 else _tok2d(out))
     if s2 != 0.0:
-        if _FUSE_LN and C in (192, 384):
+        if _FUSE_MLP and C == 192:           # the whole MLP branch + post-norm residual in one launch: the hidden stays on chip
+            x2o = ops.mlp_ln_residual(x1, blk.linear.linear1.weight, blk.linear.linear1.bias, blk.linear.linear2.weight,
+                                      blk.linear.linear2.bias, blk.norm2.weight, blk.norm2.bias, out=o2, branch_scale=s2)
+        elif _FUSE_LN and C in (192, 384):
             h = ops.linear(x1, blk.linear.linear1.weight, blk.linear.linear1.bias, act=ops.ACT_GELU)
             x2o = ops.linear_ln_residual(h, blk.linear.linear2.weight, blk.linear.linear2.bias, x1, blk.norm2.weight,
                                          blk.norm2.bias, out=o2, branch_scale=s2)

@@ -371,6 +371,29 @@ def linear_ln_residual(a, weight, bias, shortcut, gamma, beta, out=None, branch_
     return out
 
 
+def mlp_ln_residual(x, w1, b1, w2, b2, gamma, beta, out=None, branch_scale=1.0):
+    """out = x + branch_scale * (LayerNorm(GELU(x @ w1^T + b1) @ w2^T + b2) * gamma + beta) in ONE launch (C = 192 / 384; inference):
+    the (M, 4C) hidden activation never reaches memory.  x / out may be row-strided."""
+    lib = _lib.load()
+    xp, ldx = _rows(x, "mlp_ln.x")
+    M, C = x.shape
+    if tuple(w1.shape) != (4 * C, C) or tuple(w2.shape) != (C, 4 * C):
+        raise RuntimeError(f"mlp_ln_residual: x {tuple(x.shape)} w1 {tuple(w1.shape)} w2 {tuple(w2.shape)}")
+    if out is None:
+        out = torch.empty((M, C), dtype=torch.float32, device=x.device)
+    op, ldo = _rows(out, "mlp_ln.out")
+    chunks = _row_chunks(M, 4 * ldx, 4 * ldo)
+    if chunks is not None:
+        for m0, m1 in chunks:
+            mlp_ln_residual(x[m0:m1], w1, b1, w2, b2, gamma, beta, out[m0:m1], branch_scale)
+        return out
+    with _timed("mlp_fused", 16.0 * M * C * C):
+        _lib.check(lib.pangu_mlp_ln_residual_fwd(_stream(x), xp, ldx, _chk(w1, "w1"), _chk(b1, "b1"), _chk(w2, "w2"), _chk(b2, "b2"),
+                                                 _chk(gamma, "gamma"), _chk(beta, "beta"), op, ldo, M, C, float(branch_scale)),
+                   "mlp_ln_residual_fwd")
+    return out
+
+
 _WGRAD_WS_BYTES = 96 << 20
 _wgrad_ws = {}      # (device, stream) -> fp32 scratch buffer of the two-stage weight-gradient reduction (shared with ops_bf16)
 
