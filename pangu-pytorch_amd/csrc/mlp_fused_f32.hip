@@ -29,6 +29,19 @@ constexpr int STAGE_SLABS = 6;
 constexpr int STAGE = STAGE_SLABS * SLAB; // 24 576 B
 constexpr int RING = 4;
 constexpr float LN_EPS = 1e-5f;
+// timing-only ablations (tools/ablate_mlp_f32.sh builds them into scratch/; never in the shipped library)
+#ifndef MLP_PIN
+#define MLP_PIN 1          // scheduling barrier after every MFMA gap
+#endif
+#ifndef MLP_NOGELU
+#define MLP_NOGELU 0       // 1: skip the GELU (wrong results)
+#endif
+#ifndef MLP_NODMA
+#define MLP_NODMA 0        // 1: no in-loop LDS-DMA requests and no barriers (stale LDS: wrong results)
+#endif
+#ifndef MLP_DUAL
+#define MLP_DUAL 0         // 1: the first product alternates two accumulators (independent MFMA chains), summed per chunk
+#endif
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -144,6 +157,9 @@ __global__ __launch_bounds__(256) void mlp_ln_residual_f32_kernel(const float* _
   };
 
   f32x4 a[2][4];                 // A operands of the slab in flight / the next one (16 MFMAs each)
+  f32x16 Hd;                     // (MLP_DUAL ablation: second accumulator of the first product)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) Hd[r] = 0.f;
   f32x16 Hc, G;                  // Hc: first-product accumulator of the chunk in flight; G: the previous chunk, GELU'd IN PLACE
   auto h_init = [&](int c) {
 #pragma unroll
@@ -199,16 +215,20 @@ __global__ __launch_bounds__(256) void mlp_ln_residual_f32_kernel(const float* _
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int m = k * 16 + q * 4 + e;
-          if (KIND == 0) Hc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k & 1][q][e], xr[jo][q][e], Hc, 0, 0, 0);
-          else Y[jo] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k & 1][q][e], G[4 * q + e], Y[jo], 0, 0, 0);
+          if (KIND == 0) {
+            if (MLP_DUAL && (m & 1)) Hd = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k & 1][q][e], xr[jo][q][e], Hd, 0, 0, 0);
+            else Hc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k & 1][q][e], xr[jo][q][e], Hc, 0, 0, 0);
+          } else Y[jo] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k & 1][q][e], G[4 * q + e], Y[jo], 0, 0, 0);
           if (m % 16 < 4) {                        // the next slab's fragments, one read per gap
             if (k + 1 < STAGE_SLABS) a[(k + 1) & 1][m % 16] = frag1(base + (k + 1) * SLAB, m % 16);
             else if (s + 1 < NSTAGE) a[0][m % 16] = frag1(next, m % 16);
           }
-          if (m == 48) sync(s + 1);
-          if (m > 48 && m <= 48 + STAGE_SLABS && s + 2 < NSTAGE) issue_piece(s + 2, m - 49);
-          if (KIND == 0 && gelu_prev && part == 0 && (m & 1) == 0 && m / 2 < 48) gelu_group(m / 6, (m / 2) % 3);
-          __builtin_amdgcn_sched_barrier(0);
+          if (!MLP_NODMA) {
+            if (m == 48) sync(s + 1);
+            if (m > 48 && m <= 48 + STAGE_SLABS && s + 2 < NSTAGE) issue_piece(s + 2, m - 49);
+          }
+          if (!MLP_NOGELU && KIND == 0 && gelu_prev && part == 0 && (m & 1) == 0 && m / 2 < 48) gelu_group(m / 6, (m / 2) % 3);
+          if (MLP_PIN) __builtin_amdgcn_sched_barrier(0);
         }
     }
   };
@@ -235,13 +255,18 @@ __global__ __launch_bounds__(256) void mlp_ln_residual_f32_kernel(const float* _
   for (int p = 0; p < SPP; ++p) run_stage(K0{}, p, sn++, false);
   for (int c = 0; c < NCH; ++c) {
     G = Hc;                                                              // chunk c before GELU
+    if (MLP_DUAL) {
+      G += Hd;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Hd[r] = 0.f;
+    }
     if (c + 1 < NCH) {
       h_init(c + 1);
 #pragma unroll
       for (int p = 0; p < SPP; ++p) run_stage(K0{}, p, sn++, true);
     } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) G[r] = gelu_erf(G[r]);
+      for (int r = 0; r < 16; ++r) G[r] = MLP_NOGELU ? G[r] : gelu_erf(G[r]);
     }
 #pragma unroll
     for (int p = 0; p < SPP; ++p) run_stage(K1{}, p, sn++, false);

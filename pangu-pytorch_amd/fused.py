@@ -41,7 +41,12 @@ def _tok2d(x):
 
 
 _FUSE_LN = os.environ.get("PANGU_F32_FUSE_LN", "1") != "0"       # A/B knob: 0 = separate GEMM + LN-residual launches
-_FUSE_MLP = os.environ.get("PANGU_F32_FUSE_MLP", "1") != "0"     # A/B knob: 0 = MLP-up + GELU and MLP-down + LN as two launches
+# A/B knob: 1 = the whole MLP branch of the C = 192 blocks in ONE launch (csrc/mlp_fused_f32.hip: hidden activation on chip).  Built
+# and measured in round 5 (profiles/r05_mlp_f32_ab.md): parity-green, 2.59-2.75 ms against 2.46-2.50 ms for the two launches it
+# replaces (whole forward 67.6-68.0 vs 66.5 ms) -- on gfx950 the fp32 "matrix" rate IS the vector ALUs' rate, so the GELU's VALU work
+# costs matrix time whoever issues it, and one wave per SIMD cannot hide it behind other waves' MFMAs as the 4-5 resident GEMM
+# workgroups do.  Off by default.
+_FUSE_MLP = os.environ.get("PANGU_F32_FUSE_MLP", "0") == "1"
 
 
 def mlp(m, x2d):

@@ -4,6 +4,7 @@ dispatches of that instantiation) and the kernel-trace duration of the same pass
 import csv, glob, re, sys
 from collections import defaultdict
 root = sys.argv[1]
+FILTER = sys.argv[2] if len(sys.argv) > 2 else "window_attn_qkv"      # substring of the kernel names to tabulate
 cnt = defaultdict(lambda: defaultdict(list))     # kernel -> counter -> per-dispatch values
 dur = defaultdict(list)
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
@@ -19,9 +20,9 @@ for f in glob.glob(root + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 def short(k):
-    m = re.search(r"(window_attn_qkv\w*)<([^>]*)>", k)
+    m = re.search(r"(\w+)<([^>]*)>", k.replace("(anonymous namespace)::", ""))
     return f"{m.group(1)}<{m.group(2)}>" if m else k[:60]
-keys = sorted(k for k in cnt if "window_attn_qkv" in k)
+keys = sorted(k for k in cnt if any(f in k for f in FILTER.split(",")))
 cols = ["TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
         "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE", "FETCH_SIZE", "SQ_BUSY_CYCLES"]
 cols = [c for c in cols if any(c in cnt[k] for k in keys)]
