@@ -149,6 +149,41 @@ def cpu_baseline_full(threads):
     return t
 
 
+def rollout_vs_reference(dev):
+    """BASELINE configs[4] pinned to the REFERENCE: the 7 x 24 h rollout on the goldens' closed-form weights and
+    inputs, fp32 and bf16, against the fingerprints of seven chained reference forwards (tests/golden/rollout7.npz, written by
+    oracle/gen_golden.py rollout7 in the build container).  Checker leg: uses oracle/ (closed-form generators, fingerprint compare)
+    and runs with the CPU baseline only (rank 0, N = 1)."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cases
+    import synth
+    import pangu_pytorch_amd as P
+    from pangu_pytorch_amd import rollout as R
+    gpath = os.path.join(ROOT, "tests", "golden", "rollout7.npz")
+    if not os.path.exists(gpath):
+        return None
+    g = np.load(gpath)
+    m = P.PanguModel(device=dev).to(dev).eval()
+    m.load_state_dict(synth.fill_state_dict(cases.model_param_shapes(), str(dev)))
+    inp, inp_s, stats, maps, const_h = cases.model_inputs(str(dev))
+    s_mean, s_std, u_mean, u_std = stats
+    sl = (s_mean.view(1, 4, 1, 1), s_std.view(1, 4, 1, 1), u_mean.reshape(13, 5).flip(0).t().reshape(1, 5, 13, 1, 1).contiguous(),
+          u_std.reshape(13, 5).flip(0).t().reshape(1, 5, 13, 1, 1).contiguous())
+    res = {"note": "max relative fingerprint error (samples, column sums, mass; relative to the largest reference value) of each step's "
+                   "normalised upper-air output against the REFERENCE's own 7-step rollout on the same closed-form weights / inputs "
+                   "(tests/golden/rollout7.npz); these weights are deliberately not contractive, so one step's error is carried on"}
+    for key, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        m.set_compute_dtype(dt)
+        _, _, hist = R.rollout(m, inp, inp_s, stats, maps, const_h, sl, steps=7, graph=True, keep=True)
+        res[key] = [cases.compare_summary(o, g, f"rollout.step{k + 1}.out", 1.0) for k, (o, _) in enumerate(hist)]
+        del hist
+    del m
+    torch.cuda.empty_cache()
+    return res
+
+
 def pmc_traffic(dtype, family):
     """Per-launch HBM bytes / MFMA-busy of a kernel family from the committed rocprofv3 PMC run (tools/pmc_traffic.sh ->
     profiles/pmc_traffic_<dtype>.json).  Counters cannot be read from inside this process; the JSON records the sha256 of the
@@ -425,19 +460,31 @@ def main():
                     for name, kw in (("flat_buffer_no_traffic", None), ("traffic_32wg_x2", {"workgroups": 32, "passes": 2}),
                                      ("traffic_64wg_x2", {"workgroups": 64, "passes": 2})):
                         fs = FlatGradSync(model, rehearse=kw)
+                        evs = []
+
+                        def fin(fs=fs, evs=evs):      # GPU time the compute stream waits for the side stream at finish()
+                            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            a.record()
+                            fs.finish()
+                            b.record()
+                            evs.append((a, b))
                         torch.manual_seed(1234 + rank)
                         for _ in range(2):
-                            train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=fs.finish)
+                            train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=fin)
                         lsync()
+                        del evs[:]
                         t3 = time.perf_counter()
                         for _ in range(args.train_steps):
-                            train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=fs.finish)
+                            train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=fin)
                         lsync()
-                        reh[name] = (time.perf_counter() - t3) / args.train_steps * 1e3
+                        reh[name] = {"ms_per_step": (time.perf_counter() - t3) / args.train_steps * 1e3,
+                                     "exposed_wait_ms_per_step": sum(a.elapsed_time(b) for a, b in evs) / max(len(evs), 1)}
                         fs.remove()
                         model.zero_grad(set_to_none=True)
                         del fs
-                    reh["note"] = ("ms per step, DropPath on, same seed; traffic = per bucket 2 x (read + write) of the bucket by a copy kernel "
+                    reh["note"] = ("DropPath on, same seed; exposed_wait = what the optimizer waits for the last buckets' traffic (the tail a "
+                                   "real collective would expose too); ms_per_step - exposed_wait - the no-traffic step = what the overlapped "
+                                   "traffic costs the backward kernels; traffic = per bucket 2 x (read + write) of the bucket by a copy kernel "
                                    "confined to N workgroups on a side stream, released when the bucket's last gradient exists; the "
                                    "optimizer waits for it")
                     train_res[tag]["allreduce_rehearsal_ms_per_step"] = reh
@@ -623,6 +670,12 @@ def main():
                 cb["sample"] = (f"the oracle's WHOLE forward (oracle/pangu_oracle.forward = reference pangu_model.py:50-87 restated), one "
                                 f"step on the bench's shapes: {t_full:.1f} s with {cb['cores']} threads")
             res["cpu_baseline"] = cb
+            try:
+                rv = rollout_vs_reference(dev)
+                if rv is not None:
+                    res["rollout_7x24h_vs_reference"] = rv
+            except Exception as e:      # a checker leg must never take the headline line down
+                res["rollout_7x24h_vs_reference"] = {"error": repr(e)[:300]}
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

@@ -25,7 +25,7 @@ FAMILIES = {
             "gemm_ln": (("gemm_ln_residual_f32",), ("gemm_ln_f32_dma.hip",)),
             "attn": (("window_attn_f32_kernel",), ("attn_f32.hip",))},
     "bf16": {"mlp_fused": (("mlp_ln_residual_bf16_kernel",), ("mlp_fused_bf16.hip",)),
-             "attn_qkv": (("window_attn_qkv_bf16_kernel",), ("attn_bf16.hip",)),
+             "attn_qkv": (("window_attn_qkv_bf16_kernel",), ("attn_bf16.hip", "attn_bf16_tile.h")),
              "gemm": (("gemm_tn_bf16", "gemm_ws_bf16"), ("gemm_bf16.hip", "gemm_ws_bf16.hip")),
              "gemm_ln": (("gemm_ln_residual_bf16",), ("gemm_ln_bf16.hip",))},
 }

@@ -33,6 +33,7 @@ for dt in ([torch.float32, torch.bfloat16] if which == "both" else [torch.bfloat
         one_step = lambda: gts.step()
     else:
         one_step = lambda: train.train_step(model, opt, batch, stats, maps, const_h)
+    torch.manual_seed(1234)      # bench.py seeds the DropPath draws (host RNG) the same way before its training loops
     for _ in range(warm):
         one_step()
     torch.cuda.synchronize()
@@ -50,5 +51,8 @@ for dt in ([torch.float32, torch.bfloat16] if which == "both" else [torch.bfloat
         print("warm-up only")
         continue
     wall = (time.perf_counter() - t0) / steps * 1e3
+    from pangu_pytorch_amd.layers import DropPath
+    nd = [sum(m.n_dropped_branch[i] for m in model.modules() if isinstance(m, DropPath)) for i in (0, 1)]
+    print(f"dropped branches so far (attention, MLP): {nd}")
     print(f"{'bf16' if dt == torch.bfloat16 else 'f32'} train ({mode}): wall {wall:.2f} ms/step, GPU (events) {a.elapsed_time(b) / steps:.2f} ms/step, "
           f"host time spent issuing a step {host / steps * 1e3:.2f} ms, loss {float(loss):.4f}")
