@@ -520,20 +520,25 @@ def main():
             # (a) test() of models/pangu_sample.py:197-202: model.eval() and NO torch.no_grad() -> the autograd (activation-saving)
             # forward runs; the graph is dropped with the outputs
             model.eval()
-            fe = {"note": "model.eval() with grads ENABLED (reference models/pangu_sample.py:197-202 calls the model without no_grad): "
-                          "the activation-saving training forward runs; wrap test() in torch.no_grad() to get the headline"}
-            for key, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
-                model.set_compute_dtype(dt)
-                for _ in range(2):
-                    o = model(inp, inp_s, stats, maps, const_h)
-                    del o
-                lsync()
-                t1 = time.perf_counter()
-                for _ in range(n_x):
-                    o = model(inp, inp_s, stats, maps, const_h)
-                    del o
-                lsync()
-                fe[key] = (time.perf_counter() - t1) / n_x * 1e3
+            fe = {}
+            for sfx, mode in (("", "recompute"), ("_saving_activations", "save")):
+                model.eval_grad_mode = mode
+                for key, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+                    model.set_compute_dtype(dt)
+                    for _ in range(2):
+                        o = model(inp, inp_s, stats, maps, const_h)
+                        del o
+                    lsync()
+                    t1 = time.perf_counter()
+                    for _ in range(n_x):
+                        o = model(inp, inp_s, stats, maps, const_h)
+                        del o
+                    lsync()
+                    fe[key + sfx] = (time.perf_counter() - t1) / n_x * 1e3
+            model.eval_grad_mode = "recompute"
+            fe["note"] = ("model.eval() with grads ENABLED, the call of reference models/pangu_sample.py:197-202 (no no_grad).  f32 / bf16: the "
+                          "default (PanguModel.eval_grad_mode = 'recompute': inference kernels now, the autograd forward re-run only if a backward "
+                          "arrives); *_saving_activations: eval_grad_mode = 'save' (the activation-saving training forward at once)")
             extras["forward_grad_enabled_eval_ms"] = fe
             # (b) the loop body of models/pangu_sample.py:45-77 as written there: optimizer.zero_grad(); model.train(); forward;
             # torch-op weighted L1; loss.backward(); optimizer.step() with torch.optim.Adam's defaults (finetune_fully.py:121)

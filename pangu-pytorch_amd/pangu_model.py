@@ -21,6 +21,33 @@ def compact_bias_stamp(p):
     return ops.param_stamp(p)
 
 
+class _EvalRecomputeFn(torch.autograd.Function):
+    """`model.eval()` called WITH gradients enabled -- the reference's own `test()` does exactly that (models/pangu_sample.py:197-202:
+    no `torch.no_grad()`), and nothing ever calls backward there.  The forward runs the INFERENCE kernels under no_grad and keeps
+    nothing but its inputs (no 30 / 66 GB of saved activations, the fused inference launches instead of the activation-saving
+    training ones); if a backward does arrive, it re-runs the forward on the autograd path and differentiates that: whole-model
+    activation checkpointing -- what the reference does per block on every call (layers.py:115-119, `use_checkpoint` is always on).
+    Stochastic depth is off in eval(), so the two forwards see the same function."""
+
+    @staticmethod
+    def forward(ctx, model, args, *params):
+        # args = (input, input_surface, statistics, maps, const_h, want_bf16): the compute dtype is decided ONCE, here (an enclosing
+        # autocast is not active any more when the backward runs)
+        ctx.model, ctx.args = model, args
+        with torch.no_grad():
+            return model._forward_dispatch(*args, grad_path=False)
+
+    @staticmethod
+    def backward(ctx, d_out, d_out_s):
+        model = ctx.model
+        need = ctx.needs_input_grad[2:]
+        params = [p for p, n in zip(model.parameters(), need) if n]
+        with torch.enable_grad():
+            out, out_s = model._forward_dispatch(*ctx.args, grad_path=True)
+        grads = iter(torch.autograd.grad((out, out_s), params, (d_out, d_out_s), allow_unused=True))
+        return (None, None) + tuple(next(grads) if n else None for n in need)
+
+
 class PanguModel(nn.Module):
     def __init__(self, depths=[2, 6, 6, 2], num_heads=[6, 12, 12, 6], dims=[192, 384, 384, 192],
                  patch_size=(2, 4, 4), device=None):
@@ -49,6 +76,10 @@ class PanguModel(nn.Module):
         self.compute_dtype = torch.float32
         self._shadow = None
         self._compact_bias = False
+        # eval() forward with gradients enabled: "recompute" (default: inference kernels now, the autograd forward again only if a
+        # backward arrives -- _EvalRecomputeFn) or "save" (the activation-saving training forward at once: cheaper when every eval-mode
+        # forward IS followed by a backward, e.g. train.GraphedTrainStep, deterministic fine-tuning with stochastic depth off)
+        self.eval_grad_mode = "recompute"
 
     def set_compute_dtype(self, dtype):
         """torch.float32 (default; parity <= 1e-3 with the reference) or torch.bfloat16 (inference: bf16 activations and
@@ -172,6 +203,11 @@ class PanguModel(nn.Module):
         grad_path = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         want_bf16 = self.compute_dtype == torch.bfloat16 or (
             torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+        if grad_path and not self.training and getattr(self, "eval_grad_mode", "save") == "recompute":
+            return _EvalRecomputeFn.apply(self, (input, input_surface, statistics, maps, const_h, want_bf16), *self.parameters())
+        return self._forward_dispatch(input, input_surface, statistics, maps, const_h, want_bf16, grad_path)
+
+    def _forward_dispatch(self, input, input_surface, statistics, maps, const_h, want_bf16, grad_path):
         if want_bf16:
             from . import autograd_bf16, fused_bf16
             if self._shadow is None:

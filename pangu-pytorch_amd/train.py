@@ -268,7 +268,13 @@ class GraphedTrainStep:
 
     def _fwd_bwd(self):
         inp, inp_s, tgt, tgt_s = self.batch
-        out, out_s = self.model(inp, inp_s, *self.consts)
+        # every forward here IS followed by its backward: the activation-saving forward at once, not inference kernels + a recompute
+        # (PanguModel.eval_grad_mode; this class needs stochastic depth off, i.e. usually model.eval())
+        mode, self.model.eval_grad_mode = getattr(self.model, "eval_grad_mode", "save"), "save"
+        try:
+            out, out_s = self.model(inp, inp_s, *self.consts)
+        finally:
+            self.model.eval_grad_mode = mode
         if self.stats_last is not None:
             tgt, tgt_s = norm_data(tgt, tgt_s, self.stats_last)
         loss = weighted_l1_loss(out, out_s, tgt, tgt_s)

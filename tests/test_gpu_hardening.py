@@ -190,6 +190,47 @@ def test_partially_frozen_finetune_f32(P, trainable):
             assert p.grad is None, k
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_eval_forward_with_grad_is_the_inference_forward_and_recomputes_for_backward(P, dtype):
+    """The reference's `test()` calls the model in eval() WITHOUT no_grad (models/pangu_sample.py:197-202).  Default
+    `eval_grad_mode = "recompute"`: that call runs the inference kernels (bit-identical to the no_grad forward, no saved activations)
+    and a backward, should one arrive, re-runs the autograd forward: gradients equal those of `eval_grad_mode = "save"` (the
+    activation-saving forward at once) -- identical kernels on identical inputs, accumulation order of the fp32 atomics aside."""
+    m = P.PanguModel(device="cuda").cuda().eval()
+    m.load_state_dict(synth.fill_state_dict(cases.model_param_shapes(), "cuda"))
+    m.set_compute_dtype(dtype)
+    inp, inp_s, stats, maps, const_h = cases.model_inputs("cuda")
+    with torch.no_grad():
+        ref, ref_s = m(inp, inp_s, stats, maps, const_h)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    assert m.eval_grad_mode == "recompute"
+    out, out_s = m(inp, inp_s, stats, maps, const_h)
+    assert out.requires_grad and torch.equal(out, ref) and torch.equal(out_s, ref_s)
+    held = (torch.cuda.memory_allocated() - base) / 2**30
+    assert held < 1.0, held                      # the two output fields (0.29 GB), not 30 / 66 GB of activations
+    # a FIXED cotangent (not the L1 loss, whose sign(o - t) would be taken on two slightly different outputs): the backward is then
+    # the same graph on the same inputs in both modes -- the autograd forward is what gets differentiated either way
+    cot, cot_s = cases.cotangent("evalrc", out.shape, "cuda"), cases.cotangent("evalrc_s", out_s.shape, "cuda")
+    ((out * cot).sum() + (out_s * cot_s).sum()).backward()
+    got = {k: p.grad.clone() for k, p in m.named_parameters()}
+    assert all(g is not None for g in got.values())
+    m.zero_grad(set_to_none=True)
+    del out, out_s
+    m.eval_grad_mode = "save"
+    out, out_s = m(inp, inp_s, stats, maps, const_h)
+    ((out * cot).sum() + (out_s * cot_s).sum()).backward()
+    worst, worst_l2 = (0.0, ""), (0.0, "")
+    for k, p in m.named_parameters():
+        e = ((p.grad - got[k]).abs().max() / p.grad.abs().max().clamp_min(1e-30)).item()
+        l2 = ((p.grad - got[k]).double().norm() / p.grad.double().norm().clamp_min(1e-30)).item()
+        worst, worst_l2 = max(worst, (e, k)), max(worst_l2, (l2, k))
+    print("eval recompute vs save, worst gradient difference (max-abs / max, rel-L2):", worst, worst_l2)
+    assert worst_l2[0] < 1e-4 and worst[0] < 1e-3, (worst, worst_l2)      # identical kernels; only the fp32 atomics' order differs
+    m.set_compute_dtype(torch.float32)
+
+
 def test_hip_adam_follows_replaced_state(P):
     """optimizer.load_state_dict(snapshot) after a step replaces exp_avg / exp_avg_sq while the parameters and
     (FlatGradSync-style) gradient buffers keep their addresses; the cached device job table must not keep the old moments."""
