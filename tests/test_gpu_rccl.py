@@ -35,3 +35,28 @@ def test_bench_under_torchrun_one_rank_rccl():
     for tag in ("ddp_train", "ddp_train_bf16"):
         assert "error" not in res[tag], res[tag]
         assert res[tag]["loss"] == res[tag]["loss"]        # not NaN
+
+
+def test_reduce_scatter_mode_on_a_one_rank_rccl_communicator():
+    """`--grad-sync reduce_scatter` (FlatGradSync mode "reduce_scatter": per bucket an in-place reduce_scatter(AVG) into this rank's
+    shard + an in-place all_gather, both issued asynchronously from the backward hooks) through REAL RCCL calls: on a 1-rank
+    communicator the collectives are identities, so the training loss must equal the all_reduce mode's (to the run-to-run spread of
+    the step's fp32 atomics: two optimizer steps, 1e-5) -- what the test buys is that RCCL accepts the in-place / aliased tensor arguments and the issue order (gloo, which runs the world-2 parity
+    tests, takes a different code path)."""
+    losses = {}
+    for mode in ("all_reduce", "reduce_scatter"):
+        env = dict(os.environ, PANGU_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+               os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--train-steps", "2",
+               "--no-cpu-baseline", "--no-bf16", "--no-extras", "--grad-sync", mode]
+        r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        dd = res["ddp_samples_per_s"]
+        assert dd["rccl_ranks"] == 1 and dd["backend"] == "nccl" and (("reduce_scatter" in dd["collective"]) == (mode == "reduce_scatter"))
+        for tag in ("ddp_train", "ddp_train_bf16"):
+            assert "error" not in res[tag], res[tag]
+        losses[mode] = (res["ddp_train"]["loss"], res["ddp_train_bf16"]["loss"])
+    for a, b in zip(losses["all_reduce"], losses["reduce_scatter"]):
+        assert abs(a - b) <= 1e-5 * abs(a), losses
