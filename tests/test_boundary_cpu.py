@@ -125,3 +125,47 @@ def test_bench_gpus_n_without_a_launcher_spawns_child_ranks_and_relays_failure()
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert "launch with" not in r.stderr and "torch.distributed" in r.stderr      # the child launcher ran and reported its ranks
+
+
+def test_eval_recompute_function_plumbs_gradients_like_plain_autograd():
+    """pangu_model._EvalRecomputeFn on a stand-in module (CPU): the forward runs `_forward_dispatch(.., grad_path=False)` under no_grad
+    and returns outputs that require grad; the backward re-runs it with grad_path=True and hands every trainable parameter the gradient
+    plain autograd gives, frozen parameters None -- also when only ONE of the two outputs is used by the loss."""
+    import torch
+    from pangu_pytorch_amd.pangu_model import _EvalRecomputeFn
+
+    class Stub(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Parameter(torch.tensor([1.5, -2.0, 0.5]))
+            self.b = torch.nn.Parameter(torch.tensor([0.25]))
+            self.frozen = torch.nn.Parameter(torch.tensor([3.0]), requires_grad=False)
+            self.calls = []
+
+        def _forward_dispatch(self, x, xs, stats, maps, const_h, want_bf16, grad_path):
+            self.calls.append((grad_path, torch.is_grad_enabled()))
+            return (x * self.a).sin() * self.b + self.frozen, (xs * self.a.sum()).cos()
+
+    m = Stub().eval()
+    x, xs = torch.tensor([0.3, 0.7, -1.1]), torch.tensor([0.2, 0.9])
+    out, out_s = _EvalRecomputeFn.apply(m, (x, xs, None, None, None, False), *m.parameters())
+    assert m.calls == [(False, False)] and out.requires_grad and out_s.requires_grad
+    (out.sum() * 2.0 + (out_s ** 2).sum()).backward()
+    assert m.calls == [(False, False), (True, True)]
+    got = [p.grad.clone() if p.grad is not None else None for p in m.parameters()]
+    m.zero_grad(set_to_none=True)
+    o, o_s = m._forward_dispatch(x, xs, None, None, None, False, True)
+    (o.sum() * 2.0 + (o_s ** 2).sum()).backward()
+    for g, p in zip(got, m.parameters()):
+        if p.requires_grad:
+            assert torch.allclose(g, p.grad, rtol=1e-6, atol=1e-7)
+        else:
+            assert g is None and p.grad is None
+    # one output unused: its cotangent is materialised as zeros
+    m.zero_grad(set_to_none=True)
+    out, _ = _EvalRecomputeFn.apply(m, (x, xs, None, None, None, False), *m.parameters())
+    out.sum().backward()
+    ga = m.a.grad.clone()
+    m.zero_grad(set_to_none=True)
+    m._forward_dispatch(x, xs, None, None, None, False, True)[0].sum().backward()
+    assert torch.allclose(ga, m.a.grad, rtol=1e-6, atol=1e-7)
