@@ -53,9 +53,14 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the reference-call-convention timings (grad-enabled eval forward, the reference's own loop body)")
     ap.add_argument("--train-steps", type=int, default=6)
-    ap.add_argument("--rehearse-collective", action="store_true",
-                    help="N = 1 only: time the training step again with a traffic generator standing in for the bucketed all-reduce "
-                         "(dist.FlatGradSync(rehearse=..): per bucket two device-to-device copies on a side stream, 32 workgroups)")
+    ap.add_argument("--no-fed", action="store_true",
+                    help="skip the host-fed training-step measurement (train_fed_from_host: pageable 573 MB batches through "
+                         "data.DevicePrefetcher, beside the resident-batch step)")
+    ap.add_argument("--rehearse-collective", action="store_true", help="(kept for old command lines: the rehearsal is ON by default at N = 1)")
+    ap.add_argument("--no-rehearse", action="store_true",
+                    help="N = 1 only: skip `allreduce_rehearsal_ms_per_step` (the training step timed again with a traffic generator "
+                         "standing in for the bucketed all-reduce: dist.FlatGradSync(rehearse=..), per bucket two device-to-device copies "
+                         "on a side stream confined to 32 / 64 workgroups)")
     ap.add_argument("--grad-sync", choices=("all_reduce", "reduce_scatter"), default="all_reduce",
                     help="the collective of dist.FlatGradSync (N > 1): bucketed all_reduce(AVG), or reduce_scatter + all_gather per bucket")
     return ap.parse_args()
@@ -179,6 +184,10 @@ def rollout_vs_reference(dev):
         _, _, hist = R.rollout(m, inp, inp_s, stats, maps, const_h, sl, steps=7, graph=True, keep=True)
         res[key] = [cases.compare_summary(o, g, f"rollout.step{k + 1}.out", 1.0) for k, (o, _) in enumerate(hist)]
         del hist
+    apath = os.path.join(ROOT, "tests", "golden", "autocast.npz")
+    if os.path.exists(apath):      # the yardstick for the bf16 list: the reference's own CPU autocast(bfloat16) rollout, same metric
+        ac = np.load(apath)
+        res["bf16_reference_autocast"] = [float(ac[f"rollout.step{k + 1}.err"][0]) for k in range(7)]
     del m
     torch.cuda.empty_cache()
     return res
@@ -218,6 +227,104 @@ def pmc_train(tag):
         return (None if stale else e), stale, j.get("commit")
     except (OSError, KeyError, ValueError):
         return None, None, None
+
+
+def xgmi_topology():
+    """The node's GPU link table as rocm-smi reports it (rank 0, once): hop and weight matrices + link types, parsed from
+    `rocm-smi --showtopo --json`; on any failure the reason (and the head of the raw output) instead -- never an exception."""
+    import re
+    import subprocess
+    try:
+        r = subprocess.run(["rocm-smi", "--showtopo", "--json"], capture_output=True, text=True, timeout=60)
+        raw = r.stdout.strip()
+        j = json.loads(raw[raw.index("{"):raw.rindex("}") + 1])
+        mats = {}
+
+        def walk(o):
+            if isinstance(o, dict):
+                for k, v in o.items():
+                    m = re.search(r"(Weight|Hops|Link [Tt]ype)[^0-9]*(\d+)\D+(\d+)", str(k))
+                    if m and not isinstance(v, (dict, list)):
+                        mats.setdefault(m.group(1).lower().replace(" ", "_"), {})[(int(m.group(2)), int(m.group(3)))] = v
+                    else:
+                        walk(v)
+            elif isinstance(o, list):
+                for v in o:
+                    walk(v)
+        walk(j)
+        n = 1 + max((max(a, b) for m in mats.values() for a, b in m), default=0)
+        out = {"gpus": n, "source": "rocm-smi --showtopo --json"}
+        for name, m in mats.items():
+            mat = [[None] * n for _ in range(n)]
+            for (a, b), v in m.items():
+                try:
+                    v = int(v)
+                except (TypeError, ValueError):
+                    pass
+                mat[a][b] = v
+                if mat[b][a] is None:
+                    mat[b][a] = v
+            out[name] = mat
+        if not mats:
+            out["raw_head"] = raw[:600]
+        return out
+    except Exception as e:
+        return {"error": repr(e)[:200]}
+
+
+def fed_from_host(model, opt, dev, consts, grad_sync, steps, rank):
+    """The training step FED FROM THE HOST (reference models/pangu_sample.py:41-43 `.to(device)` of four pageable
+    tensors = 573 MB per step, :77 `loss.item()` every step, era5_data/utils_data.py:117 level reversal in the reader): three
+    distinct full-size pageable samples in FILE level order, cycled, through
+      resident            the same samples already on the device (what `ddp_train*` / `ddp_samples_per_s` time), loss.item() per step
+      fed_free_running    data.DevicePrefetcher(fuse_flip=True): worker-thread staging into page-locked slots, copy-engine upload two
+                          batches ahead, the level flip an address inside patch_embed_gather / the loss kernel; no host sync
+      fed_item_per_step   the same with the reference's per-step loss.item()
+      reference_to_device the reference's own loop body: `.to(device)` of the four pageable tensors on the training thread, then the
+                          step, then loss.item()  (its reader's host-side `[::-1]` copy is NOT timed: it runs in DataLoader workers)
+    Returns ms per step of each and the pipeline's measured rates."""
+    import torch
+    from pangu_pytorch_amd import data, train
+    stats, maps, const_h = consts
+    g = torch.Generator().manual_seed(3000 + rank)
+    shapes = ((1, 5, 13, 721, 1440), (1, 4, 721, 1440), (1, 5, 13, 721, 1440), (1, 4, 721, 1440))
+    host = [tuple(torch.rand(sh, generator=g) * 2 - 1 for sh in shapes) for _ in range(3)]
+    n_warm, n = 3, max(6, steps)
+    sync = torch.cuda.synchronize
+
+    def timed(batches, item, rev, to_device=False):
+        t0 = None
+        for k, b in enumerate(batches):
+            if k == n_warm:
+                sync()
+                t0 = time.perf_counter()
+            if to_device:
+                b = tuple(t.to(dev) for t in b)                      # pangu_sample.py:41-43 (pageable source: a blocking copy each)
+            loss = train.train_step(model, opt, b, stats, maps, const_h, grad_sync=grad_sync, levels_reversed=rev)
+            if item:
+                loss.item()                                          # pangu_sample.py:77
+        sync()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    cyc = [host[i % 3] for i in range(n_warm + n)]
+    res = {}
+    resident = [tuple(t.to(dev) for t in b) for b in host]
+    res["resident_item_per_step_ms"] = timed([resident[i % 3] for i in range(n_warm + n)], True, True)
+    del resident
+    pf = data.DevicePrefetcher(cyc, dev, flip_levels=True, fuse_flip=True, depth=2)
+    res["fed_free_running_ms"] = timed(pf, False, pf.levels_reversed)
+    res["fed_item_per_step_ms"] = timed(pf, True, pf.levels_reversed)
+    sync()
+    res["pipeline"] = pf.summary()
+    res["reference_to_device_item_per_step_ms"] = timed(cyc, True, True, to_device=True)
+    res["fed_over_resident"] = res["fed_item_per_step_ms"] / res["resident_item_per_step_ms"]
+    res["bytes_per_step"] = sum(t.numel() * 4 for t in host[0])
+    res["host_cpus"] = os.cpu_count()
+    res["note"] = ("ms per training step, DropPath on, three distinct pageable host samples in file (ascending) level order cycled; "
+                   "needed host->device rate = bytes_per_step / step time; pipeline.host_stage_GBps is the page-locked staging copy "
+                   "(pangu_host_copy, pipeline.copy_threads threads), pipeline.h2d_GBps the copy engine, consumer_wait what the training "
+                   "thread waited for batches (both fed loops)")
+    return res
 
 
 def synthetic_inputs(dev, seed):
@@ -376,7 +483,8 @@ def main():
         model.train()
         tgt, tgt_s, *_ = synthetic_inputs(dev, seed=2000 + rank)      # synthetic targets of the input's shape
         opt = train.make_optimizer(model)      # Adam(lr=5e-6, weight_decay=3e-6), reference finetune_fully.py:121
-        sync = FlatGradSync(model, force_collective=True, mode=args.grad_sync) if dist is not None else None
+        sync = FlatGradSync(model, force_collective=True, mode=args.grad_sync, timing=True) if dist is not None else None
+        other_mode = "reduce_scatter" if args.grad_sync == "all_reduce" else "all_reduce"
         batch = (inp, inp_s, tgt, tgt_s)
         exposed = []      # (event before finish(), event after): GPU time the compute stream spends waiting for the buckets
 
@@ -402,12 +510,16 @@ def main():
                     train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=grad_sync if sync else None)
                 lsync()
                 del exposed[:]
+                if sync:
+                    sync.bucket_times_ms()                # (drops the warm-up steps' event pairs)
                 drops0 = [tuple(d.n_dropped_branch) for _, d in dps]
                 t1 = time.perf_counter()
                 for _ in range(args.train_steps):
                     loss = train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=grad_sync if sync else None)
                 lsync()
                 t_train = time.perf_counter() - t1
+                bucket_ms = sync.bucket_times_ms() if sync else None
+                exposed_main = sum(a.elapsed_time(b) for a, b in exposed) / max(len(exposed), 1) if sync else None
                 skipped = dropped_gflop(drops0) / args.train_steps            # forward GFLOP per step that was NOT executed
                 n_drop = sum(d.n_dropped_branch[0] + d.n_dropped_branch[1] - b[0] - b[1] for (_, d), b in zip(dps, drops0))
                 exec_gflop = 3.0 * (FWD_GFLOP_EXEC - skipped)                 # fwd + bwd = 3 x forward
@@ -423,18 +535,20 @@ def main():
                     "dropped_branches_in_timed_steps": n_drop}
                 # the same step with stochastic depth OFF (every branch computed: the full 3 x forward ledger), timed beside it
                 saved_p = [d.drop_prob for _, d in dps]
-                for _, d in dps:
-                    d.drop_prob = 0.0
-                train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=grad_sync if sync else None)
-                lsync()
-                t2 = time.perf_counter()
-                n_off = max(2, args.train_steps // 2)
-                for _ in range(n_off):
+                try:
+                    for _, d in dps:
+                        d.drop_prob = 0.0
                     train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=grad_sync if sync else None)
-                lsync()
-                t_off = (time.perf_counter() - t2) / n_off
-                for (_, d), pr in zip(dps, saved_p):
-                    d.drop_prob = pr
+                    lsync()
+                    t2 = time.perf_counter()
+                    n_off = max(2, args.train_steps // 2)
+                    for _ in range(n_off):
+                        train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=grad_sync if sync else None)
+                    lsync()
+                    t_off = (time.perf_counter() - t2) / n_off
+                finally:      # a failure in here must not leave stochastic depth off for the next dtype's "DropPath on" numbers
+                    for (_, d), pr in zip(dps, saved_p):
+                        d.drop_prob = pr
                 # roofline block of the training step: EXECUTED work of the timed steps; bytes per step from the committed PMC table
                 pm, pm_stale, pm_commit = pmc_train("bf16" if dt == torch.bfloat16 else "f32")
                 t_s = t_train / args.train_steps
@@ -453,7 +567,7 @@ def main():
                     "traffic_stale": pm_stale, "traffic_commit": pm_commit,
                     "traffic_unit": "HBM bytes per step = sum over all kernels of one step (FETCH_SIZE x2 + WRITE_SIZE; rocprofv3 --pmc "
                                     "passes of tools/profile_train.py, same DropPath seed as this loop -> profiles/pmc_train.json)"}
-                if args.rehearse_collective and sync is None:
+                if sync is None and not args.no_rehearse:
                     # the same step with a flat gradient buffer and, per bucket, a traffic generator on a side stream where the
                     # RCCL all-reduce would run: how much the overlapped collective slows the backward kernels (an upper bound)
                     reh = {}
@@ -489,19 +603,74 @@ def main():
                                    "optimizer waits for it")
                     train_res[tag]["allreduce_rehearsal_ms_per_step"] = reh
                 if sync:
-                    train_res[tag]["exposed_allreduce_ms_per_step"] = sum(a.elapsed_time(b) for a, b in exposed) / max(len(exposed), 1)
+                    train_res[tag]["exposed_allreduce_ms_per_step"] = exposed_main
                     train_res[tag]["grad_copy_fallback_mib"] = sync.copied_bytes / 2**20
+                    train_res[tag]["grad_sync_mode"] = args.grad_sync
+                    # per bucket (0 = the first one backward completes: the output layer; 19 = the input layer): launch -> its last
+                    # collective done, mean over the timed steps -- events on a side stream that only waits for that collective
+                    train_res[tag]["bucket_launch_to_done_ms"] = bucket_ms
+                    train_res[tag]["bucket_mib"] = [b / 2**20 for b in sync.bucket_bytes()]
+                    # the SAME step with the other collective, in this very invocation: one command yields the A/B
+                    sync.remove()
+                    model.zero_grad(set_to_none=True)
+                    sync = FlatGradSync(model, force_collective=True, mode=other_mode, timing=True)
+                    torch.manual_seed(1234 + rank)
+                    for _ in range(2):
+                        train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=grad_sync)
+                    lsync()
+                    del exposed[:]
+                    sync.bucket_times_ms()
+                    t3 = time.perf_counter()
+                    for _ in range(args.train_steps):
+                        train.train_step(model, opt, batch, stats, maps, const_h, grad_sync=grad_sync)
+                    lsync()
+                    t_other = (time.perf_counter() - t3) / args.train_steps * 1e3
+                    train_res[tag]["grad_sync_ab"] = {
+                        args.grad_sync: {"ms_per_step": t_train / args.train_steps * 1e3, "exposed_ms_per_step": exposed_main,
+                                         "bucket_launch_to_done_ms": bucket_ms},
+                        other_mode: {"ms_per_step": t_other,
+                                     "exposed_ms_per_step": sum(a.elapsed_time(b) for a, b in exposed) / max(len(exposed), 1),
+                                     "bucket_launch_to_done_ms": sync.bucket_times_ms()},
+                        "note": "same DropPath seed, same batch, this rank's times; all_reduce = one all_reduce(AVG) per bucket, "
+                                "reduce_scatter = reduce_scatter(AVG) + all_gather per bucket in place"}
+                    sync.remove()
+                    model.zero_grad(set_to_none=True)
+                    sync = FlatGradSync(model, force_collective=True, mode=args.grad_sync, timing=True)
+                    del exposed[:]
+                if not args.no_fed:
+                    torch.manual_seed(1234 + rank)
+                    train_res[tag]["train_fed_from_host"] = fed_from_host(model, opt, dev, (stats, maps, const_h),
+                                                                          grad_sync if sync else None, args.train_steps, rank)
             except Exception as e:      # secondary metrics must never take the headline line down
                 train_res[tag] = {"error": repr(e)[:300]}
             if dist is not None:        # collectives OUTSIDE the try: every rank gets here, failed or not
                 ok = "error" not in train_res[tag]
-                t = torch.tensor([train_res[tag]["ms_per_step"] if ok else 0.0, 0.0 if ok else 1.0], dtype=torch.float64, device=dev)
+                fed_keys = ("resident_item_per_step_ms", "fed_free_running_ms", "fed_item_per_step_ms", "reference_to_device_item_per_step_ms")
+                fed = train_res[tag].get("train_fed_from_host") if ok else None
+                t = torch.tensor([train_res[tag]["ms_per_step"] if ok else 0.0, 0.0 if ok else 1.0] +
+                                 [fed[k] if fed else 0.0 for k in fed_keys], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 if ok and t[1].item() > 0:
                     train_res[tag] = {"error": "another rank failed this section"}
                     break
                 if ok:
-                    train_res[tag].update(ms_per_step=t[0].item(), value=world / (t[0].item() * 1e-3))
+                    # slowest rank's step time; the FLOP-derived numbers follow it (executed FLOPs stay this rank's DropPath draws:
+                    # `flop_counts_of: rank 0`)
+                    ms_max = t[0].item()
+                    r_ = train_res[tag]
+                    scale = r_["ms_per_step"] / ms_max
+                    r_.update(ms_per_step=ms_max, value=world / (ms_max * 1e-3), model_tflops=r_["model_tflops"] * scale)
+                    rf = r_.get("roofline")
+                    if rf:
+                        rf["mfma_frac"] *= scale
+                        for k in ("hbm_frac_of_8TBps", "hbm_frac_of_achievable_6.29TBps"):
+                            if rf.get(k) is not None:
+                                rf[k] *= scale
+                        rf["flop_counts_of"] = "rank 0 (its DropPath draws); times: max over ranks"
+                    if fed:
+                        fed.update({k: t[2 + i].item() for i, k in enumerate(fed_keys)})
+                        fed["fed_over_resident"] = fed["fed_item_per_step_ms"] / fed["resident_item_per_step_ms"]
+                        fed["times"] = "max over ranks; pipeline rates: rank 0"
                 else:
                     break
         model.set_compute_dtype(torch.float32)
@@ -624,19 +793,35 @@ def main():
             res.update(extras)
         # the metric's second half ("DDP samples/sec at 1/2/4/8") as TOP-LEVEL keys: measured in this very run by all `world` ranks
         # (fwd + bwd + the bucketed gradient all-reduce issued from the backward hooks + Adam; max-over-ranks step time)
-        dd = {"unit": "samples/s", "measured": True, "ranks": world,
+        dd = {"unit": "samples/s", "measured": True, "ranks": world, "resident_batch": True,
+              "resident_batch_note": "input and target of every step are already in HBM; the step fed from pageable host memory "
+                                     "(573 MB per step) is ddp_train*.train_fed_from_host",
               "rccl_ranks": world if (dist is not None and backend == "nccl") else 0,
               "backend": (backend if dist is not None else None),
               "collective": ((("bucketed all_reduce(AVG)" if args.grad_sync == "all_reduce" else
                                "bucketed reduce_scatter(AVG) + all_gather, in place,") +
                               " of the flat fp32 gradient buffer, overlapped with backward") if dist is not None
                              else "none (one rank: no process group)")}
+        if dist is not None:
+            try:
+                v = torch.cuda.nccl.version()
+                dd["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+            except Exception as e:
+                dd["rccl_version"] = repr(e)[:120]
+            dd["xgmi_topology"] = xgmi_topology()
+            dd["hip_devices_visible"] = n_dev
         for tag, key in (("ddp_train", "fp32"), ("ddp_train_bf16", "bf16")):
             tr_ = train_res.get(tag)
             if tr_ and "error" not in tr_:
+                fed_ = tr_.get("train_fed_from_host") or {}
                 dd[key] = {"value": tr_["value"], "ms_per_step": tr_["ms_per_step"],
+                           "fed_from_host_value": (world / (fed_["fed_item_per_step_ms"] * 1e-3)) if "fed_item_per_step_ms" in fed_ else None,
+                           "fed_from_host_ms_per_step": fed_.get("fed_item_per_step_ms"),
                            "exposed_allreduce_ms_per_step": tr_.get("exposed_allreduce_ms_per_step"),
-                           "grad_copy_fallback_mib": tr_.get("grad_copy_fallback_mib")}
+                           "grad_copy_fallback_mib": tr_.get("grad_copy_fallback_mib"),
+                           "bucket_launch_to_done_ms": tr_.get("bucket_launch_to_done_ms"),
+                           "grad_sync_ab_ms_per_step": ({k: v["ms_per_step"] for k, v in tr_["grad_sync_ab"].items() if isinstance(v, dict)}
+                                                        if "grad_sync_ab" in tr_ else None)}
             elif tr_:
                 dd[key] = {"error": tr_["error"]}
         res["ddp_samples_per_s"] = dd

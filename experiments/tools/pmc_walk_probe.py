@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """Run the fused QKV attention in its two forms on the model's two shapes (for rocprofv3 --pmc passes):
-python tools/pmc_walk_probe.py <variant,variant,..> [reps]   -- variant 0 = the (window, head) kernel, 40 / 21 / .. = attn_walk_bf16.hip"""
+python experiments/tools/pmc_walk_probe.py <variant,variant,..> [reps]   -- variant 0 = the (window, head) kernel, 40 / 21 / .. = attn_walk_bf16.hip"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "experiments"))
+import exp_ops as E
 import torch
 from pangu_pytorch_amd import ops_bf16 as ob
 variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,40,21").split(",")]
@@ -19,5 +21,8 @@ for C, Z, H, W, heads, types in ((192, 8, 181, 360, 6, 124), (384, 8, 91, 180, 1
     for sh in (False, True):
         for v in variants:
             for _ in range(reps):
-                ob.window_attention_qkv(x, w, b, esb, Z, H, W, heads, sh, variant=v)
+                if v:
+                    E.window_attention_qkv_walk(x, w, b, esb, Z, H, W, heads, sh, variant=v)
+                else:
+                    ob.window_attention_qkv(x, w, b, esb, Z, H, W, heads, sh)
 torch.cuda.synchronize()

@@ -145,15 +145,6 @@ int pangu_linear_ln_residual_fwd(pangu_stream_t stream, const float* A, int lda,
                                  const float* shortcut, int lds, const float* gamma, const float* beta, float* out, int ldo,
                                  int M, int N, int K, float branch_scale);
 
-/* The whole MLP branch of a block in ONE launch, fp32 inference (reference layers.py:251 with :264-270 inside):
- *   out[M,C] = x[M,C] + branch_scale * (LayerNorm(GELU(x @ W1^T + b1) @ W2^T + b2) * gamma + beta)
- * W1 [4C][C], b1 [4C], W2 [C][4C], b2 [C] in the reference's torch layouts (read in place: nothing is packed); x / out row strides
- * ldx / ldo (multiples of 4); C = 192 (the stage-0 / stage-3 width).  The (M x 4C) hidden activation stays on chip.  Replaces pangu_linear_fwd
- * (PANGU_ACT_GELU) + pangu_linear_ln_residual_fwd. */
-int pangu_mlp_ln_residual_fwd(pangu_stream_t stream, const float* x, int ldx, const float* w1, const float* b1, const float* w2,
-                              const float* b2, const float* gamma, const float* beta, float* out, int ldo, int M, int C,
-                              float branch_scale);
-
 /* Backward of the LayerNorm branch of pangu_ln_residual_fwd (the shortcut's gradient is dout itself):
  *   dy [N][C] overwritten;  dgamma[C], dbeta[C] ACCUMULATED (atomics).  dout may be row-strided (lddo). */
 int pangu_ln_residual_bwd(pangu_stream_t stream, const float* dout, int lddo, const float* y, const float* gamma,
@@ -188,11 +179,24 @@ int pangu_upsample_ln_bwd(pangu_stream_t stream, const float* dout, const float*
  *   a_upper [7*H4*W4][192]  col = c*32 + pz*16 + ph*4 + pw, c<5: (input-mean_used)/std_used, c==5: const_h
  * with mean_used[c][l] = upper_mean[12-l][c] (level-reversed statistics, layers.py:73-76).
  * input [5][13][LAT][LON], input_surface [4][LAT][LON], maps [3][4*H4][LON], const_h [13][LAT][LON],
- * surface_mean/std [4], upper_mean/std [13][5].  LAT=721, LON=1440 -> H4=181, W4=360. */
+ * surface_mean/std [4], upper_mean/std [13][5].  LAT=721, LON=1440 -> H4=181, W4=360.
+ * levels_reversed != 0: `input` is stored with its level axis in the file's (ascending) order and the reader's reversal
+ * (reference era5_data/utils_data.py:117, `[::-1]` on the host) is done by this kernel's addressing: logical level l is read
+ * from plane 12 - l.  Statistics, const_h and the outputs are unaffected. */
 int pangu_patch_embed_gather(pangu_stream_t stream, const float* input, const float* input_surface,
                              const float* surface_mean, const float* surface_std, const float* upper_mean,
                              const float* upper_std, const float* maps, const float* const_h,
-                             float* a_surface, float* a_upper, int LAT, int LON);
+                             float* a_surface, float* a_upper, int LAT, int LON, int levels_reversed);
+
+/* Adjoint of the gather above w.r.t. the raw fields (autograd of reference layers.py:48-55,71-76 when a caller sets
+ * input.requires_grad): d_input [5][13][LAT][LON] = da_upper[token][c*32+pz*16+ph*4+pw] / upper_std[12-l][c],
+ * d_input_surface [4][LAT][LON] = da_surface[token][c*16+ph*4+pw] / surface_std[c]; every element of both fields is
+ * written.  da_surface [H4*W4][64], da_upper [7*H4*W4][160] fp32: the gradient of the A-matrices' field columns only (the
+ * first 64 of 112 / 160 of 192; the columns of maps / const_h have no field behind them).
+ * levels_reversed as in the forward: d_input is laid out like the `input` it belongs to. */
+int pangu_patch_embed_gather_bwd(pangu_stream_t stream, const float* da_surface, const float* da_upper,
+                                 const float* surface_std, const float* upper_std, float* d_input,
+                                 float* d_input_surface, int LAT, int LON, int levels_reversed);
 
 /* Un-patchify + crop (reference layers.py:522-543):
  *   y_upper [7*H4*W4][160] col = v*32 + pz*16 + ph*4 + pw -> output [5][13][LAT][LON]
@@ -242,14 +246,6 @@ int pangu_window_attn_qkv_fwd_bf16(pangu_stream_t stream, const void* x, int ldx
                                    const void* esb, void* out, float* lse, int Z, int H, int W, int C, int heads,
                                    int shifted);
 
-/* The same operator (same arguments, same result) in its LONGITUDE-WALKING form: one persistent workgroup per (window type,
- * head) keeps that head's 96 linear1 rows in LDS (and, variant % 10 == 1, the wave's Earth-specific bias rows in registers) and
- * walks the nLon longitude windows that share them (reference layers.py:306-311: one bias per (type, head), broadcast over
- * longitude, :395).  variant = 10 * pipelines + bias_mode: 40, 30, 20 (bias rows re-read from L2 per window), 21, 11 (resident). */
-int pangu_window_attn_qkv_walk_fwd_bf16(pangu_stream_t stream, const void* x, int ldx, const void* w_qkv, const float* b_qkv,
-                                        const void* esb, void* out, float* lse, int Z, int H, int W, int C, int heads,
-                                        int shifted, int variant);
-
 int pangu_ln_residual_fwd_bf16(pangu_stream_t stream, const void* y, const void* shortcut, int lds, const float* gamma,
                                const float* beta, void* out, int ldo, int N, int C, float branch_scale);
 /* Projection + post-norm residual in one launch (inference path of layers.py:250-251):
@@ -291,7 +287,7 @@ int pangu_upsample_ln_fwd_bf16(pangu_stream_t stream, const void* y, const float
 int pangu_patch_embed_gather_bf16(pangu_stream_t stream, const float* input, const float* input_surface,
                                   const float* surface_mean, const float* surface_std, const float* upper_mean,
                                   const float* upper_std, const float* maps, const float* const_h, void* a_surface,
-                                  void* a_upper, int LAT, int LON);
+                                  void* a_upper, int LAT, int LON, int levels_reversed);
 
 /* bf16 backward (configs[2]): operands / saved activations / activation gradients bf16; parameter gradients,
  * statistics and all accumulation fp32 (they feed the fp32 master weights).  Semantics as the fp32 entry points. */
@@ -331,14 +327,31 @@ int pangu_shadow_refresh_bf16(pangu_stream_t stream, const void* jobs, int n_job
  * out / target: [B][Vu][plane_u] fp32 (plane_u = levels * H * W), out_surface / target_surface: [B][Vs][plane_s]; w_upper [Vu],
  * w_surface [Vs] device fp32.  fwd: `partial` = scratch of pangu_weighted_l1_loss_blocks(..) floats; loss[0] = the loss,
  * loss[1] / loss[2] = the two means.  bwd: grad = device scalar (d loss); d_out = sign(out - target) * ((grad / n) * w[var])
- * in the order torch's autograd multiplies (surface: grad * 0.25 first), sign(0) = 0. */
-long long pangu_weighted_l1_loss_blocks(int B, int Vu, long long plane_u, int Vs, long long plane_s);
+ * in the order torch's autograd multiplies (surface: grad * 0.25 first), sign(0) = 0.
+ * levels: the upper-air level count (plane_u % levels == 0): blocks never straddle a (sample, variable, level) plane.
+ * The target side of the loop body is folded in (no separate pass over the 286 MB target):
+ *   target_levels_reversed != 0: `target` is stored with its level axis in the file's (ascending) order (the reader's
+ *     `[::-1]`, era5_data/utils_data.py:117, becomes an address: logical level l = plane levels-1-l);
+ *   t_mean_upper / t_std_upper [Vu][levels] (logical level order), t_mean_surface / t_std_surface [Vs], all four or none:
+ *     the targets arrive in physical units and are normalised on the fly, (t - mean) / std -- `normData`,
+ *     era5_data/utils_data.py:315-321, called at models/pangu_sample.py:57.  NULL: the targets are already normalised. */
+long long pangu_weighted_l1_loss_blocks(int B, int Vu, long long plane_u, int Vs, long long plane_s, int levels);
 int pangu_weighted_l1_loss_fwd(pangu_stream_t stream, const float* out, const float* target, const float* out_surface,
                                const float* target_surface, const float* w_upper, const float* w_surface, float* partial,
-                               float* loss, int B, int Vu, long long plane_u, int Vs, long long plane_s);
+                               float* loss, int B, int Vu, long long plane_u, int Vs, long long plane_s, int levels,
+                               int target_levels_reversed, const float* t_mean_upper, const float* t_std_upper,
+                               const float* t_mean_surface, const float* t_std_surface);
 int pangu_weighted_l1_loss_bwd(pangu_stream_t stream, const float* out, const float* target, const float* out_surface,
                                const float* target_surface, const float* w_upper, const float* w_surface, const float* grad,
-                               float* d_out, float* d_out_surface, int B, int Vu, long long plane_u, int Vs, long long plane_s);
+                               float* d_out, float* d_out_surface, int B, int Vu, long long plane_u, int Vs, long long plane_s,
+                               int levels, int target_levels_reversed, const float* t_mean_upper, const float* t_std_upper,
+                               const float* t_mean_surface, const float* t_std_surface);
+
+/* Host side of the input pipeline (the idea of reference era5_data/utils_data.py:16-51 and the four
+ * `.to(device)` of models/pangu_sample.py:41-43): copy `bytes` from the loader's pageable memory into a page-locked staging
+ * buffer with up to `threads` host threads (each one contiguous 4 KB-aligned span; < 4 MB per thread is not split).  Pure
+ * host code, no stream, returns when the copy is complete. */
+int pangu_host_copy(void* dst, const void* src, long long bytes, int threads);
 
 /* Adam over a whole list of tensors in ONE launch (reference finetune_fully.py:121 torch.optim.Adam, stepped at
  * models/pangu_sample.py:75): p, grad, exp_avg, exp_avg_sq fp32, updated in place with the arithmetic of torch's fused Adam

@@ -1,6 +1,6 @@
 """Generate golden vectors by running the REFERENCE itself (build container only; needs /root/reference).
 
-TEST INFRASTRUCTURE. Usage:  python oracle/gen_golden.py [index] [blocks] [layers] [model] [model_bwd] [model_bwd_smooth] [extras] [rollout2] [rollout7] [keys_table] [refinit] [attn_windows]
+TEST INFRASTRUCTURE. Usage:  python oracle/gen_golden.py [index] [blocks] [layers] [model] [model_bwd] [model_bwd_smooth] [extras] [rollout2] [rollout7] [keys_table] [refinit] [attn_windows] [model_bwd_input] [autocast_grads] [autocast_rollout]
 Outputs small fixtures (fingerprints: samples + sums, index tensors, packed masks) under tests/golden/.
 Inputs and parameters are closed-form (oracle/synth.py), so tests regenerate them bit-identically.
 """
@@ -309,6 +309,96 @@ def gen_rollout(L, M, steps=2, name="rollout2.npz"):
     save(name, d)
 
 
+def gen_autocast(L, M, what=("rollout", "grads")):
+    """The REFERENCE's own bf16: the reference run under `torch.autocast("cpu", dtype=torch.bfloat16)` -- the
+    autocast its authors left commented out in models/pangu_sample.py:46-47 -- measured against the reference's fp32 goldens with
+    the SAME error metrics the GPU tests apply to the HIP bf16 path, so that those tests bound "HIP bf16 vs reference fp32" by a
+    multiple of "reference bf16 vs reference fp32" instead of by hand-picked constants.  Stored in tests/golden/autocast.npz:
+      rollout.step{k}.err          cases.compare_summary of step k's normalised upper-air output of the seven-step autocast rollout
+                                   (golden-spec weights, loop of gen_rollout) against rollout7.npz's fp32 fingerprints; step 1 is
+                                   the whole forward on the golden inputs
+      rollout.step{k}.err_surface  the same for the surface output
+      grads.sample_err / grads.norm_err   per parameter (named_parameters order): rel-L2 over the 256 stored samples and relative
+                                   norm error of the autocast smooth-loss gradients (refinit weights) against refinit.npz
+      grads.out_err, grads.loss    output-sample rel-L2 and the loss of that run
+    Commands:  python oracle/gen_golden.py autocast_rollout ; python oracle/gen_golden.py autocast_grads  (each merges into the file)"""
+    path = os.path.join(OUT, "autocast.npz")
+    d = dict(np.load(path)) if os.path.exists(path) else {}
+    if "rollout" in what:
+        g = np.load(os.path.join(OUT, "rollout7.npz"))
+        model = build_model(M).eval()
+        inp, inp_s, stats, maps, const_h = cases.model_inputs()
+        s_mean, s_std, u_mean, u_std = stats_last_of(stats)
+        up, sf = inp, inp_s
+        for k in range(7):
+            t = time.time()
+            with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+                out, out_s = model(up, sf, stats, maps, const_h)
+            out, out_s = out.float(), out_s.float()
+            e = cases.compare_summary(out, g, f"rollout.step{k + 1}.out", 1.0)
+            es = cases.compare_summary(out_s, g, f"rollout.step{k + 1}.out_surface", 1.0)
+            print("autocast rollout step %d ref %.1fs fingerprint err vs fp32 reference: %.3e (surface %.3e)" % (k + 1, time.time() - t, e, es),
+                  flush=True)
+            d[f"rollout.step{k + 1}.err"] = np.array([e], dtype=np.float64)
+            d[f"rollout.step{k + 1}.err_surface"] = np.array([es], dtype=np.float64)
+            up = out * u_std + u_mean
+            sf = out_s * s_std + s_mean
+        del model
+        np.savez_compressed(path, **d)
+    if "grads" in what:
+        g = np.load(os.path.join(OUT, "refinit.npz"))
+        torch.manual_seed(0)
+        model = M.PanguModel(device="cpu")
+        load_params(model, "", spec="refinit")
+        model.eval()
+        inp, inp_s, stats, maps, const_h = cases.model_inputs()
+        t = time.time()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            out, out_s = model(inp, inp_s, stats, maps, const_h)
+        out, out_s = out.float(), out_s.float()
+        loss = ((out * cases.cotangent("model_out", out.shape)).sum() +
+                (out_s * cases.cotangent("model_out_s", out_s.shape)).sum()) / out.numel()
+        loss.backward()
+        print("autocast refinit smooth fwd+bwd ref %.1fs loss %.8f (fp32 %.8f)" % (time.time() - t, loss.item(), float(g["model.loss"][0])),
+              flush=True)
+        se, ne = [], []
+        for k, p in model.named_parameters():
+            flat = p.grad.detach().float().flatten()
+            pos = synth.sample_positions(flat.numel(), cases.NSAMP, synth.name_seed("pos_model.d_" + k))[:256]
+            gs = torch.as_tensor(g[f"model.d_{k}.samples"]).double()
+            se.append(((flat[pos].double() - gs).norm() / gs.norm().clamp_min(1e-30)).item())
+            ne.append(abs(flat.double().norm().item() - float(g[f"model.d_{k}.l2"][0])) / float(g[f"model.d_{k}.l2"][0]))
+        pos = synth.sample_positions(out.numel(), cases.NSAMP, synth.name_seed("pos_model.out"))
+        go = torch.as_tensor(g["model.out.samples"]).double()
+        d["grads.sample_err"] = np.array(se)
+        d["grads.norm_err"] = np.array(ne)
+        d["grads.out_err"] = np.array([((out.detach().flatten()[pos].double() - go).norm() / go.norm()).item()])
+        d["grads.loss"] = np.array([loss.item()])
+        print("autocast grads: worst sample err %.3e median %.3e worst norm err %.3e out err %.3e" %
+              (max(se), sorted(se)[len(se) // 2], max(ne), float(d["grads.out_err"][0])), flush=True)
+        np.savez_compressed(path, **d)
+    print("wrote autocast.npz", sorted(d))
+
+
+def gen_model_input_grads(L, M):
+    """Gradients of the RAW FIELDS through the whole reference model (the reference's patch embedding is plain
+    autograd, models/layers.py:40-93, so `input.requires_grad_()` yields input.grad): smooth loss sum(out * cot) / numel on the
+    golden weights and inputs, fingerprints of d loss / d input and d loss / d input_surface -> model_bwd_input.npz."""
+    model = build_model(M).eval()
+    inp, inp_s, stats, maps, const_h = cases.model_inputs()
+    inp, inp_s = inp.requires_grad_(True), inp_s.requires_grad_(True)
+    t = time.time()
+    out, out_s = model(inp, inp_s, stats, maps, const_h)
+    loss = ((out * cases.cotangent("model_out", out.shape)).sum() +
+            (out_s * cases.cotangent("model_out_s", out_s.shape)).sum()) / out.numel()
+    loss.backward()
+    print("model input-gradient fwd+bwd ref %.1fs loss %.8f" % (time.time() - t, loss.item()))
+    d = {"model.loss": torch.tensor([loss.item()], dtype=torch.float64)}
+    d.update(cases.summarize(inp.grad, "model.d_input"))
+    d.update(cases.summarize(inp_s.grad, "model.d_input_surface"))
+    save("model_bwd_input.npz", d)
+
+
 def gen_keys_table(L, M):
     """The reference's torch_name -> onnx_name table (keys_all.csv, the lookup of models/onnx2torch.py:23-36) as a data
     fixture: 223 name pairs, no weights."""
@@ -379,3 +469,9 @@ if __name__ == "__main__":
         gen_refinit(L, M)
     if "attn_windows" in what:
         gen_attn_windows(L, M)
+    if "model_bwd_input" in what:
+        gen_model_input_grads(L, M)
+    if "autocast_rollout" in what:
+        gen_autocast(L, M, what=("rollout",))
+    if "autocast_grads" in what:
+        gen_autocast(L, M, what=("grads",))

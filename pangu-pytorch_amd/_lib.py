@@ -36,7 +36,6 @@ SIGNATURES = {
     "pangu_linear_fwd_bf16": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I],
     "pangu_window_attn_fwd_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I],
     "pangu_window_attn_qkv_fwd_bf16": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I],
-    "pangu_window_attn_qkv_walk_fwd_bf16": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I],
     "pangu_ln_residual_fwd_bf16": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _F],
     "pangu_linear_ln_residual_fwd_bf16": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
     "pangu_mlp_ln_residual_fwd_bf16": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F],
@@ -44,14 +43,15 @@ SIGNATURES = {
     "pangu_linear_gelu_bwd_bf16": [_P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P],
     "pangu_downsample_ln_fwd_bf16": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I],
     "pangu_upsample_ln_fwd_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I],
-    "pangu_patch_embed_gather_bf16": [_P] * 11 + [_I, _I],
+    "pangu_patch_embed_gather_bf16": [_P] * 11 + [_I, _I, _I],
     "pangu_linear_wgrad_bf16": [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I],
     "pangu_linear_wgrad_bf16_ws": [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _P, _c.c_longlong],
     "pangu_shadow_refresh_bf16": [_P, _P, _I, _c.c_longlong],
     "pangu_adam_step_multi": [_P, _P, _I, _c.c_longlong] + [_c.c_double] * 5 + [_F, _F],
-    "pangu_weighted_l1_loss_blocks": [_I, _I, _c.c_longlong, _I, _c.c_longlong],
-    "pangu_weighted_l1_loss_fwd": [_P] * 9 + [_I, _I, _c.c_longlong, _I, _c.c_longlong],
-    "pangu_weighted_l1_loss_bwd": [_P] * 10 + [_I, _I, _c.c_longlong, _I, _c.c_longlong],
+    "pangu_weighted_l1_loss_blocks": [_I, _I, _c.c_longlong, _I, _c.c_longlong, _I],
+    "pangu_weighted_l1_loss_fwd": [_P] * 9 + [_I, _I, _c.c_longlong, _I, _c.c_longlong, _I, _I] + [_P] * 4,
+    "pangu_weighted_l1_loss_bwd": [_P] * 10 + [_I, _I, _c.c_longlong, _I, _c.c_longlong, _I, _I] + [_P] * 4,
+    "pangu_host_copy": [_P, _P, _c.c_longlong, _I],
     "pangu_window_attn_bwd_bf16": [_P] * 10 + [_I] * 6,
     "pangu_ln_residual_bwd_bf16": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _F],
     "pangu_downsample_ln_bwd_bf16": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -63,10 +63,10 @@ SIGNATURES = {
     "pangu_attn_windows_bwd": [_P, _P, _P, _P, _c.c_longlong, _P, _P, _P, _I, _I, _I, _I],
     "pangu_ln_residual_fwd": [_P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _F],
     "pangu_linear_ln_residual_fwd": [_P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _F],
-    "pangu_mlp_ln_residual_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F],
     "pangu_downsample_ln_fwd": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I],
     "pangu_upsample_ln_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I],
-    "pangu_patch_embed_gather": [_P] * 11 + [_I, _I],
+    "pangu_patch_embed_gather": [_P] * 11 + [_I, _I, _I],
+    "pangu_patch_embed_gather_bwd": [_P] * 7 + [_I, _I, _I],
     "pangu_patch_recover_scatter": [_P, _P, _P, _P, _P, _I, _I],
     "pangu_patch_recover_scatter_denorm": [_P] * 11 + [_I, _I],
     "pangu_traffic_copy": [_P, _P, _P, _c.c_longlong, _I],

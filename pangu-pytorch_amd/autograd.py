@@ -149,27 +149,49 @@ class MlpFn(torch.autograd.Function):
         return ops.linear(dpre, _wt(w1)), dw1, db1, dw2, db2
 
 
+def refuse_constant_grads(maps, const_h, statistics=()):
+    """The constant operands of the patch embedding (maps, const_h, the normalisation statistics) get no gradient from this
+    build; asking for one must not return None silently."""
+    for name, t in (("maps", maps), ("const_h", const_h)) + tuple((f"statistics[{i}]", t) for i, t in enumerate(statistics)):
+        if torch.is_tensor(t) and t.requires_grad:
+            raise RuntimeError(f"PanguModel (MI355X build): {name}.requires_grad is set, but gradients with respect to the constant maps, "
+                               "const_h and the normalisation statistics are not implemented (input / input_surface are)")
+
+
 class PatchEmbedFn(torch.autograd.Function):
-    """reference models/layers.py:40-93 for one sample; the raw fields get no gradient."""
+    """reference models/layers.py:40-93 for one sample.  The raw fields get their gradient when they ask for it
+    (`input.requires_grad_()`, plain autograd in the reference): d_input = scatter-adjoint of the gather of (dx @ W) / std."""
 
     @staticmethod
-    def forward(ctx, cw, cb, sw, sb, inp, inp_s, s_mean, s_std, u_mean, u_std, maps, const_h):
-        a_s, a_u = ops.patch_embed_gather(inp, inp_s, s_mean, s_std, u_mean, u_std, maps, const_h)
+    def forward(ctx, cw, cb, sw, sb, inp, inp_s, s_mean, s_std, u_mean, u_std, maps, const_h, levels_reversed=False):
+        a_s, a_u = ops.patch_embed_gather(inp, inp_s, s_mean, s_std, u_mean, u_std, maps, const_h, levels_reversed)
         n_s = a_s.shape[0]
         x = torch.empty((n_s + a_u.shape[0], cw.shape[0]), dtype=torch.float32, device=inp.device)
         ops.linear(a_s, sw, sb, out=x[:n_s])
         ops.linear(a_u, cw, cb, out=x[n_s:])
-        ctx.save_for_backward(a_s, a_u)
-        ctx.shapes = (cw.shape, sw.shape)
+        ctx.save_for_backward(a_s, a_u, cw, sw, s_std, u_std)
+        ctx.shapes, ctx.geom = (cw.shape, sw.shape), (inp.shape[-2], inp.shape[-1], bool(levels_reversed))
         return x
 
     @staticmethod
     def backward(ctx, dx):
-        a_s, a_u = ctx.saved_tensors
+        a_s, a_u, cw, sw, s_std, u_std = ctx.saved_tensors
         n_s = a_s.shape[0]
-        dsw, dsb = ops.linear_wgrad(dx[:n_s], a_s)
-        dcw, dcb = ops.linear_wgrad(dx[n_s:], a_u)
-        return (dcw.reshape(ctx.shapes[0]), dcb, dsw.reshape(ctx.shapes[1]), dsb) + (None,) * 8
+        dx = dx.contiguous()
+        need = ctx.needs_input_grad
+        dsw = dsb = dcw = dcb = None
+        if any(need[:4]):
+            dsw, dsb = ops.linear_wgrad(dx[:n_s], a_s)
+            dcw, dcb = ops.linear_wgrad(dx[n_s:], a_u)
+            dcw, dsw = dcw.reshape(ctx.shapes[0]), dsw.reshape(ctx.shapes[1])
+        d_in = d_in_s = None
+        if need[4] or need[5]:
+            LAT, LON, rev = ctx.geom
+            # only the A-matrix columns with a field behind them: the first 64 of 112 (surface) / 160 of 192 (upper)
+            da_s = ops.linear(dx[:n_s], _wt(sw)[:64].contiguous())
+            da_u = ops.linear(dx[n_s:], _wt(cw)[:160].contiguous())
+            d_in, d_in_s = ops.patch_embed_gather_bwd(da_s, da_u, s_std, u_std, LAT, LON, rev)
+        return (dcw, dcb, dsw, dsb, d_in if need[4] else None, d_in_s if need[5] else None) + (None,) * 7
 
 
 class DownSampleFn(torch.autograd.Function):

@@ -126,24 +126,39 @@ class EarthBlockFnBF16(torch.autograd.Function):
 
 class PatchEmbedFnBF16(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, cw, cb, sw, sb, inp, inp_s, s_mean, s_std, u_mean, u_std, maps, const_h, sh):
-        a_s, a_u = ob.patch_embed_gather(inp, inp_s, s_mean, s_std, u_mean, u_std, maps, const_h)
+    def forward(ctx, cw, cb, sw, sb, inp, inp_s, s_mean, s_std, u_mean, u_std, maps, const_h, sh, levels_reversed=False):
+        a_s, a_u = ob.patch_embed_gather(inp, inp_s, s_mean, s_std, u_mean, u_std, maps, const_h, levels_reversed)
         n_s = a_s.shape[0]
         x = torch.empty((n_s + a_u.shape[0], cw.shape[0]), dtype=torch.bfloat16, device=inp.device)
         ob.linear(a_s, sh.get(sw, pad_k=128), sb, out=x[:n_s])
         ob.linear(a_u, sh.get(cw), cb, out=x[n_s:])
-        ctx.save_for_backward(a_s, a_u)
-        ctx.shapes = (cw.shape, sw.shape)
+        ctx.save_for_backward(a_s, a_u, s_std, u_std)
+        ctx.shapes, ctx.geom = (cw.shape, sw.shape), (inp.shape[-2], inp.shape[-1], bool(levels_reversed))
+        ctx.sh, ctx.params = sh, (cw, sw)
         return x
 
     @staticmethod
     def backward(ctx, dx):
-        a_s, a_u = ctx.saved_tensors
+        a_s, a_u, s_std, u_std = ctx.saved_tensors
         n_s = a_s.shape[0]
-        dsw, dsb = ob.linear_wgrad(dx[:n_s], a_s)                 # (192, 128): columns 112.. are padding
-        dcw, dcb = ob.linear_wgrad(dx[n_s:], a_u)
-        k_s = ctx.shapes[1][1]
-        return (dcw.reshape(ctx.shapes[0]), dcb, dsw[:, :k_s].reshape(ctx.shapes[1]), dsb) + (None,) * 9
+        need = ctx.needs_input_grad
+        dsw = dsb = dcw = dcb = None
+        if any(need[:4]):
+            dsw, dsb = ob.linear_wgrad(dx[:n_s], a_s)                 # (192, 128): columns 112.. are padding
+            dcw, dcb = ob.linear_wgrad(dx[n_s:], a_u)
+            k_s = ctx.shapes[1][1]
+            dcw, dsw = dcw.reshape(ctx.shapes[0]), dsw[:, :k_s].reshape(ctx.shapes[1])
+        d_in = d_in_s = None
+        if need[4] or need[5]:
+            # the raw fields asked for their gradient (reference layers.py:40-93 is plain autograd): dA for the columns with a field
+            # behind them (bf16 operands, fp32 result), then the fp32 scatter adjoint of the gather, divided by the std
+            LAT, LON, rev = ctx.geom
+            cw, sw = ctx.params
+            dx = dx.contiguous()
+            da_s = ob.linear(dx[:n_s], ctx.sh.get_t(sw)[:64].contiguous(), out_dtype=torch.float32)
+            da_u = ob.linear(dx[n_s:], ctx.sh.get_t(cw)[:160].contiguous(), out_dtype=torch.float32)
+            d_in, d_in_s = ops.patch_embed_gather_bwd(da_s, da_u, s_std, u_std, LAT, LON, rev)
+        return (dcw, dcb, dsw, dsb, d_in if need[4] else None, d_in_s if need[5] else None) + (None,) * 8
 
 
 class DownSampleFnBF16(torch.autograd.Function):
@@ -243,7 +258,7 @@ class PatchRecoverFnBF16(torch.autograd.Function):
         return d_skip, d_x, dcw.reshape(cw.shape), dcb, dsw.reshape(sw.shape), dsb, None, None, None
 
 
-def forward_train(model, inp, inp_surface, statistics, maps, const_h):
+def forward_train(model, inp, inp_surface, statistics, maps, const_h, levels_reversed=False):
     """Autograd-enabled bf16 forward of the whole model (B looped; the reference is B = 1 per rank)."""
     sh = model._shadow
     s_mean, s_std, u_mean, u_std = statistics
@@ -275,7 +290,7 @@ def forward_train(model, inp, inp_surface, statistics, maps, const_h):
     for b in range(B):
         x = PatchEmbedFnBF16.apply(emb.conv.weight, emb.conv.bias, emb.conv_surface.weight, emb.conv_surface.bias,
                                    inp[b].contiguous(), inp_surface[b].contiguous(), s_mean, s_std, u_mean, u_std, maps_c,
-                                   const_c, sh)
+                                   const_c, sh, levels_reversed)
         # skip connection (reference pangu_model.py:81): layer 0 / layer 3 write their results straight into the two halves of
         # one (N, 2C) buffer -- no concat copy, as in the inference path
         Nn, Cc = x.shape

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void patch_embed_gather_kernel(
     const float* __restrict__ input, const float* __restrict__ input_surface, const float* __restrict__ s_mean,
     const float* __restrict__ s_std, const float* __restrict__ u_mean, const float* __restrict__ u_std,
     const float* __restrict__ maps, const float* __restrict__ const_h, float* __restrict__ a_surface,
-    float* __restrict__ a_upper, int LAT, int LON, int H4, int W4, int chunks) {
+    float* __restrict__ a_upper, int LAT, int LON, int H4, int W4, int chunks, int levels_reversed) {
   constexpr int TLD = 196;               // tile row stride in floats: 16-B aligned, 8 tokens x 4 dwords cover the 32 banks
   __shared__ __attribute__((aligned(16))) float tile[EMB_TOK * TLD];
   const int chunk = blockIdx.x % chunks, h4 = (blockIdx.x / chunks) % H4, zp = blockIdx.x / (chunks * H4);
@@ -154,7 +154,9 @@ __global__ __launch_bounds__(256) void patch_embed_gather_kernel(
       valid = valid && lev < 13;
       if (valid) {
         if (c < 5) {
-          src = input + ((size_t)c * 13 + lev) * plane + (size_t)lat * LON;
+          // levels_reversed: the field is stored as the reader finds it on disk (level axis ascending) and the reversal of
+          // reference era5_data/utils_data.py:117 is this address -- logical level `lev` lives in plane 12 - lev
+          src = input + ((size_t)c * 13 + (levels_reversed ? 12 - lev : lev)) * plane + (size_t)lat * LON;
           mean = u_mean[(12 - lev) * 5 + c]; sd = u_std[(12 - lev) * 5 + c];
         } else {
           src = const_h + (size_t)lev * plane + (size_t)lat * LON;
@@ -181,6 +183,51 @@ __global__ __launch_bounds__(256) void patch_embed_gather_kernel(
   for (int i = tid; i < ntok * c4n; i += 256) {
     const int tk = i / c4n, c4 = i - tk * c4n;
     reinterpret_cast<f32x4*>(dst)[i] = *reinterpret_cast<const f32x4*>(&tile[tk * TLD + c4 * 4]);
+  }
+}
+
+// ---- patch embed gather, adjoint w.r.t. the raw fields ---------------------------------------------------------
+// d_input[c][lev][lat][lon] = da_upper[token][c*32 + pz*16 + ph*4 + pw] / upper_std(lev, c) and the surface twin: the transpose of
+// the gather above for the columns that came from `input` / `input_surface` -- the caller forms only those columns of dA (the
+// first 160 of 192 / 64 of 112: the constant maps, const_h and the zero padding have no field behind them) -- divided by the
+// std the forward divided by (autograd of `(x - mean) / std`, reference models/layers.py:48-55,71-76).  One workgroup per (plane zp, patch row h4, chunk of 64 patch columns), like the
+// gather; rows of da are read whole into LDS, the fields are written in 1 KB longitude runs.
+__global__ __launch_bounds__(256) void patch_embed_gather_bwd_kernel(
+    const float* __restrict__ da_surface, const float* __restrict__ da_upper, const float* __restrict__ s_std,
+    const float* __restrict__ u_std, float* __restrict__ d_input, float* __restrict__ d_input_surface, int LAT, int LON,
+    int H4, int W4, int chunks, int levels_reversed) {
+  __shared__ float tile[EMB_TOK * 161];
+  const int chunk = blockIdx.x % chunks, h4 = (blockIdx.x / chunks) % H4, zp = blockIdx.x / (chunks * H4);
+  const int w0 = chunk * EMB_TOK;
+  const int ntok = min(EMB_TOK, W4 - w0);
+  const int tid = threadIdx.x;
+  const int ncol = zp == 0 ? 64 : 160;        // the A-matrix columns that came from the fields (4 x 16 of 112, 5 x 32 of 192)
+  const float* src = zp == 0 ? da_surface + ((size_t)h4 * W4 + w0) * 64
+                             : da_upper + (((size_t)(zp - 1) * H4 + h4) * W4 + w0) * 160;
+  for (int i = tid; i < ntok * ncol; i += 256) {
+    const int tk = i / ncol, col = i - tk * ncol;
+    tile[tk * 161 + col] = src[i];
+  }
+  __syncthreads();
+  const size_t plane = (size_t)LAT * LON;
+  const int nrun = ncol / 4;
+  for (int run = tid >> 6; run < nrun; run += 4) {
+    int v, pz, ph;
+    if (zp == 0) { v = run >> 2; pz = 0; ph = run & 3; } else { v = run >> 3; pz = (run >> 2) & 1; ph = run & 3; }
+    const int lat = 4 * h4 + ph;
+    if (lat >= LAT) continue;
+    float* dst;
+    float sd;
+    if (zp == 0) {
+      dst = d_input_surface + v * plane + (size_t)lat * LON;
+      sd = s_std[v];
+    } else {
+      const int lev = 2 * (zp - 1) + pz;
+      if (lev >= 13) continue;
+      dst = d_input + ((size_t)v * 13 + (levels_reversed ? 12 - lev : lev)) * plane + (size_t)lat * LON;
+      sd = u_std[(12 - lev) * 5 + v];
+    }
+    for (int i = (tid & 63); i < 4 * ntok; i += 64) dst[4 * w0 + i] = tile[(i >> 2) * 161 + run * 4 + (i & 3)] / sd;
   }
 }
 
@@ -293,7 +340,8 @@ extern "C" int pangu_upsample_ln_fwd(pangu_stream_t stream, const float* y, cons
 extern "C" int pangu_patch_embed_gather(pangu_stream_t stream, const float* input, const float* input_surface,
                                         const float* surface_mean, const float* surface_std,
                                         const float* upper_mean, const float* upper_std, const float* maps,
-                                        const float* const_h, float* a_surface, float* a_upper, int LAT, int LON) {
+                                        const float* const_h, float* a_surface, float* a_upper, int LAT, int LON,
+                                        int levels_reversed) {
   if (!input || !input_surface || !surface_mean || !surface_std || !upper_mean || !upper_std || !maps || !const_h ||
       !a_surface || !a_upper)
     return PANGU_E_NULL;
@@ -301,7 +349,18 @@ extern "C" int pangu_patch_embed_gather(pangu_stream_t stream, const float* inpu
   const int H4 = (LAT + 3) / 4, W4 = LON / 4, chunks = (W4 + EMB_TOK - 1) / EMB_TOK;
   hipLaunchKernelGGL(patch_embed_gather_kernel, dim3(8 * H4 * chunks), dim3(256), 0, (hipStream_t)stream, input,
                      input_surface, surface_mean, surface_std, upper_mean, upper_std, maps, const_h, a_surface, a_upper,
-                     LAT, LON, H4, W4, chunks);
+                     LAT, LON, H4, W4, chunks, levels_reversed != 0);
+  return pangu_launch_status();
+}
+
+extern "C" int pangu_patch_embed_gather_bwd(pangu_stream_t stream, const float* da_surface, const float* da_upper,
+                                            const float* surface_std, const float* upper_std, float* d_input,
+                                            float* d_input_surface, int LAT, int LON, int levels_reversed) {
+  if (!da_surface || !da_upper || !surface_std || !upper_std || !d_input || !d_input_surface) return PANGU_E_NULL;
+  if (LAT <= 0 || LON <= 0 || (LON & 3)) return PANGU_E_SHAPE;
+  const int H4 = (LAT + 3) / 4, W4 = LON / 4, chunks = (W4 + EMB_TOK - 1) / EMB_TOK;
+  hipLaunchKernelGGL(patch_embed_gather_bwd_kernel, dim3(8 * H4 * chunks), dim3(256), 0, (hipStream_t)stream, da_surface,
+                     da_upper, surface_std, upper_std, d_input, d_input_surface, LAT, LON, H4, W4, chunks, levels_reversed != 0);
   return pangu_launch_status();
 }
 

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void patch_embed_gather_bf16_kernel(
     const float* __restrict__ input, const float* __restrict__ input_surface, const float* __restrict__ s_mean,
     const float* __restrict__ s_std, const float* __restrict__ u_mean, const float* __restrict__ u_std,
     const float* __restrict__ maps, const float* __restrict__ const_h, u16* __restrict__ a_surface,
-    u16* __restrict__ a_upper, int LAT, int LON, int H4, int W4, int chunks) {
+    u16* __restrict__ a_upper, int LAT, int LON, int H4, int W4, int chunks, int levels_reversed) {
   constexpr int TLD = 200;               // tile row stride in bf16: rows 16-B aligned
   __shared__ __attribute__((aligned(16))) u16 tile[EMB_TOK * TLD];
   const int chunk = blockIdx.x % chunks, h4 = (blockIdx.x / chunks) % H4, zp = blockIdx.x / (chunks * H4);
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void patch_embed_gather_bf16_kernel(
       valid = valid && lev < 13;
       if (valid) {
         if (c < 5) {
-          src = input + ((size_t)c * 13 + lev) * plane + (size_t)lat * LON;
+          src = input + ((size_t)c * 13 + (levels_reversed ? 12 - lev : lev)) * plane + (size_t)lat * LON;   // see rowops.hip
           mean = u_mean[(12 - lev) * 5 + c]; sd = u_std[(12 - lev) * 5 + c];
         } else {
           src = const_h + (size_t)lev * plane + (size_t)lat * LON;
@@ -457,7 +457,8 @@ extern "C" int pangu_upsample_ln_fwd_bf16(pangu_stream_t stream, const void* y, 
 extern "C" int pangu_patch_embed_gather_bf16(pangu_stream_t stream, const float* input, const float* input_surface,
                                              const float* surface_mean, const float* surface_std,
                                              const float* upper_mean, const float* upper_std, const float* maps,
-                                             const float* const_h, void* a_surface, void* a_upper, int LAT, int LON) {
+                                             const float* const_h, void* a_surface, void* a_upper, int LAT, int LON,
+                                             int levels_reversed) {
   if (!input || !input_surface || !surface_mean || !surface_std || !upper_mean || !upper_std || !maps || !const_h ||
       !a_surface || !a_upper)
     return PANGU_E_NULL;
@@ -465,6 +466,6 @@ extern "C" int pangu_patch_embed_gather_bf16(pangu_stream_t stream, const float*
   const int H4 = (LAT + 3) / 4, W4 = LON / 4, chunks = (W4 + EMB_TOK - 1) / EMB_TOK;
   hipLaunchKernelGGL(patch_embed_gather_bf16_kernel, dim3(8 * H4 * chunks), dim3(256), 0, (hipStream_t)stream, input,
                      input_surface, surface_mean, surface_std, upper_mean, upper_std, maps, const_h, (u16*)a_surface,
-                     (u16*)a_upper, LAT, LON, H4, W4, chunks);
+                     (u16*)a_upper, LAT, LON, H4, W4, chunks, levels_reversed != 0);
   return pangu_launch_status();
 }

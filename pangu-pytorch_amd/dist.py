@@ -80,7 +80,7 @@ class FlatGradSync:
     """
 
     def __init__(self, model, process_group=None, buckets=None, average=True, force_collective=False, mode="all_reduce",
-                 rehearse=None):
+                 rehearse=None, timing=False):
         """mode: "all_reduce" (default: one all_reduce(AVG) per bucket) or "reduce_scatter" (per bucket a reduce_scatter(AVG) into
         this rank's 1/world shard followed by an all_gather of the shards, both in place in the flat buffer: on the fully connected
         xGMI mesh every peer link carries 1/world of the bucket in each phase -- SURVEY section 5 -- instead of a ring's whole
@@ -92,6 +92,12 @@ class FlatGradSync:
         # launch also starts k device-to-device copies of the bucket on a side stream, each confined to n workgroups -- the HBM
         # traffic and CU footprint a real RCCL all-reduce of that bucket would put next to the remaining backward kernels
         self.rehearse = dict(rehearse) if rehearse else None
+        # timing: per bucket, an event pair (gradients complete on the compute stream = launch; the bucket's last collective done,
+        # recorded on a side stream that only ever waits for that collective) -- `bucket_times_ms()`; what an N > 1 bench line needs
+        # to explain its number (which buckets queue behind which, what the tail after the last backward kernel is)
+        self.timing = bool(timing)
+        self._tstream = None
+        self._tev = []             # (bucket index, launch event, done event) of the steps since the last bucket_times_ms()
         self._side = None
         self.group = process_group
         self.world = tdist.get_world_size(process_group) if tdist.is_initialized() else 1
@@ -104,9 +110,9 @@ class FlatGradSync:
         buckets = [b for b in buckets if b]
         assert sum(len(b) for b in buckets) == len(params), "buckets must cover every trainable parameter once"
         dev, dtype = params[0].device, params[0].dtype
-        # every bucket's length is a multiple of 4 * world elements (zero padding at its end): 16-B aligned bucket starts and, in
-        # "reduce_scatter" mode, equal 16-B aligned shards per rank
-        quantum = 4 * max(self.world, 1)
+        # every bucket's length is a multiple of (16 bytes / element size) * world elements (zero padding at its end): 16-B aligned
+        # bucket starts and, in "reduce_scatter" mode, equal 16-B aligned shards per rank -- for 2-byte parameters too
+        quantum = (16 // max(1, min(16, params[0].element_size()))) * max(self.world, 1)
         padded = lambda n: (n + quantum - 1) // quantum * quantum
         total = sum(padded(sum(p.numel() for p in b)) for b in buckets)
         self.flat = torch.zeros(total, dtype=dtype, device=dev)
@@ -175,6 +181,31 @@ class FlatGradSync:
                                                           int(self.rehearse.get("workgroups", 32))), "traffic_copy")
         if self.world == 1 and not self.force:
             return
+        n_before = len(self._works)
+        e0 = None
+        if self.timing and self._cuda:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self._launch_collective(bi)
+        if e0 is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            if self._gloo or len(self._works) == n_before:
+                # gloo (tests): works complete on host threads -- the done event is recorded by finish() after the host wait (or
+                # right here when the phases ran synchronously)
+                if len(self._works) == n_before:
+                    e1.record()
+                    self._tev.append((bi, e0, e1))
+                else:
+                    self._works[-1] = self._works[-1] + ((bi, e0, e1),)
+            else:
+                if self._tstream is None:
+                    self._tstream = torch.cuda.Stream(device=self.flat.device)
+                with torch.cuda.stream(self._tstream):
+                    self._works[-1][0].wait()          # stream-side wait: the side stream blocks until this bucket's last collective is done
+                    e1.record()
+                self._tev.append((bi, e0, e1))
+
+    def _launch_collective(self, bi):
         start, end, _ = self.buckets[bi]
         chunk = self.flat[start:end]
         if self.mode == "reduce_scatter":
@@ -208,10 +239,13 @@ class FlatGradSync:
             self._launch(bi)
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)      # the optimizer waits for the rehearsal "collectives" as it would for RCCL's
-        for work, chunk in self._works:
+        for work, chunk, *tev in self._works:
             work.wait()
             if chunk is not None:
                 chunk.div_(self.world)
+            if tev:                     # (gloo timing: the host wait above is the completion)
+                tev[0][2].record()
+                self._tev.append(tev[0])
         self._works = []
         self._fired = set()
         self._next = 0
@@ -219,6 +253,22 @@ class FlatGradSync:
         if self._cuda:
             for p in self._slot:
                 self._ops.release_grad_slot(p)
+
+    def bucket_times_ms(self):
+        """timing=True: per bucket, the mean over the steps since the last call of (launch -> its last collective done) in ms,
+        bucket 0 = the first one backward completes (the output layer); None for buckets never launched.  Synchronises the device."""
+        if not self._tev:
+            return None
+        torch.cuda.synchronize(self.flat.device)
+        acc = [[0.0, 0] for _ in self.buckets]
+        for bi, e0, e1 in self._tev:
+            acc[bi][0] += e0.elapsed_time(e1)
+            acc[bi][1] += 1
+        self._tev = []
+        return [a / n if n else None for a, n in acc]
+
+    def bucket_bytes(self):
+        return [(end - start) * self.flat.element_size() for start, end, _ in self.buckets]
 
     def zero_grad(self):
         """Zero the flat buffer in one memset; gradients stay views into it."""

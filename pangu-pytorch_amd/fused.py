@@ -41,13 +41,6 @@ def _tok2d(x):
 
 
 _FUSE_LN = os.environ.get("PANGU_F32_FUSE_LN", "1") != "0"       # A/B knob: 0 = separate GEMM + LN-residual launches
-# A/B knob: 1 = the whole MLP branch of the C = 192 blocks in ONE launch (csrc/mlp_fused_f32.hip: hidden activation on chip).  Built
-# and measured in round 5 (profiles/r05_mlp_f32_ab.md): parity-green, 2.59-2.75 ms against 2.46-2.50 ms for the two launches it
-# replaces (whole forward 67.6-68.0 vs 66.5 ms) -- on gfx950 the fp32 "matrix" rate IS the vector ALUs' rate, so the GELU's VALU work
-# costs matrix time whoever issues it, and one wave per SIMD cannot hide it behind other waves' MFMAs as the 4-5 resident GEMM
-# workgroups do.  Off by default.
-_FUSE_MLP = os.environ.get("PANGU_F32_FUSE_MLP", "0") == "1"
-
 
 def mlp(m, x2d):
     """Mlp.forward on its own (reference layers.py:264-270; the block never comes through here): differentiable."""
@@ -108,10 +101,7 @@ def earth_block(blk, x, Z, H, W, roll, out=None):
     # of layer 0 / 3 on the autograd path; a partially frozen fine-tune (nothing upstream of this block trains) lands here
     o2 = None if out is None else (out if out.dim() == 2 else _tok2d(out))
     if s2 != 0.0:
-        if _FUSE_MLP and C == 192:           # the whole MLP branch + post-norm residual in one launch: the hidden stays on chip
-            x2o = ops.mlp_ln_residual(x1, blk.linear.linear1.weight, blk.linear.linear1.bias, blk.linear.linear2.weight,
-                                      blk.linear.linear2.bias, blk.norm2.weight, blk.norm2.bias, out=o2, branch_scale=s2)
-        elif _FUSE_LN and C in (192, 384):
+        if _FUSE_LN and C in (192, 384):
             h = ops.linear(x1, blk.linear.linear1.weight, blk.linear.linear1.bias, act=ops.ACT_GELU)
             x2o = ops.linear_ln_residual(h, blk.linear.linear2.weight, blk.linear.linear2.bias, x1, blk.norm2.weight,
                                          blk.norm2.bias, out=o2, branch_scale=s2)
@@ -128,7 +118,7 @@ def earth_block(blk, x, Z, H, W, roll, out=None):
     return x2o.view(B, N, C)
 
 
-def patch_embed(m, inp, inp_surface, statistics, maps, const_h):
+def patch_embed(m, inp, inp_surface, statistics, maps, const_h, levels_reversed=False):
     """reference layers.py:40-93 -> (B, 8*181*360, 192)."""
     s_mean, s_std, u_mean, u_std = statistics
     B = inp.shape[0]
@@ -142,13 +132,13 @@ def patch_embed(m, inp, inp_surface, statistics, maps, const_h):
     u_mean, u_std = f32(u_mean).reshape(13, 5), f32(u_std).reshape(13, 5)
     maps_c = f32(maps).reshape(3, 4 * H4, LON)
     const_c = f32(const_h).reshape(13, LAT, LON)
-    if _train_path(m):
+    if _train_path(m, inp, inp_surface):
         return _stack([PatchEmbedFn.apply(m.conv.weight, m.conv.bias, m.conv_surface.weight, m.conv_surface.bias,
                                           inp[b].contiguous(), inp_surface[b].contiguous(), s_mean, s_std, u_mean,
-                                          u_std, maps_c, const_c) for b in range(B)], B)
+                                          u_std, maps_c, const_c, levels_reversed) for b in range(B)], B)
     for b in range(B):
         a_s, a_u = ops.patch_embed_gather(inp[b].contiguous(), inp_surface[b].contiguous(), s_mean, s_std, u_mean,
-                                          u_std, maps_c, const_c)
+                                          u_std, maps_c, const_c, levels_reversed)
         ops.linear(a_s, m.conv_surface.weight, m.conv_surface.bias, out=x[b, :n_s])
         ops.linear(a_u, m.conv.weight, m.conv.bias, out=x[b, n_s:])
     return x

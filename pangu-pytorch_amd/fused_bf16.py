@@ -233,7 +233,7 @@ def _layer(layer, sh, x, Z, H, W, out=None):
     return x
 
 
-def forward(model, inp, inp_surface, statistics, maps, const_h):
+def forward(model, inp, inp_surface, statistics, maps, const_h, levels_reversed=False):
     sh = model._shadow
     s_mean, s_std, u_mean, u_std = statistics
     B = inp.shape[0]
@@ -251,7 +251,7 @@ def forward(model, inp, inp_surface, statistics, maps, const_h):
     C = emb.conv.weight.shape[0]
     for b in range(B):
         a_s, a_u = ob.patch_embed_gather(inp[b].contiguous(), inp_surface[b].contiguous(), s_mean, s_std, u_mean, u_std,
-                                         maps_c, const_c)
+                                         maps_c, const_c, levels_reversed)
         x = torch.empty((N, C), dtype=torch.bfloat16, device=dev)
         ob.linear(a_s, sh.get(emb.conv_surface.weight, pad_k=128), emb.conv_surface.bias, out=x[:n_s])
         ob.linear(a_u, sh.get(emb.conv.weight), emb.conv.bias, out=x[n_s:])

@@ -89,8 +89,8 @@ class PatchEmbedding_pretrain(nn.Module):
         self.conv_surface = nn.Conv1d(in_channels=112, out_channels=dim, kernel_size=1, stride=1)
         self.window_size = WINDOW
 
-    def forward(self, input, input_surface, statistics, maps, const_h):
-        return fused.patch_embed(self, input, input_surface, statistics, maps, const_h)
+    def forward(self, input, input_surface, statistics, maps, const_h, levels_reversed=False):
+        return fused.patch_embed(self, input, input_surface, statistics, maps, const_h, levels_reversed)
 
 
 class Mlp(nn.Module):

@@ -2,6 +2,8 @@
 
 Every function requires CUDA(HIP) fp32 contiguous tensors and launches on torch's current stream.
 """
+import threading
+
 import torch
 
 from . import _lib
@@ -105,14 +107,28 @@ def _rows(t, name):
 #           straight into its flat data-parallel slot when there is one),
 #   "none"  what train.train_step selects around its own backward: it gives those parameters the zero-gradient step itself
 #           (HipAdam.step(missing_as_zero=True), dist.FlatGradSync) without materialising zeros.
-_dropped_grads = "zeros"
+_dropped_default = "zeros"
+_dropped_scopes = {"none": 0, "zeros": 0}      # active `dropped_branch_grads` scopes per mode (any thread)
+_dropped_lock = threading.Lock()
 
 
 def set_dropped_branch_grads(mode):
-    global _dropped_grads
+    """The process-wide default policy (outside any `dropped_branch_grads` scope)."""
+    global _dropped_default
     if mode not in ("none", "zeros"):
         raise ValueError("set_dropped_branch_grads: 'none' or 'zeros'")
-    _dropped_grads = mode
+    _dropped_default = mode
+
+
+def dropped_branch_policy():
+    """The policy in force: "zeros" while ANY "zeros" scope is active (always safe: it only materialises what the reference
+    materialises), else "none" while any "none" scope is active, else the default.  Scopes are COUNTED, not saved-and-restored:
+    two loops training two models from two threads may enter and leave in any order without leaving the process at "none"."""
+    if _dropped_scopes["zeros"]:
+        return "zeros"
+    if _dropped_scopes["none"]:
+        return "none"
+    return _dropped_default
 
 
 class dropped_branch_grads:
@@ -125,18 +141,18 @@ class dropped_branch_grads:
         self.mode = mode
 
     def __enter__(self):
-        global _dropped_grads
-        self.prev, _dropped_grads = _dropped_grads, self.mode
+        with _dropped_lock:
+            _dropped_scopes[self.mode] += 1
         return self
 
     def __exit__(self, *exc):
-        global _dropped_grads
-        _dropped_grads = self.prev
+        with _dropped_lock:
+            _dropped_scopes[self.mode] -= 1
 
 
 def fill_dropped_grads(g, like):
     """g: name -> gradient or None; like: name -> parameter of that shape.  Under the "zeros" policy every None becomes zeros."""
-    if _dropped_grads == "zeros":
+    if dropped_branch_policy() == "zeros":
         for k, p in like.items():
             if g.get(k) is None:
                 # matrices (`like` holds the parameter itself for every >= 2-D entry; vectors are shape stand-ins): with a
@@ -371,29 +387,6 @@ def linear_ln_residual(a, weight, bias, shortcut, gamma, beta, out=None, branch_
     return out
 
 
-def mlp_ln_residual(x, w1, b1, w2, b2, gamma, beta, out=None, branch_scale=1.0):
-    """out = x + branch_scale * (LayerNorm(GELU(x @ w1^T + b1) @ w2^T + b2) * gamma + beta) in ONE launch (C = 192 / 384; inference):
-    the (M, 4C) hidden activation never reaches memory.  x / out may be row-strided."""
-    lib = _lib.load()
-    xp, ldx = _rows(x, "mlp_ln.x")
-    M, C = x.shape
-    if tuple(w1.shape) != (4 * C, C) or tuple(w2.shape) != (C, 4 * C):
-        raise RuntimeError(f"mlp_ln_residual: x {tuple(x.shape)} w1 {tuple(w1.shape)} w2 {tuple(w2.shape)}")
-    if out is None:
-        out = torch.empty((M, C), dtype=torch.float32, device=x.device)
-    op, ldo = _rows(out, "mlp_ln.out")
-    chunks = _row_chunks(M, 4 * ldx, 4 * ldo)
-    if chunks is not None:
-        for m0, m1 in chunks:
-            mlp_ln_residual(x[m0:m1], w1, b1, w2, b2, gamma, beta, out[m0:m1], branch_scale)
-        return out
-    with _timed("mlp_fused", 16.0 * M * C * C):
-        _lib.check(lib.pangu_mlp_ln_residual_fwd(_stream(x), xp, ldx, _chk(w1, "w1"), _chk(b1, "b1"), _chk(w2, "w2"), _chk(b2, "b2"),
-                                                 _chk(gamma, "gamma"), _chk(beta, "beta"), op, ldo, M, C, float(branch_scale)),
-                   "mlp_ln_residual_fwd")
-    return out
-
-
 _WGRAD_WS_BYTES = 96 << 20
 _wgrad_ws = {}      # (device, stream) -> fp32 scratch buffer of the two-stage weight-gradient reduction (shared with ops_bf16)
 
@@ -610,8 +603,10 @@ def upsample_ln(y, gamma, beta, Z, H2, W2, H, want_stats=False):
     return (out, stats) if want_stats else out
 
 
-def patch_embed_gather(inp, inp_surface, s_mean, s_std, u_mean, u_std, maps, const_h):
-    """One sample: inp (5,13,LAT,LON), inp_surface (4,LAT,LON) -> (a_surface [H4*W4,112], a_upper [7*H4*W4,192])."""
+def patch_embed_gather(inp, inp_surface, s_mean, s_std, u_mean, u_std, maps, const_h, levels_reversed=False):
+    """One sample: inp (5,13,LAT,LON), inp_surface (4,LAT,LON) -> (a_surface [H4*W4,112], a_upper [7*H4*W4,192]).
+    levels_reversed: `inp` is stored with ascending levels (as on disk); the reader's reversal (reference
+    era5_data/utils_data.py:117) is done by the kernel's addressing."""
     lib = _lib.load()
     LAT, LON = inp.shape[-2], inp.shape[-1]
     H4, W4 = (LAT + 3) // 4, LON // 4
@@ -620,9 +615,25 @@ def patch_embed_gather(inp, inp_surface, s_mean, s_std, u_mean, u_std, maps, con
     _lib.check(lib.pangu_patch_embed_gather(_stream(inp), _chk(inp, "input"), _chk(inp_surface, "input_surface"),
                                             _chk(s_mean, "surface_mean"), _chk(s_std, "surface_std"),
                                             _chk(u_mean, "upper_mean"), _chk(u_std, "upper_std"), _chk(maps, "maps"),
-                                            _chk(const_h, "const_h"), a_s.data_ptr(), a_u.data_ptr(), LAT, LON),
-               "patch_embed_gather")
+                                            _chk(const_h, "const_h"), a_s.data_ptr(), a_u.data_ptr(), LAT, LON,
+                                            int(bool(levels_reversed))), "patch_embed_gather")
     return a_s, a_u
+
+
+def patch_embed_gather_bwd(da_s, da_u, s_std, u_std, LAT, LON, levels_reversed=False):
+    """Adjoint of patch_embed_gather w.r.t. the raw fields: da_s [H4*W4, 64], da_u [7*H4*W4, 160] fp32 (the A-matrix columns that
+    came from the fields) -> (d_input (5,13,LAT,LON), d_input_surface (4,LAT,LON)), each divided by the std the forward divided by
+    (autograd of reference models/layers.py:48-55,71-76)."""
+    lib = _lib.load()
+    H4, W4 = (LAT + 3) // 4, LON // 4
+    if da_s.shape != (H4 * W4, 64) or da_u.shape != (7 * H4 * W4, 160):
+        raise RuntimeError(f"patch_embed_gather_bwd: da_s {tuple(da_s.shape)} da_u {tuple(da_u.shape)} for {LAT}x{LON}")
+    d_in = torch.empty((5, 13, LAT, LON), dtype=torch.float32, device=da_u.device)
+    d_in_s = torch.empty((4, LAT, LON), dtype=torch.float32, device=da_u.device)
+    _lib.check(lib.pangu_patch_embed_gather_bwd(_stream(da_u), _chk(da_s, "da_surface"), _chk(da_u, "da_upper"),
+                                                _chk(s_std, "surface_std"), _chk(u_std, "upper_std"), d_in.data_ptr(),
+                                                d_in_s.data_ptr(), LAT, LON, int(bool(levels_reversed))), "patch_embed_gather_bwd")
+    return d_in, d_in_s
 
 
 _denorm_target = None      # (phys_upper (B,5,13,LAT,LON), phys_surface (B,4,LAT,LON), (u_mean, u_std, s_mean, s_std) flat fp32, [sample counter])

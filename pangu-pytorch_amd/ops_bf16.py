@@ -58,31 +58,11 @@ def window_attention(qkv, qkv_bias, esb, Z, H, W, heads, shifted, want_lse=False
     return (out, lse) if want_lse else out
 
 
-# A/B knob (read once): the longitude-walking form of the fused QKV attention; value = variant (10 * pipelines + bias mode), or
-# "C192:VA,C384:VB" per width; 0 / unset = the (window, head) kernel
-import os as _os
-
-
-def _walk_variants():
-    v = _os.environ.get("PANGU_ATTN_QKV_WALK", "").strip()
-    if not v or v == "0":
-        return {}
-    if ":" in v:
-        return {int(k.strip()[1:]): int(val) for k, val in (kv.split(":") for kv in v.split(","))}
-    return {192: int(v), 384: int(v)}
-
-
-_WALK = _walk_variants()
-
-
-def window_attention_qkv(x, w_qkv, b_qkv, esb, Z, H, W, heads, shifted, want_lse=False, variant=None):
+def window_attention_qkv(x, w_qkv, b_qkv, esb, Z, H, W, heads, shifted, want_lse=False):
     """Earth-specific window attention INCLUDING the QKV projection (reference layers.py:365-415 up to linear2): x (N, C)
     bf16 rows, w_qkv (3C, C) bf16, b_qkv (3C,) fp32, esb (types, heads, 144, 144) bf16 -> (N, C) bf16.  The qkv tensor is
-    never written.  variant: None = the default form for this width; 0 = the (window, head) kernel; 10 * pipelines + bias mode
-    = the longitude-walking kernel (csrc/attn_walk_bf16.hip)."""
+    never written.  (The longitude-walking form of this operator lost its A/B and lives in experiments/.)"""
     lib = _lib.load()
-    if variant is None:
-        variant = _WALK.get(x.shape[1], 0)
     xp, ldx = _rows(x, "attn_qkv.x")
     N, C = x.shape
     if N != Z * H * W or tuple(w_qkv.shape) != (3 * C, C) or x.dtype != torch.bfloat16:
@@ -90,12 +70,6 @@ def window_attention_qkv(x, w_qkv, b_qkv, esb, Z, H, W, heads, shifted, want_lse
     out = torch.empty((N, C), dtype=torch.bfloat16, device=x.device)
     lse = torch.empty((N, heads), dtype=torch.float32, device=x.device) if want_lse else None
     Np = (Z // 2) * ((H + 5) // 6) * (W // 12) * 144
-    if variant:
-        with _timed("attn_qkv_bf16", 4.0 * Np * 144 * C + 6.0 * Np * C * C):
-            _lib.check(lib.pangu_window_attn_qkv_walk_fwd_bf16(
-                _stream(x), xp, ldx, _p(w_qkv, "w_qkv"), _p(b_qkv, "b_qkv", torch.float32), _p(esb, "esb"), out.data_ptr(),
-                lse.data_ptr() if want_lse else None, Z, H, W, C, heads, int(shifted), int(variant)), "window_attn_qkv_walk_fwd_bf16")
-        return (out, lse) if want_lse else out
     with _timed("attn_qkv_bf16", 4.0 * Np * 144 * C + 6.0 * Np * C * C):
         _lib.check(lib.pangu_window_attn_qkv_fwd_bf16(_stream(x), xp, ldx, _p(w_qkv, "w_qkv"), _p(b_qkv, "b_qkv", torch.float32),
                                                       _p(esb, "esb"), out.data_ptr(), lse.data_ptr() if want_lse else None,
@@ -283,7 +257,7 @@ def upsample_ln(y, gamma, beta, Z, H2, W2, H):
     return out
 
 
-def patch_embed_gather(inp, inp_surface, s_mean, s_std, u_mean, u_std, maps, const_h):
+def patch_embed_gather(inp, inp_surface, s_mean, s_std, u_mean, u_std, maps, const_h, levels_reversed=False):
     lib = _lib.load()
     LAT, LON = inp.shape[-2], inp.shape[-1]
     H4, W4 = (LAT + 3) // 4, LON // 4
@@ -293,7 +267,8 @@ def patch_embed_gather(inp, inp_surface, s_mean, s_std, u_mean, u_std, maps, con
     _lib.check(lib.pangu_patch_embed_gather_bf16(_stream(inp), _p(inp, "input", f), _p(inp_surface, "input_surface", f),
                                                  _p(s_mean, "s_mean", f), _p(s_std, "s_std", f), _p(u_mean, "u_mean", f),
                                                  _p(u_std, "u_std", f), _p(maps, "maps", f), _p(const_h, "const_h", f),
-                                                 a_s.data_ptr(), a_u.data_ptr(), LAT, LON), "patch_embed_gather_bf16")
+                                                 a_s.data_ptr(), a_u.data_ptr(), LAT, LON, int(bool(levels_reversed))),
+               "patch_embed_gather_bf16")
     return a_s, a_u
 
 

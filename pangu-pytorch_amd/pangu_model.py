@@ -27,25 +27,33 @@ class _EvalRecomputeFn(torch.autograd.Function):
     nothing but its inputs (no 30 / 66 GB of saved activations, the fused inference launches instead of the activation-saving
     training ones); if a backward does arrive, it re-runs the forward on the autograd path and differentiates that: whole-model
     activation checkpointing -- what the reference does per block on every call (layers.py:115-119, `use_checkpoint` is always on).
-    Stochastic depth is off in eval(), so the two forwards see the same function."""
+    Stochastic depth is off in eval(), so the two forwards see the same function.  The two fields go through save_for_backward:
+    overwriting them in place between forward and backward (a rollout's static buffers) raises instead of differentiating a
+    different function; they get their gradients when they ask for them."""
 
     @staticmethod
-    def forward(ctx, model, args, *params):
-        # args = (input, input_surface, statistics, maps, const_h, want_bf16): the compute dtype is decided ONCE, here (an enclosing
+    def forward(ctx, model, consts, inp, inp_s, *params):
+        # consts = (statistics, maps, const_h, want_bf16, levels_reversed): the compute dtype is decided ONCE, here (an enclosing
         # autocast is not active any more when the backward runs)
-        ctx.model, ctx.args = model, args
+        ctx.model, ctx.consts = model, consts
+        ctx.save_for_backward(inp, inp_s)
+        statistics, maps, const_h, want_bf16, rev = consts
         with torch.no_grad():
-            return model._forward_dispatch(*args, grad_path=False)
+            return model._forward_dispatch(inp, inp_s, statistics, maps, const_h, want_bf16, False, rev)
 
     @staticmethod
     def backward(ctx, d_out, d_out_s):
         model = ctx.model
-        need = ctx.needs_input_grad[2:]
-        params = [p for p, n in zip(model.parameters(), need) if n]
+        inp, inp_s = ctx.saved_tensors
+        need_in, need = ctx.needs_input_grad[2:4], ctx.needs_input_grad[4:]
+        statistics, maps, const_h, want_bf16, rev = ctx.consts
+        fields = [t.detach().requires_grad_(n) for t, n in zip((inp, inp_s), need_in)]
+        wrt = [t for t, n in zip(fields, need_in) if n] + [p for p, n in zip(model.parameters(), need) if n]
         with torch.enable_grad():
-            out, out_s = model._forward_dispatch(*ctx.args, grad_path=True)
-        grads = iter(torch.autograd.grad((out, out_s), params, (d_out, d_out_s), allow_unused=True))
-        return (None, None) + tuple(next(grads) if n else None for n in need)
+            out, out_s = model._forward_dispatch(fields[0], fields[1], statistics, maps, const_h, want_bf16, True, rev)
+        grads = iter(torch.autograd.grad((out, out_s), wrt, (d_out, d_out_s), allow_unused=True))
+        g_in = tuple(next(grads) if n else None for n in need_in)
+        return (None, None) + g_in + tuple(next(grads) if n else None for n in need)
 
 
 class PanguModel(nn.Module):
@@ -179,8 +187,10 @@ class PanguModel(nn.Module):
         self._c_maps = torch.as_tensor(maps, dtype=torch.float32).to(dev)
         self._c_const_h = torch.as_tensor(const_h, dtype=torch.float32).to(dev)
 
-    def forward(self, input, input_surface, statistics=None, maps=None, const_h=None):
-        """reference pangu_model.py:50-87."""
+    def forward(self, input, input_surface, statistics=None, maps=None, const_h=None, levels_reversed=False):
+        """reference pangu_model.py:50-87.  levels_reversed (keyword, not in the reference): `input` is stored with its level axis
+        as on disk (ascending) and the reader's `[::-1]` (era5_data/utils_data.py:117) is done by the first kernel's addressing
+        instead of a host- or device-side flip of the 270 MB field (data.DevicePrefetcher(fuse_flip=True) delivers such batches)."""
         if statistics is None or maps is None or const_h is None:
             if self._c_maps is None:
                 raise TypeError("forward() needs statistics, maps, const_h (or call set_constants() first)")
@@ -199,29 +209,36 @@ class PanguModel(nn.Module):
             # an 8-GPU node driven from one process (or a caller that never called torch.cuda.set_device): every launch of this
             # forward goes to the INPUT's device and its current stream (ops._stream refuses anything else)
             with torch.cuda.device(input.device):
-                return self.forward(input, input_surface, statistics, maps, const_h)
-        grad_path = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+                return self.forward(input, input_surface, statistics, maps, const_h, levels_reversed)
+        # the autograd path runs when a parameter OR one of the two fields asks for a gradient (the reference's patch embedding is
+        # plain autograd, layers.py:40-93: `input.requires_grad_()` yields input.grad there); the constant operands are refused
+        grad_path = torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters())
+                                                 or input.requires_grad or input_surface.requires_grad)
+        if torch.is_grad_enabled():
+            from .autograd import refuse_constant_grads
+            refuse_constant_grads(maps, const_h, statistics)
         want_bf16 = self.compute_dtype == torch.bfloat16 or (
             torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+        rev = bool(levels_reversed)
         if grad_path and not self.training and getattr(self, "eval_grad_mode", "save") == "recompute":
-            return _EvalRecomputeFn.apply(self, (input, input_surface, statistics, maps, const_h, want_bf16), *self.parameters())
-        return self._forward_dispatch(input, input_surface, statistics, maps, const_h, want_bf16, grad_path)
+            return _EvalRecomputeFn.apply(self, (statistics, maps, const_h, want_bf16, rev), input, input_surface, *self.parameters())
+        return self._forward_dispatch(input, input_surface, statistics, maps, const_h, want_bf16, grad_path, rev)
 
-    def _forward_dispatch(self, input, input_surface, statistics, maps, const_h, want_bf16, grad_path):
+    def _forward_dispatch(self, input, input_surface, statistics, maps, const_h, want_bf16, grad_path, levels_reversed=False):
         if want_bf16:
             from . import autograd_bf16, fused_bf16
             if self._shadow is None:
                 self._shadow = fused_bf16.WeightShadow()
             if grad_path:
-                return autograd_bf16.forward_train(self, input, input_surface, statistics, maps, const_h)
-            return fused_bf16.forward(self, input, input_surface, statistics, maps, const_h)
+                return autograd_bf16.forward_train(self, input, input_surface, statistics, maps, const_h, levels_reversed)
+            return fused_bf16.forward(self, input, input_surface, statistics, maps, const_h, levels_reversed)
         if self._compact_bias and not grad_path:
             self._build_compact_bias()            # no-op while the tables exist (dropped with the weight shadows)
-        return self._forward_f32(input, input_surface, statistics, maps, const_h, grad_path)
+        return self._forward_f32(input, input_surface, statistics, maps, const_h, grad_path, levels_reversed)
 
-    def _forward_f32(self, input, input_surface, statistics, maps, const_h, grad_path):
+    def _forward_f32(self, input, input_surface, statistics, maps, const_h, grad_path, levels_reversed=False):
         B = input.shape[0]
-        x = self._input_layer(input, input_surface, statistics, maps, const_h)             # (B,521280,192)
+        x = self._input_layer(input, input_surface, statistics, maps, const_h, levels_reversed)             # (B,521280,192)
         N, C = x.shape[1], x.shape[2]
         # skip connection: layer 0 writes its result into the left half, layer 3 into the right half of one
         # (B,N,2C) buffer, so the channel concat of reference pangu_model.py:81 costs no copy

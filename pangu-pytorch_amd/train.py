@@ -31,57 +31,89 @@ def _weights_on(device, dtype):
     return w
 
 
-def _weighted_l1_loss_torch(output, output_surface, target, target_surface):
+def _weighted_l1_loss_torch(output, output_surface, target, target_surface, target_levels_reversed=False, stats_last=None):
+    if target_levels_reversed:
+        target = target.flip(-3)                       # the reader's `[::-1]` (reference era5_data/utils_data.py:117)
+    if stats_last is not None:
+        target, target_surface = norm_data(target, target_surface, stats_last)
     wu, ws = _weights_on(output.device, output.dtype)
     loss_surface = torch.mean(torch.abs(output_surface - target_surface) * ws)
     loss_upper = torch.mean(torch.abs(output - target) * wu)
     return loss_upper + loss_surface * 0.25
 
 
+_stats_flat = {}      # (ids of the four statistics tensors) -> (the tensors, their flat fp32 device copies)
+
+
+def _flat_stats(stats_last, device, Vu, L, Vs):
+    """stats_last = (s_mean (1,Vs,1,1), s_std, u_mean (1,Vu,L,1,1), u_std) -> four flat contiguous fp32 device tensors, converted
+    once per set of statistics tensors (they are constants of a training run)."""
+    key = tuple(id(t) for t in stats_last) + (str(device),)
+    hit = _stats_flat.get(key)
+    if hit is not None and all(a is b for a, b in zip(hit[0], stats_last)):
+        return hit[1]
+    s_mean, s_std, u_mean, u_std = stats_last
+    if u_mean.numel() != Vu * L or u_std.numel() != Vu * L or s_mean.numel() != Vs or s_std.numel() != Vs:
+        raise RuntimeError(f"weighted_l1_loss: stats_last shapes {[tuple(t.shape) for t in stats_last]} for {Vu} x {L} upper / {Vs} surface planes")
+    flat = tuple(t.detach().to(device=device, dtype=torch.float32).reshape(-1).contiguous() for t in (u_mean, u_std, s_mean, s_std))
+    if len(_stats_flat) > 8:
+        _stats_flat.clear()
+    _stats_flat[key] = (tuple(stats_last), flat)
+    return flat
+
+
 class WeightedL1LossFn(torch.autograd.Function):
     """The loss and its gradient as one HIP pass each (csrc/loss.hip): the torch expression reads / writes the 286 MB fields
-    fourteen times per step (0.9 ms); the forward here reads them once, the backward once more and writes the two gradients."""
+    fourteen times per step (0.9 ms); the forward here reads them once, the backward once more and writes the two gradients.
+    The target side of the reference's loop body is folded into the same two passes: `normData` of the targets
+    (era5_data/utils_data.py:315-321, called at models/pangu_sample.py:57) when `stats_last` is given, and the reader's level
+    reversal (utils_data.py:117) when the target arrives with ascending levels (`target_levels_reversed`)."""
 
     @staticmethod
-    def forward(ctx, output, output_surface, target, target_surface):
+    def forward(ctx, output, output_surface, target, target_surface, target_levels_reversed=False, stats_last=None):
         from . import _lib
-        from .ops import _stream
         lib = _lib.load()
         wu, ws = _weights_on(output.device, torch.float32)
         with torch.cuda.device(output.device):
-            return WeightedL1LossFn._forward(ctx, lib, wu, ws, output, output_surface, target, target_surface)
+            return WeightedL1LossFn._forward(ctx, lib, wu, ws, output, output_surface, target, target_surface,
+                                             bool(target_levels_reversed), stats_last)
 
     @staticmethod
-    def _forward(ctx, lib, wu, ws, output, output_surface, target, target_surface):
+    def _forward(ctx, lib, wu, ws, output, output_surface, target, target_surface, rev, stats_last):
         from . import _lib
         from .ops import _stream
-        B, Vu = output.shape[0], output.shape[1]
+        B, Vu, L = output.shape[0], output.shape[1], output.shape[2]
         Vs = output_surface.shape[1]
-        geom = (B, Vu, output[0, 0].numel(), Vs, output_surface[0, 0].numel())
+        geom = (B, Vu, output[0, 0].numel(), Vs, output_surface[0, 0].numel(), L)
         nblk = lib.pangu_weighted_l1_loss_blocks(*geom)
         if nblk <= 0:
             raise RuntimeError(f"weighted_l1_loss: unsupported shapes {tuple(output.shape)} {tuple(output_surface.shape)}")
+        st = _flat_stats(stats_last, output.device, Vu, L, Vs) if stats_last is not None else ()
+        sp = tuple(t.data_ptr() for t in st) if st else (None,) * 4
         partial = torch.empty((nblk,), dtype=torch.float32, device=output.device)
         loss = torch.empty((3,), dtype=torch.float32, device=output.device)
         _lib.check(lib.pangu_weighted_l1_loss_fwd(_stream(output), output.data_ptr(), target.data_ptr(), output_surface.data_ptr(),
                                                   target_surface.data_ptr(), wu.data_ptr(), ws.data_ptr(), partial.data_ptr(),
-                                                  loss.data_ptr(), *geom), "weighted_l1_loss_fwd")
-        ctx.save_for_backward(output, output_surface, target, target_surface)
-        ctx.geom = geom
+                                                  loss.data_ptr(), *geom, int(rev), *sp), "weighted_l1_loss_fwd")
+        ctx.save_for_backward(output, output_surface, target, target_surface, *st)
+        ctx.geom, ctx.rev = geom, rev
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
         from . import _lib
         from .ops import _stream
-        output, output_surface, target, target_surface = ctx.saved_tensors
+        output, output_surface, target, target_surface, *st = ctx.saved_tensors
         wu, ws = _weights_on(output.device, torch.float32)
         d_o, d_os = torch.empty_like(output), torch.empty_like(output_surface)
         g = g.to(torch.float32).contiguous()
-        _lib.check(_lib.load().pangu_weighted_l1_loss_bwd(
-            _stream(output), output.data_ptr(), target.data_ptr(), output_surface.data_ptr(), target_surface.data_ptr(),
-            wu.data_ptr(), ws.data_ptr(), g.data_ptr(), d_o.data_ptr(), d_os.data_ptr(), *ctx.geom), "weighted_l1_loss_bwd")
-        return d_o, d_os, None, None
+        sp = tuple(t.data_ptr() for t in st) if st else (None,) * 4
+        with torch.cuda.device(output.device):
+            _lib.check(_lib.load().pangu_weighted_l1_loss_bwd(
+                _stream(output), output.data_ptr(), target.data_ptr(), output_surface.data_ptr(), target_surface.data_ptr(),
+                wu.data_ptr(), ws.data_ptr(), g.data_ptr(), d_o.data_ptr(), d_os.data_ptr(), *ctx.geom, int(ctx.rev), *sp),
+                "weighted_l1_loss_bwd")
+        return d_o, d_os, None, None, None, None
 
 
 def _hip_loss_ok(output, output_surface, target, target_surface):
@@ -93,13 +125,15 @@ def _hip_loss_ok(output, output_surface, target, target_surface):
             and not target.requires_grad and not target_surface.requires_grad)
 
 
-def weighted_l1_loss(output, output_surface, target, target_surface):
+def weighted_l1_loss(output, output_surface, target, target_surface, target_levels_reversed=False, stats_last=None):
     """reference models/pangu_sample.py:61-67: mean(|o-t| * w_upper) + 0.25 * mean(|o_s-t_s| * w_surface).  Contiguous fp32
     fields on a HIP device take the two-pass HIP form (WeightedL1LossFn); anything else (other dtypes, CPU tensors of the
-    host-side tests, targets that need gradients) is the reference's own torch expression."""
+    host-side tests, targets that need gradients) is the reference's own torch expression.
+    stats_last: the targets are in physical units and are normalised first (`normData`, :57); target_levels_reversed: the upper-air
+    target is stored with ascending levels (as on disk) -- both are folded into the HIP passes."""
     if _hip_loss_ok(output, output_surface, target, target_surface):
-        return WeightedL1LossFn.apply(output, output_surface, target, target_surface)
-    return _weighted_l1_loss_torch(output, output_surface, target, target_surface)
+        return WeightedL1LossFn.apply(output, output_surface, target, target_surface, target_levels_reversed, stats_last)
+    return _weighted_l1_loss_torch(output, output_surface, target, target_surface, target_levels_reversed, stats_last)
 
 
 class HipAdam(torch.optim.Optimizer):
@@ -275,9 +309,7 @@ class GraphedTrainStep:
             out, out_s = self.model(inp, inp_s, *self.consts)
         finally:
             self.model.eval_grad_mode = mode
-        if self.stats_last is not None:
-            tgt, tgt_s = norm_data(tgt, tgt_s, self.stats_last)
-        loss = weighted_l1_loss(out, out_s, tgt, tgt_s)
+        loss = weighted_l1_loss(out, out_s, tgt, tgt_s, stats_last=self.stats_last)      # normData folded into the loss passes
         loss.backward()
         return loss.detach()
 
@@ -298,20 +330,34 @@ class GraphedTrainStep:
         return self.loss
 
 
-def train_step(model, optimizer, batch, statistics, maps, const_h, stats_last=None, grad_sync=None):
+def _owns_dropped_branches(grad_sync):
+    """True when `grad_sync` is a bound method of dist.FlatGradSync (its flat buffer holds a zero for every parameter whose
+    branch was dropped, and every rank launches every bucket whatever it drew)."""
+    from .dist import FlatGradSync
+    return isinstance(getattr(grad_sync, "__self__", None), FlatGradSync)
+
+
+def train_step(model, optimizer, batch, statistics, maps, const_h, stats_last=None, grad_sync=None, levels_reversed=False):
     """One optimisation step (reference pangu_sample.py:45-77). batch = (input, input_surface, target, target_surface).
     `grad_sync` (optional callable) runs between backward and optimizer.step(): the data-parallel gradient
-    all-reduce (the reference's intended `gather_grad`, era5_data/utils_dist.py:125-134)."""
+    all-reduce (the reference's intended `gather_grad`, era5_data/utils_dist.py:125-134).
+    `stats_last`: the targets are in physical units (`normData`, :57, folded into the loss kernel).
+    `levels_reversed`: input and target carry their level axis as on disk (ascending); the reader's reversal
+    (era5_data/utils_data.py:117) is done by the first / last kernel's addressing (data.DevicePrefetcher(fuse_flip=True)).
+
+    Dropped-branch contract: a DropPath-dropped branch is not computed here, so the backward leaves its parameters WITHOUT a
+    gradient and the arm that steps the optimizer hands them the reference's zero-gradient step (moments decay, weight decay
+    applies).  That holds for grad_sync=None and for a dist.FlatGradSync method (flat buffer: zeros are already there, every rank
+    launches every bucket).  Any OTHER grad_sync callable (e.g. dist.gather_grad, which all-reduces parameter by parameter and
+    skips `p.grad is None`) sees materialised ZERO gradients instead: ranks that drew different DropPath patterns would
+    otherwise issue different numbers of collectives (a hang) and the optimizer would skip those parameters."""
     inp, inp_s, tgt, tgt_s = batch
     optimizer.zero_grad(set_to_none=True)
-    out, out_s = model(inp, inp_s, statistics, maps, const_h)
-    if stats_last is not None:
-        tgt, tgt_s = norm_data(tgt, tgt_s, stats_last)
-    loss = weighted_l1_loss(out, out_s, tgt, tgt_s)
+    out, out_s = model(inp, inp_s, statistics, maps, const_h, levels_reversed=levels_reversed)
+    loss = weighted_l1_loss(out, out_s, tgt, tgt_s, target_levels_reversed=levels_reversed, stats_last=stats_last)
     from . import ops
-    # the three arms below hand the parameters of a DropPath-dropped branch their zero-gradient step themselves: the backward need
-    # not materialise the zeros (ops.dropped_branch_grads: "zeros" is the default for any OTHER loop, the reference's semantics)
-    with ops.dropped_branch_grads("none"):
+    lean = grad_sync is None or _owns_dropped_branches(grad_sync)
+    with ops.dropped_branch_grads("none" if lean else "zeros"):
         loss.backward()
     if grad_sync is not None:
         grad_sync()

@@ -58,9 +58,23 @@ def test_argument_validation_without_gpu():
     assert lib.pangu_error_string(-5) is not None
     assert lib.pangu_adam_step_multi(None, None, 3, 10, 1e-3, 0.9, 0.999, 0.0, 1e-8, 0.1, 0.03) == -2
     assert lib.pangu_adam_step_multi(None, P8, 3, 10, 1e-3, 1.0, 0.999, 0.0, 1e-8, 0.1, 0.03) == -4          # beta1 = 1
-    assert lib.pangu_weighted_l1_loss_blocks(1, 5, 13 * 721 * 1440, 4, 721 * 1440) == 5 * 1648 + 4 * 127
-    assert lib.pangu_weighted_l1_loss_fwd(None, P8, P8, P8, P8, P8, P8, None, P8, 1, 5, 100, 4, 100) == -2
-    assert lib.pangu_weighted_l1_loss_bwd(None, P8, P8, P8, P8, P8, P8, P8, P8, P8, 0, 5, 100, 4, 100) == -1
+    # blocks never straddle a (sample, variable, level) plane: (5 x 13 + 4) planes of 721 x 1440 -> 127 blocks each
+    assert lib.pangu_weighted_l1_loss_blocks(1, 5, 13 * 721 * 1440, 4, 721 * 1440, 13) == (5 * 13 + 4) * 127
+    assert lib.pangu_weighted_l1_loss_blocks(1, 5, 13 * 721 * 1440, 4, 721 * 1440, 11) == -1         # plane_u % levels != 0
+    assert lib.pangu_weighted_l1_loss_fwd(None, P8, P8, P8, P8, P8, P8, None, P8, 1, 5, 100, 4, 100, 1, 0, None, None, None, None) == -2
+    assert lib.pangu_weighted_l1_loss_bwd(None, P8, P8, P8, P8, P8, P8, P8, P8, P8, 0, 5, 100, 4, 100, 1, 0, None, None, None, None) == -1
+    assert lib.pangu_weighted_l1_loss_fwd(None, P8, P8, P8, P8, P8, P8, P8, P8, 1, 5, 100, 4, 100, 1, 0, P8, None, None, None) == -2   # statistics: all four or none
+    assert lib.pangu_patch_embed_gather_bwd(None, P8, P8, P8, P8, P8, None, 721, 1440, 0) == -2
+    assert lib.pangu_patch_embed_gather_bwd(None, P8, P8, P8, P8, P8, P8, 721, 1442, 0) == -1
+    # the host side of the input pipeline is plain host code: callable (and checked) without a GPU
+    import numpy as np
+    src = np.arange(3 * (1 << 20) + 13, dtype=np.float32)              # 12 MB + a ragged tail: three spans on three threads
+    dst = np.zeros_like(src)
+    assert lib.pangu_host_copy(dst.ctypes.data, src.ctypes.data, src.nbytes, 3) == 0 and np.array_equal(dst, src)
+    dst[:] = 0
+    assert lib.pangu_host_copy(dst.ctypes.data, src.ctypes.data, 1000, 64) == 0 and np.array_equal(dst[:250], src[:250]) and dst[250] == 0
+    assert lib.pangu_host_copy(dst.ctypes.data, None, 16, 1) == -2 and lib.pangu_host_copy(None, None, 0, 1) == 0
+    assert lib.pangu_host_copy(dst.ctypes.data, src.ctypes.data, -1, 1) == -1
     assert lib.pangu_shadow_refresh_bf16(None, None, 3, 10) == -2
     assert lib.pangu_shadow_refresh_bf16(None, P8, 0, 10) == -1
     assert lib.pangu_shadow_refresh_bf16(None, P8, 3, 1 << 31) == -1           # more blocks than a grid dimension holds

@@ -130,7 +130,10 @@ def test_bench_gpus_n_without_a_launcher_spawns_child_ranks_and_relays_failure()
 def test_eval_recompute_function_plumbs_gradients_like_plain_autograd():
     """pangu_model._EvalRecomputeFn on a stand-in module (CPU): the forward runs `_forward_dispatch(.., grad_path=False)` under no_grad
     and returns outputs that require grad; the backward re-runs it with grad_path=True and hands every trainable parameter the gradient
-    plain autograd gives, frozen parameters None -- also when only ONE of the two outputs is used by the loss."""
+    plain autograd gives, frozen parameters None -- also when only ONE of the two outputs is used by the loss; the two FIELDS get
+    their gradients when they ask for them, and overwriting a field in place between forward and backward raises
+    (the recompute would differentiate a different function)."""
+    import pytest
     import torch
     from pangu_pytorch_amd.pangu_model import _EvalRecomputeFn
 
@@ -142,16 +145,17 @@ def test_eval_recompute_function_plumbs_gradients_like_plain_autograd():
             self.frozen = torch.nn.Parameter(torch.tensor([3.0]), requires_grad=False)
             self.calls = []
 
-        def _forward_dispatch(self, x, xs, stats, maps, const_h, want_bf16, grad_path):
-            self.calls.append((grad_path, torch.is_grad_enabled()))
+        def _forward_dispatch(self, x, xs, stats, maps, const_h, want_bf16, grad_path, levels_reversed=False):
+            self.calls.append((grad_path, torch.is_grad_enabled(), levels_reversed))
             return (x * self.a).sin() * self.b + self.frozen, (xs * self.a.sum()).cos()
 
     m = Stub().eval()
     x, xs = torch.tensor([0.3, 0.7, -1.1]), torch.tensor([0.2, 0.9])
-    out, out_s = _EvalRecomputeFn.apply(m, (x, xs, None, None, None, False), *m.parameters())
-    assert m.calls == [(False, False)] and out.requires_grad and out_s.requires_grad
+    consts = (None, None, None, False, True)
+    out, out_s = _EvalRecomputeFn.apply(m, consts, x, xs, *m.parameters())
+    assert m.calls == [(False, False, True)] and out.requires_grad and out_s.requires_grad
     (out.sum() * 2.0 + (out_s ** 2).sum()).backward()
-    assert m.calls == [(False, False), (True, True)]
+    assert m.calls == [(False, False, True), (True, True, True)]
     got = [p.grad.clone() if p.grad is not None else None for p in m.parameters()]
     m.zero_grad(set_to_none=True)
     o, o_s = m._forward_dispatch(x, xs, None, None, None, False, True)
@@ -163,9 +167,25 @@ def test_eval_recompute_function_plumbs_gradients_like_plain_autograd():
             assert g is None and p.grad is None
     # one output unused: its cotangent is materialised as zeros
     m.zero_grad(set_to_none=True)
-    out, _ = _EvalRecomputeFn.apply(m, (x, xs, None, None, None, False), *m.parameters())
+    out, _ = _EvalRecomputeFn.apply(m, consts, x, xs, *m.parameters())
     out.sum().backward()
     ga = m.a.grad.clone()
     m.zero_grad(set_to_none=True)
     m._forward_dispatch(x, xs, None, None, None, False, True)[0].sum().backward()
     assert torch.allclose(ga, m.a.grad, rtol=1e-6, atol=1e-7)
+    # the fields' own gradients: only the one that asks gets one
+    m.zero_grad(set_to_none=True)
+    xg = x.clone().requires_grad_(True)
+    out, out_s = _EvalRecomputeFn.apply(m, consts, xg, xs, *m.parameters())
+    (out.sum() * 2.0 + (out_s ** 2).sum()).backward()
+    xr = x.clone().requires_grad_(True)
+    o, o_s = m._forward_dispatch(xr, xs, None, None, None, False, True)
+    (gx,) = torch.autograd.grad(o.sum() * 2.0 + (o_s ** 2).sum(), xr)
+    assert torch.allclose(xg.grad, gx, rtol=1e-6, atol=1e-7) and xs.grad is None
+    # a field overwritten in place before the backward: refused
+    m.zero_grad(set_to_none=True)
+    x2 = x.clone()
+    out, _ = _EvalRecomputeFn.apply(m, consts, x2, xs, *m.parameters())
+    x2.add_(1.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        out.sum().backward()

@@ -374,7 +374,7 @@ def test_dropped_branch_gradient_policy(P, dt):
     reference's autograd result, layers.py:250-251 -- branch computed, multiplied by zero -- so any optimizer of any foreign loop
     steps them as the reference does) and None under ops.dropped_branch_grads("none"), which train.train_step selects around its
     own backward (it gives those parameters the zero-gradient step without materialising zeros)."""
-    assert P.ops._dropped_grads == "zeros"                  # the drop-in default (VERDICT r4 item 2)
+    assert P.ops.dropped_branch_policy() == "zeros"                  # the drop-in default (VERDICT r4 item 2)
     C, roll, W = 192, False, 12
     st = cases.STAGES[C]
     blk = P.layers.EarthSpecificBlock(C, 0.2, st["heads"], device="cuda").cuda().train()

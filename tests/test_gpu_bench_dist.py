@@ -24,7 +24,7 @@ def test_bench_two_ranks_emits_ddp_keys():
     env = dict(os.environ, PANGU_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--train-steps", "1", "--no-bf16", "--no-cpu-baseline"]
+           "--train-steps", "1", "--no-bf16", "--no-cpu-baseline", "--no-fed"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -38,6 +38,10 @@ def test_bench_two_ranks_emits_ddp_keys():
         assert "error" not in e, e
         assert e["value"] > 0 and e["ms_per_step"] > 0 and e["exposed_allreduce_ms_per_step"] is not None
         assert abs(e["value"] - 2e3 / e["ms_per_step"]) < 1e-6 * e["value"]      # whole-job samples/s = ranks / step time
+        # the keys that explain an N > 1 number: 20 per-bucket launch -> done times, both collective modes
+        assert len(e["bucket_launch_to_done_ms"]) == 20 and all(t is not None for t in e["bucket_launch_to_done_ms"])
+        assert set(e["grad_sync_ab_ms_per_step"]) == {"all_reduce", "reduce_scatter"}
+    assert dd["resident_batch"] is True and "rccl_version" in dd and "xgmi_topology" in dd
     assert d["ddp_model"]["measured"] is False
     assert all(v["measured"] is False for v in d["ddp_model"]["allreduce_ms"].values())
     assert d["ddp_train"]["value"] == dd["fp32"]["value"]
@@ -51,7 +55,7 @@ def test_bench_gpus2_plain_invocation_launches_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(PANGU_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--train-steps", "1",
-           "--no-bf16", "--no-cpu-baseline", "--no-extras", "--grad-sync", "reduce_scatter"]
+           "--no-bf16", "--no-cpu-baseline", "--no-extras", "--no-fed", "--grad-sync", "reduce_scatter"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

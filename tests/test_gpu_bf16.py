@@ -266,39 +266,6 @@ def test_window_attention_qkv_fused_bf16(P, C, shifted):
     assert rel_err(got, two) < ROUND
 
 
-@pytest.mark.parametrize("variant", [40, 30, 20, 21, 11])
-@pytest.mark.parametrize("C", [192, 384])
-@pytest.mark.parametrize("shifted", [False, True])
-def test_window_attention_qkv_walk_bf16(P, C, shifted, variant):
-    """The longitude-walking form of the fused QKV attention (csrc/attn_walk_bf16.hip: one persistent workgroup per (window type,
-    head), linear1's rows resident in LDS, `variant // 10` window pipelines of three waves, variant % 10 == 1: bias rows resident
-    in registers -- reference layers.py:306-311,395: one bias per (type, head), broadcast over longitude) on SEVEN longitude
-    windows (every pipeline walks more than one window and they take unequal shares) == the oracle on the same bf16-rounded
-    operands, and == the (window, head) kernel bit for bit on the attention output (same tile code, same operand values)."""
-    from pangu_pytorch_amd import ops_bf16 as ob
-    st = cases.STAGES[C]
-    Z, H, W, heads = st["Z"], st["H"], 84, st["heads"]
-    N = Z * H * W
-    x = synth.uniform((N, C), 35, 1.5).to(BF)
-    w = synth.uniform((3 * C, C), 36, 1.5 / C ** 0.5).to(BF)
-    b = synth.uniform((3 * C,), 37, 0.5)
-    esb = synth.uniform((1, st["types"], heads, 144, 144), 38, 0.5).to(BF)
-    base, base_lse = ob.window_attention_qkv(x.cuda(), w.cuda(), b.cuda(), esb[0].cuda(), Z, H, W, heads, shifted, want_lse=True, variant=0)
-    got, lse = ob.window_attention_qkv(x.cuda(), w.cuda(), b.cuda(), esb[0].cuda(), Z, H, W, heads, shifted, want_lse=True, variant=variant)
-    torch.cuda.synchronize()
-    # q, k, v: the same MFMA chain over the same 32-channel steps, bias added after the chain instead of as its initial value
-    # (one fp32 rounding apart before the bf16 rounding of q / k / v): bf16-rounding-level agreement with the other kernel
-    assert rel_err(got, base) < ROUND and rel_err(lse, base_lse) < 2e-3
-    if variant in (40, 21):      # and against the oracle (the pad rows' q/k/v from the bf16-rounded bias, layers.py:192)
-        qkv = (x.double() @ w.double().t() + b.double()).to(BF)
-        ref, ref_lse = O.window_attention_core(qkv.float()[None], b.to(BF).float(), esb.float(), Z, H, W, heads, shifted)
-        assert rel_err(got, ref[0]) < ROUND
-        assert rel_err(lse, ref_lse[0]) < 2e-3
-    # every launch of the same inputs gives the same bits (the pipelines' rendezvous orders all LDS traffic)
-    again, _ = ob.window_attention_qkv(x.cuda(), w.cuda(), b.cuda(), esb[0].cuda(), Z, H, W, heads, shifted, want_lse=True, variant=variant)
-    assert torch.equal(again, got)
-
-
 @pytest.mark.parametrize("C", [192, 384])
 def test_ln_residual_bf16(P, C):
     from pangu_pytorch_amd import ops_bf16 as ob
@@ -690,9 +657,8 @@ def test_block_bf16_drift_within_2x_of_reference_autocast(P, golden_dir, C, roll
 
 def test_full_backward_smooth_bf16_refinit_vs_reference(P, golden_dir):
     """whole-model bf16 backward against the REFERENCE's fp32 autograd in the reference's initialisation
-    regime (tests/golden/refinit.npz): the loss, the output, and every one of the 223 gradient tensors -- worst tensor bounded
-    at 5.5e-2 rel-L2 over its stored samples (the O(1) non-contractive golden weights need 0.35: they amplify, this regime
-    does not)."""
+    regime (tests/golden/refinit.npz): the loss, the output, and every one of the 223 gradient tensors -- each bounded by 1.5x the
+    error the REFERENCE'S OWN CPU autocast(bfloat16) makes on that tensor (tests/golden/autocast.npz), not by a hand-picked constant."""
     g = np.load(os.path.join(golden_dir, "refinit.npz"))
     m = P.PanguModel(device="cuda").cuda().eval()
     m.load_state_dict(synth.fill_state_dict(cases.model_param_shapes(), "cuda", spec="refinit"))
@@ -717,16 +683,34 @@ def test_full_backward_smooth_bf16_refinit_vs_reference(P, golden_dir):
         go = torch.as_tensor(g["model.out.samples"]).double()
         return loss.item(), ((out.detach().flatten()[pos].cpu().double() - go).norm() / go.norm()).item(), res
 
-    # bf16 worst-tensor sample error: 5.02e-2 (median 1.19e-2) with the 16-B resampling LayerNorm kernels, which are the only arm
-    # since round 4 (compile-time constants in csrc/rowops_bf16.hip; the equally accurate generic kernels gave 4.4e-2 / 1.17e-2)
-    for dt, tol_s, tol_n, tol_o in ((torch.float32, 2e-3, 1e-3, 1e-4), (BF, 5.5e-2, 2e-2, 1.5e-2)):
-        loss, oerr, res = run(dt)
-        worst_s, worst_n = max(res), max((r[1], r[2]) for r in res)
-        med = sorted(r[0] for r in res)[len(res) // 2]
-        print(f"REFINIT {dt}: loss {loss:.8f} (reference {float(g['model.loss'][0]):.8f}), output rel-L2 {oerr:.2e}; gradient samples "
-              f"worst {worst_s[0]:.2e} ({worst_s[2]}), median {med:.2e}; gradient norm worst {worst_n[0]:.2e} ({worst_n[1]})")
-        assert oerr < tol_o and worst_s[0] < tol_s and worst_n[0] < tol_n
-        assert abs(loss - float(g["model.loss"][0])) < (2e-6 if dt == torch.float32 else 2e-5)
+    # fp32: absolute bounds.  bf16: the yardstick is the REFERENCE'S OWN bf16 -- the same forward + backward run by
+    # the reference under torch.autocast("cpu", dtype=torch.bfloat16) (models/pangu_sample.py:46-47, commented out there), its error
+    # against its own fp32 autograd stored PER TENSOR with this test's metrics (tests/golden/autocast.npz, oracle/gen_golden.py
+    # autocast_grads: sample error median 1.4e-2, worst 5.7e-1 on the LayerNorm parameters, which autocast reduces in bf16).
+    # Every HIP bf16 gradient tensor must be within 1.5x of the reference-autocast error OF THAT TENSOR (absolute floor for the
+    # tensors the reference's autocast happens to get nearly exactly), and so must the output.
+    ac = np.load(os.path.join(golden_dir, "autocast.npz"))
+    loss, oerr, res = run(torch.float32)
+    worst_s, worst_n = max(res), max((r[1], r[2]) for r in res)
+    print(f"REFINIT fp32: loss {loss:.8f} (reference {float(g['model.loss'][0]):.8f}), output rel-L2 {oerr:.2e}; gradient samples worst "
+          f"{worst_s[0]:.2e} ({worst_s[2]}); gradient norm worst {worst_n[0]:.2e} ({worst_n[1]})")
+    assert oerr < 1e-4 and worst_s[0] < 2e-3 and worst_n[0] < 1e-3 and abs(loss - float(g["model.loss"][0])) < 2e-6
+    loss, oerr, res = run(BF)
+    ref_s, ref_n, ref_o = ac["grads.sample_err"], ac["grads.norm_err"], float(ac["grads.out_err"][0])
+    assert len(ref_s) == len(res)
+    FLOOR_S, FLOOR_N = 2.5e-2, 1e-2
+    ratios = sorted(((r[0] / max(rs, 1e-30), r[0], rs, r[2]) for r, rs in zip(res, ref_s)), reverse=True)
+    med = sorted(r[0] for r in res)[len(res) // 2]
+    print(f"REFINIT bf16: loss {loss:.8f} (reference fp32 {float(g['model.loss'][0]):.8f}, reference autocast {float(ac['grads.loss'][0]):.8f}), "
+          f"output rel-L2 {oerr:.2e} (reference autocast {ref_o:.2e}); gradient samples worst {max(res)[0]:.2e} ({max(res)[2]}), median "
+          f"{med:.2e} (reference autocast worst {ref_s.max():.2e}, median {np.median(ref_s):.2e})")
+    print("largest HIP-bf16 / reference-autocast sample-error ratios:", [(f"{a:.2f}", f"{b:.1e}", f"{c:.1e}", k) for a, b, c, k in ratios[:6]])
+    bad = [(k, e, rs) for (e, _, k), rs in zip(res, ref_s) if e > max(1.5 * rs, FLOOR_S)]
+    bad_n = [(k, n, rn) for (_, n, k), rn in zip(res, ref_n) if n > max(1.5 * rn, FLOOR_N)]
+    assert not bad, bad
+    assert not bad_n, bad_n
+    assert oerr <= max(1.5 * ref_o, 1e-2)
+    assert abs(loss - float(g["model.loss"][0])) < 2e-5
 
 
 @pytest.mark.parametrize("s1,s2", [(0.0, 1.25), (1.25, 0.0), (1.25, 1.25), (1.0, 1.0)])

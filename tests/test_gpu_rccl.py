@@ -35,6 +35,19 @@ def test_bench_under_torchrun_one_rank_rccl():
     for tag in ("ddp_train", "ddp_train_bf16"):
         assert "error" not in res[tag], res[tag]
         assert res[tag]["loss"] == res[tag]["loss"]        # not NaN
+        # what makes a first N > 1 run self-explaining, through REAL RCCL calls: per-bucket launch -> done
+        # times from events on a side stream, and the other collective mode timed in the same invocation
+        bt = res[tag]["bucket_launch_to_done_ms"]
+        assert len(bt) == 20 and all(t is not None and t >= 0.0 for t in bt), bt
+        ab = res[tag]["grad_sync_ab"]
+        assert ab["all_reduce"]["ms_per_step"] > 0 and ab["reduce_scatter"]["ms_per_step"] > 0
+        assert len(ab["reduce_scatter"]["bucket_launch_to_done_ms"]) == 20
+        fed = res[tag]["train_fed_from_host"]
+        assert fed["fed_item_per_step_ms"] > 0 and fed["pipeline"]["levels_reversed_fused"] is True
+    dd = res["ddp_samples_per_s"]
+    assert dd["resident_batch"] is True and isinstance(dd["rccl_version"], str) and dd["rccl_version"][0].isdigit(), dd.get("rccl_version")
+    assert "xgmi_topology" in dd and ("error" in dd["xgmi_topology"] or dd["xgmi_topology"]["gpus"] >= 1)
+    assert dd["bf16"]["fed_from_host_value"] > 0 and set(dd["bf16"]["grad_sync_ab_ms_per_step"]) == {"all_reduce", "reduce_scatter"}
 
 
 def test_reduce_scatter_mode_on_a_one_rank_rccl_communicator():
@@ -49,7 +62,7 @@ def test_reduce_scatter_mode_on_a_one_rank_rccl_communicator():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--train-steps", "2",
-               "--no-cpu-baseline", "--no-bf16", "--no-extras", "--grad-sync", mode]
+               "--no-cpu-baseline", "--no-bf16", "--no-extras", "--no-fed", "--grad-sync", mode]
         r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
         res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])

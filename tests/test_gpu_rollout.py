@@ -108,10 +108,16 @@ def test_rollout_seven_steps_vs_reference_golden(setup, golden_dir):
         m.set_compute_dtype(torch.float32)
     errs_b = [cases.compare_summary(o, g, f"rollout.step{k + 1}.out", 1.0) for k, (o, _) in enumerate(hist_b)]
     print("bf16 7-step rollout, fingerprint error vs the reference per step:", ["%.2e" % e for e in errs_b])
-    # (max over samples / column sums / mass, relative to the largest reference value: the first two steps measured 0.05-0.08 in
-    # round 4; the goldens' O(1)-activation weights are not contractive, so one step's bf16 error is carried into the next)
+    # The yardstick is the REFERENCE'S OWN bf16: the same seven steps run by the reference under
+    # torch.autocast("cpu", dtype=torch.bfloat16) -- the switch its authors left commented out, models/pangu_sample.py:46-47 --
+    # measured with the same fingerprint metric against the same fp32 goldens (tests/golden/autocast.npz, oracle/gen_golden.py
+    # autocast_rollout: 2.0e-2 at step 1 growing to 2.8e-1 at step 7; these O(1)-activation weights are not contractive, one
+    # step's rounding is carried into the next).  The HIP bf16 rollout must stay within 1.5x of that at EVERY step (floor 3e-2).
+    ac = np.load(os.path.join(golden_dir, "autocast.npz"))
+    ref_b = [float(ac[f"rollout.step{k + 1}.err"][0]) for k in range(7)]
+    print("reference autocast-bf16 7-step rollout, same metric:              ", ["%.2e" % e for e in ref_b])
     assert all(torch.isfinite(o).all() for o, _ in hist_b)
-    assert all(e < 0.12 * (k + 1) for k, e in enumerate(errs_b)), errs_b
+    assert all(e <= max(1.5 * r, 3e-2) for e, r in zip(errs_b, ref_b)), (errs_b, ref_b)
 
 
 def test_rollout_7x24h_bf16_drift_bounds(setup, golden_dir):

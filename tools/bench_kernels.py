@@ -137,23 +137,6 @@ def gemm_ln():
         print(f"{name:12s} M={M:6d} N={N:4d} K={K:4d}  fused {ms:7.3f} ms {2.0 * M * N * K / ms / 1e9:6.1f} TF/s   | separate {ms2:7.3f} ms")
 
 
-def mlp_f32():
-    """The one-launch fp32 MLP branch (csrc/mlp_fused_f32.hip) vs the two launches it replaces, interleaved."""
-    for M, C, name in ((521280, 192, "s0"),):
-        x = torch.randn(M, C, device="cuda")
-        w1, b1 = torch.randn(4 * C, C, device="cuda") / C ** 0.5, torch.randn(4 * C, device="cuda")
-        w2, b2 = torch.randn(C, 4 * C, device="cuda") / (4 * C) ** 0.5, torch.randn(C, device="cuda")
-        g, be = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
-        out = torch.empty((M, C), device="cuda")
-        hbuf = torch.empty((M, 4 * C), device="cuda")
-        fl = 16.0 * M * C * C
-        for rnd in range(3):
-            ms = timeit(lambda: ops.mlp_ln_residual(x, w1, b1, w2, b2, g, be, out=out))
-            ms2 = timeit(lambda: ops.linear_ln_residual(ops.linear(x, w1, b1, act=ops.ACT_GELU, out=hbuf), w2, b2, x, g, be, out=out))
-            print(f"mlp_f32 {name} M={M} C={C}: fused {ms:7.3f} ms {fl / ms / 1e9:6.1f} TF/s ({fl / ms / 1e9 / 157.3:.3f} of peak)   | "
-                  f"two launches {ms2:7.3f} ms {fl / ms2 / 1e9:6.1f} TF/s")
-
-
 def gemm_ln_bf16():
     from pangu_pytorch_amd import ops_bf16 as ob
     bf = torch.bfloat16
@@ -217,19 +200,9 @@ def attn_qkv_bf16():
         Np = (Z // 2) * ((H + 5) // 6) * (W // 12) * 144
         fl = 4.0 * Np * 144 * C + 6.0 * Np * C * C
         for sh in (False, True):
-            ms = timeit(lambda: ob.window_attention_qkv(x, w, b, esb, Z, H, W, heads, sh, variant=0))
+            ms = timeit(lambda: ob.window_attention_qkv(x, w, b, esb, Z, H, W, heads, sh))
             ms2 = timeit(lambda: ob.window_attention(ob.linear(x, w, b), bb, esb, Z, H, W, heads, sh))
             print(f"attn_qkv_bf16 C={C} shifted={int(sh)}: fused {ms:7.3f} ms {fl / ms / 1e9:6.1f} TF/s   | qkv GEMM + attention {ms2:7.3f} ms")
-            # the longitude-walking form (csrc/attn_walk_bf16.hip), interleaved with the (window, head) kernel: two rounds
-            variants = [int(v) for v in os.environ.get("PANGU_WALK_VARIANTS", "40,30,20,21,11").split(",") if v]
-            for rnd in range(2):
-                row = []
-                for v in [0] + variants:
-                    try:
-                        row.append((v, timeit(lambda: ob.window_attention_qkv(x, w, b, esb, Z, H, W, heads, sh, variant=v))))
-                    except RuntimeError as e:
-                        row.append((v, float("nan")))
-                print(f"   walk A/B round {rnd}: " + "  ".join(f"v{v}: {t:6.3f}" for v, t in row))
 
 
 def attn_bwd():
@@ -288,5 +261,5 @@ def rows():
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
     {"gemm": lambda: gemm("--lib-compare" in sys.argv), "attn": attn, "attn_bwd": attn_bwd, "rows": rows,
-     "gemm_bf16": lambda: gemm_bf16("--lib-compare" in sys.argv), "attn_bf16": attn_bf16, "gemm_ln_bf16": gemm_ln_bf16, "mlp_fused": mlp_fused, "mlp_train": mlp_train, "attn_qkv_bf16": attn_qkv_bf16, "gemm_ln": gemm_ln, "mlp_f32": mlp_f32,
+     "gemm_bf16": lambda: gemm_bf16("--lib-compare" in sys.argv), "attn_bf16": attn_bf16, "gemm_ln_bf16": gemm_ln_bf16, "mlp_fused": mlp_fused, "mlp_train": mlp_train, "attn_qkv_bf16": attn_qkv_bf16, "gemm_ln": gemm_ln,
      "wgrad_bf16": lambda: wgrad(True), "wgrad": lambda: wgrad(False)}[what]()

@@ -12,4 +12,4 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACT
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE SQ_INSTS_VMEM_RD SQ_INSTS_SALU --output-format csv -d $O/p4 -- $P > $O/p4.log 2>&1
 echo "Counters per dispatch (mean; rocprofv3 --pmc passes of \`$P\`), kernels matching \"$F\":"
 echo
-python3 tools/pmc_walk_table.py $O "$F"
+python3 tools/pmc_counter_table.py $O "$F"

@@ -33,7 +33,7 @@ for DT in f32 bf16; do
 done
 python3 tools/pmc_train_table.py --json gpurun_out/pmc_train.json /tmp/trpmc_f32 /tmp/trpmc_bf16 2 && cp gpurun_out/pmc_train.json profiles/
 {
-  for sec in mlp_fused mlp_f32 mlp_train attn_qkv_bf16 attn_bf16 gemm_bf16 wgrad_bf16 gemm_ln_bf16 attn attn_bwd gemm wgrad; do
+  for sec in mlp_fused mlp_train attn_qkv_bf16 attn_bf16 gemm_bf16 wgrad_bf16 gemm_ln_bf16 attn attn_bwd gemm wgrad; do
     echo "## $sec"
     timeout 400 python3 tools/bench_kernels.py $sec --lib-compare 2>&1 | grep -v "amdgpu.ids"
   done
