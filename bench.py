@@ -327,6 +327,51 @@ def fed_from_host(model, opt, dev, consts, grad_sync, steps, rank):
     return res
 
 
+def bf16_roofline(fams, eager_ms):
+    """Per kernel family of the bf16 forward: live HIP-event launch times against the roof that BINDS it.
+      mlp       mlp_ln_residual_bf16_kernel (whole MLP branch, hidden on chip)                  -> bf16 MFMA peak
+      attn_qkv  window_attn_qkv_bf16_kernel (QKV projection + QK^T + bias + mask + softmax + PV) -> the SIMD's vector-issue port:
+                SQ_INSTS_VALU (wave-level, from the committed PMC pass) minus the MFMAs and the exps, x 4 issue cycles, + the exps
+                x 8, over 1024 SIMDs at the family's measured clock = the time the kernel cannot go below however idle the matrix pipe
+      gemm_ln   gemm_ln_residual_bf16_kernel (output projection + LayerNorm + residual)         -> HBM (6.29 TB/s achievable)
+      gemm      the plain projections (down / up-sampling, patch embed / recover)                -> HBM / MFMA ridge
+    fams: name -> (total ms, total algorithmic FLOP, launches) of the instrumented pass."""
+    pm_name = {"mlp": "mlp_fused", "attn_qkv": "attn_qkv", "gemm_ln": "gemm_ln", "gemm": "gemm"}
+    out = {"peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "hbm_achievable_GBps": ACHIEVABLE_HBM_GBS,
+           "timing": "HIP-event pairs around each launch in one more EAGER pass over the same K steps (the bf16 headline is the hipGraph replay)",
+           "eager_ms_per_step": eager_ms}
+    for name, (ms, flop, n) in fams.items():
+        if not n:
+            continue
+        traffic, busy, stale, commit = pmc_traffic("bf16", pm_name[name])
+        avg_ms = ms / n
+        ach = flop / (ms * 1e-3) / 1e12
+        e = {"launches": n, "avg_launch_ms": avg_ms, "algorithmic_flop_per_launch": flop / n, "achieved": ach,
+             "frac": ach / PEAK_BF16_MFMA_TFLOPS, "traffic": traffic, "traffic_stale": stale, "mfma_busy_frac_pmc": busy,
+             "hbm_floor_ms": traffic / (ACHIEVABLE_HBM_GBS * 1e9) * 1e3 if traffic else None, "bound": "mfma"}
+        if e["hbm_floor_ms"] and e["hbm_floor_ms"] > flop / n / (PEAK_BF16_MFMA_TFLOPS * 1e12) * 1e3:
+            e["bound"] = "hbm"
+            e["x_hbm_floor"] = avg_ms / e["hbm_floor_ms"]
+        if name == "attn_qkv":
+            try:
+                j = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_bf16.json")))["attn_qkv"]
+                v, clk = j["valu_insts_per_launch"], j["eff_clock_ghz"]
+                # per forward: 4 launches at C = 192 (6 heads, Np = 535680 padded tokens) and 12 at C = 384 (12 heads, Np = 138240);
+                # one v_exp per score and lane-row: scores / 64 wave-level instructions; MFMAs: v_mfma_f32_16x16x32_bf16 = 16384 FLOP
+                exps = (4 * _NP0 * 144 * 6 + 12 * _NP1 * 144 * 12) / 16 / 64
+                mfma = flop / n / 16384.0
+                cyc = ((v - mfma - exps) * 4.0 + exps * 8.0) / 1024.0
+                e.update(bound="valu", valu_issue_bound_ms=cyc / (clk * 1e6), valu_insts_per_launch=v, mfma_insts_per_launch=mfma,
+                         exp_insts_per_launch=exps, eff_clock_ghz=clk, x_valu_issue_bound=avg_ms / (cyc / (clk * 1e6)),
+                         valu_note="issue cycles per SIMD = ((SQ_INSTS_VALU - MFMAs - exps) x 4 + exps x 8) / 1024 SIMDs; "
+                                   "counters from profiles/pmc_traffic_bf16.json (stale flag as `traffic_stale`)")
+            except (OSError, KeyError, ValueError, ZeroDivisionError):
+                e.update(bound="valu", valu_issue_bound_ms=None,
+                         valu_note="profiles/pmc_traffic_bf16.json carries no SQ_INSTS_VALU pass (tools/pmc_traffic.sh)")
+        out[name] = e
+    return out
+
+
 def synthetic_inputs(dev, seed):
     """One synthetic ERA5-shaped sample, resident in HBM: upper-air (1,5,13,721,1440), surface (1,4,721,1440), O(1)
     values, non-trivial normalisation statistics, the three constant maps and const_h (reference pangu_model.py:60-66)."""
@@ -450,12 +495,19 @@ def main():
                       for hb, hf in zip(hist_b, hist_f)]
         del hist_b, hist_f
         times = [tg, tb, tr]
+        # per-family roofline of the bf16 forward: one more EAGER pass with HIP-event pairs around every launch
+        ops.timing_start()
+        for _ in range(args.steps):
+            step()
+        lin_ms, lin_flop, lin_n, fam = ops.timing_stop("linear_bf16", also=("attn_qkv_bf16", "linear_ln_bf16", "mlp_fused_bf16"))
+        bf16_roof = bf16_roofline({"gemm": (lin_ms, lin_flop, lin_n), "attn_qkv": fam["attn_qkv_bf16"], "gemm_ln": fam["linear_ln_bf16"],
+                                   "mlp": fam["mlp_fused_bf16"]}, tb / args.steps * 1e3)
         bf16_res = {"metric": "bf16 forward steps/s (bf16 activations+weights, fp32 LN/softmax/accumulate), hipGraph replay",
                     "value": world * args.steps / tg, "ms_per_step": tg / args.steps * 1e3,
                     "eager_ms_per_step": tb / args.steps * 1e3, "rel_l2_drift_vs_f32": drift,
                     "model_tflops": FWD_GFLOP_EXEC / (tg / args.steps * 1e3),
                     "frac_of_bf16_mfma_peak": FWD_GFLOP_EXEC / (tg / args.steps * 1e3) / 2500.0,
-                    "rollout_7x24h_ms": tr * 1e3, "rollout_rel_l2_drift_vs_f32_per_step": roll_drift}
+                    "rollout_7x24h_ms": tr * 1e3, "rollout_rel_l2_drift_vs_f32_per_step": roll_drift, "roofline": bf16_roof}
         model.set_compute_dtype(torch.float32)
         del out_b, gs
       except Exception as e:      # secondary metrics must never take the headline line down

@@ -152,8 +152,15 @@ __device__ __forceinline__ unsigned long long attn_stamp() {
 }
 #endif
 
+// Waves per SIMD the register allocator must leave room for (the second __launch_bounds__ argument).  2 = the compiler's free
+// choice (138-156 VGPRs -> three waves per SIMD, four 3-wave workgroups per CU); 4 = capped at 128 VGPRs (five workgroups per CU):
+// the round-6 A/B build (tools/ab_lib.sh, profiles/r06_attn_qkv_occ4_ab.md).
+#ifndef PANGU_ATTN_QKV_MIN_WAVES
+#define PANGU_ATTN_QKV_MIN_WAVES 2
+#endif
+
 template <bool SHIFTED, int C>
-__global__ __launch_bounds__(192, 2) void window_attn_qkv_bf16_kernel(const u16* __restrict__ x, int ldx,
+__global__ __launch_bounds__(192, PANGU_ATTN_QKV_MIN_WAVES) void window_attn_qkv_bf16_kernel(const u16* __restrict__ x, int ldx,
                                                                       const u16* __restrict__ wqkv,
                                                                       const float* __restrict__ bqkv,
                                                                       const u16* __restrict__ esb, u16* __restrict__ out,

@@ -51,10 +51,11 @@ def main(d, dtype):
                 if any(n in r["Kernel_Name"] for n in names):
                     agg[fam][r["Counter_Name"]] += float(r["Counter_Value"])
                     disp[fam][r["Counter_Name"]].add(r["Dispatch_Id"])
-    traced = collections.Counter()
+    traced, traced_ns = collections.Counter(), collections.Counter()
     for path in glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True):
         for r in csv.DictReader(open(path)):
             traced[r["Name"]] += int(r["Calls"])
+            traced_ns[r["Name"]] += float(r.get("TotalDurationNs") or 0.0)
     out, missing = {}, []
     for fam, (names, files) in fams.items():
         launched = sum(c for k, c in traced.items() if any(n in k for n in names))
@@ -69,12 +70,22 @@ def main(d, dtype):
                     "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
                     "mfma_busy_frac": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] * 128) if c["GRBM_GUI_ACTIVE"] else None,
                     "source_sha": source_sha(files), "sources": list(files)}
+        # issue-side counters (pass `valu`): wave-level vector-ALU instructions (MFMAs included) and waves per launch; the effective
+        # clock of the family = GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / the trace's duration of the same launches
+        ns = sum(t for k, t in traced_ns.items() if any(x in k for x in names))
+        if c.get("SQ_INSTS_VALU") and disp[fam]["SQ_INSTS_VALU"]:
+            nv = len(disp[fam]["SQ_INSTS_VALU"])
+            out[fam]["valu_insts_per_launch"] = c["SQ_INSTS_VALU"] / nv
+            out[fam]["waves_per_launch"] = c["SQ_WAVES"] / max(len(disp[fam]["SQ_WAVES"]), 1)
+        if ns > 0 and c["GRBM_GUI_ACTIVE"]:
+            out[fam]["avg_launch_us_in_trace"] = ns / launched / 1e3
+            out[fam]["eff_clock_ghz"] = (c["GRBM_GUI_ACTIVE"] / 8 / max(len(disp[fam]["GRBM_GUI_ACTIVE"]), 1)) / (ns / launched)
     try:
         commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     except OSError:
         commit = ""
     out["commit"] = commit or os.environ.get("PANGU_COMMIT", "unknown (the GPU box has no .git; see the profile's file name / git log)")
-    out["command"] = f"python3 tools/profile_fwd.py {dtype} 3   (rocprofv3 passes: FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; FETCH_SIZE x2)"
+    out["command"] = f"python3 tools/profile_fwd.py {dtype} 3   (rocprofv3 passes: FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE | SQ_INSTS_VALU SQ_WAVES; FETCH_SIZE x2)"
     print(json.dumps(out, indent=1))
     if missing:
         sys.stderr.write(f"kernel families without counters or not launched by the traced command: {missing}\n")
