@@ -311,7 +311,7 @@ def fed_from_host(model, opt, dev, consts, grad_sync, steps, rank):
     resident = [tuple(t.to(dev) for t in b) for b in host]
     res["resident_item_per_step_ms"] = timed([resident[i % 3] for i in range(n_warm + n)], True, True)
     del resident
-    pf = data.DevicePrefetcher(cyc, dev, flip_levels=True, fuse_flip=True, depth=2)
+    pf = data.DevicePrefetcher(cyc, dev, flip_levels=True, fuse_flip=True, depth=2, reuse_device_buffers=True)
     res["fed_free_running_ms"] = timed(pf, False, pf.levels_reversed)
     res["fed_item_per_step_ms"] = timed(pf, True, pf.levels_reversed)
     sync()

@@ -280,6 +280,26 @@ __global__ __launch_bounds__(192, PANGU_ATTN_QKV_MIN_WAVES) void window_attn_qkv
         const int row = (tile0 + i) * 16 + lq;
         fx[i] = *reinterpret_cast<const bf16x8*>(slot + row * ROWB + (((kk * 4 + lg) ^ fsw(row)) << 4));
       }
+#if PANGU_ATTN_QKV_MIN_WAVES >= 4
+      // register diet of the 128-VGPR build: the six weight fragments in three pairs instead of all at once (24 -> 8 registers)
+#pragma unroll
+      for (int rp = 0; rp < 3; ++rp) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int row = PANGU_WTOK + (2 * rp + h) * 16 + lq;
+          fw[h] = *reinterpret_cast<const bf16x8*>(slot + row * ROWB + (((kk * 4 + lg) ^ fsw(row)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int rt = 2 * rp + h;
+            if (rt < 4) acc[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[h], fx[i], acc[rt][i], 0, 0, 0);
+            else acc[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[i], fw[h], acc[rt][i], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#else
 #pragma unroll
       for (int rt = 0; rt < 6; ++rt) {
         const int row = PANGU_WTOK + rt * 16 + lq;
@@ -292,6 +312,7 @@ __global__ __launch_bounds__(192, PANGU_ATTN_QKV_MIN_WAVES) void window_attn_qkv
 #pragma unroll
         for (int rt = 4; rt < 6; ++rt) acc[rt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[i], fw[rt], acc[rt][i], 0, 0, 0);
       }
+#endif
     }
   }
 
@@ -336,11 +357,21 @@ __global__ __launch_bounds__(192, PANGU_ATTN_QKV_MIN_WAVES) void window_attn_qkv
 #ifdef PANGU_ATTN_STAMP
   const unsigned long long st3 = attn_stamp();
 #endif
+#if PANGU_ATTN_QKV_MIN_WAVES >= 4
+  // the 128-VGPR build: two key halves per tile, ONE bias row live (the next tile's row refills it half by half)
+  attn_tile_halves<SHIFTED, true>(Ks, Vt, qf[0], b0, bias_tile + (size_t)((tile0 + 1) * 16 + lq) * PANGU_WTOK, tile0 * 16 + lq, qtok[0],
+                                  lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
+  attn_tile_halves<SHIFTED, true>(Ks, Vt, qf[1], b0, bias_tile + (size_t)((tile0 + 2) * 16 + lq) * PANGU_WTOK, (tile0 + 1) * 16 + lq,
+                                  qtok[1], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
+  attn_tile_halves<SHIFTED, true>(Ks, Vt, qf[2], b0, nullptr, (tile0 + 2) * 16 + lq, qtok[2], lq, lg, zcut, hcut, kz_bits, kh_bits, out,
+                                  lse, C, heads, hd);
+#else
   const BiasRow b1 = load_bias_row(bias_tile, (tile0 + 1) * 16 + lq, lg);
   attn_tile<SHIFTED, true>(Ks, Vt, qf[0], b0, tile0 * 16 + lq, qtok[0], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
   b0 = load_bias_row(bias_tile, (tile0 + 2) * 16 + lq, lg);
   attn_tile<SHIFTED, true>(Ks, Vt, qf[1], b1, (tile0 + 1) * 16 + lq, qtok[1], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
   attn_tile<SHIFTED, true>(Ks, Vt, qf[2], b0, (tile0 + 2) * 16 + lq, qtok[2], lq, lg, zcut, hcut, kz_bits, kh_bits, out, lse, C, heads, hd);
+#endif
 #ifdef PANGU_ATTN_STAMP
   const unsigned long long st4 = attn_stamp();
   if (lane == 0 && (int)(blockIdx.x * 3 + wave) < STAMP_WAVES) {

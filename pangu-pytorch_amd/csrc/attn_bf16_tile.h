@@ -186,4 +186,151 @@ __device__ __forceinline__ void attn_tile(const unsigned char* Ks, const unsigne
 #endif
 }
 
+// The same tile in TWO HALVES of the keys with an online-softmax merge (round 6, the 128-VGPR / four-waves-per-SIMD build of the
+// fused QKV kernel: -DPANGU_ATTN_QKV_MIN_WAVES=4): half A = score tiles 0-3 (keys 0..63, PV k-steps 0, 1), half B = tiles 4-8
+// (keys 64..143, k-steps 2, 3 and the tail step).  20 score registers instead of 36; costs a second max reduction, one exp for
+// the rescale factor and nine multiplies per lane and tile.
+template <bool SHIFTED, bool VSWZ>
+__device__ __forceinline__ void attn_tile_halves(const unsigned char* Ks, const unsigned char* Vt, const bf16x8 qf,
+                                                 BiasRow& bias, const u16* __restrict__ next_brow, int qn, int qtok, int lq, int lg,
+                                                 bool zcut, bool hcut,
+                                                 unsigned long long kz_bits, unsigned long long kh_bits, u16* __restrict__ out,
+                                                 float* __restrict__ lse, int C, int heads, int hd) {
+  const float scale = 0.17677669529663687f, L2E = 1.4426950408889634f;
+  int lz = 0;
+  asm volatile("" : "+v"(lz));
+  const unsigned char* Ksq = Ks + lz;
+  const unsigned char* Vtq = Vt + lz;
+  unsigned long long cut = 0ull;
+  if (SHIFTED) {
+    if (zcut || hcut) {
+      const bool zq = qn >= 72, hq = ((qn / 12) % 6) < 3;
+      const unsigned long long zsel = zq ? ~kz_bits : kz_bits;
+      const unsigned long long hsel = hq ? ~kh_bits : kh_bits;
+      cut = (zcut ? zsel : 0ull) | (hcut ? hsel : 0ull);
+    }
+  }
+  f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+  float m_run = 0.f, sum = 0.f;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int j0 = half * 4, nj = half ? 5 : 4;              // score tiles j0 .. j0 + nj - 1
+    f32x4 s[5];
+#pragma unroll
+    for (int jj = 0; jj < 5; ++jj)
+      if (jj < nj) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ksq + kswz(key_of(j0 + jj, lq), lg));
+        s[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      }
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) {
+      const u32x4 bp = bias.p[2 * half + uu];
+      s[2 * uu][0] = fmaf(s[2 * uu][0], scale, bflo(bp[0]));
+      s[2 * uu][1] = fmaf(s[2 * uu][1], scale, bfhi(bp[0]));
+      s[2 * uu][2] = fmaf(s[2 * uu][2], scale, bflo(bp[1]));
+      s[2 * uu][3] = fmaf(s[2 * uu][3], scale, bfhi(bp[1]));
+      s[2 * uu + 1][0] = fmaf(s[2 * uu + 1][0], scale, bflo(bp[2]));
+      s[2 * uu + 1][1] = fmaf(s[2 * uu + 1][1], scale, bfhi(bp[2]));
+      s[2 * uu + 1][2] = fmaf(s[2 * uu + 1][2], scale, bflo(bp[3]));
+      s[2 * uu + 1][3] = fmaf(s[2 * uu + 1][3], scale, bfhi(bp[3]));
+    }
+    if (half) {
+      s[4][0] = fmaf(s[4][0], scale, bflo(bias.t[0]));
+      s[4][1] = fmaf(s[4][1], scale, bfhi(bias.t[0]));
+      s[4][2] = fmaf(s[4][2], scale, bflo(bias.t[1]));
+      s[4][3] = fmaf(s[4][3], scale, bfhi(bias.t[1]));
+    }
+    // the NEXT tile's bias row replaces this half's registers as soon as they are consumed (one row of bias registers live, not
+    // two: what lets the kernel stay under 128 VGPRs without spilling the prefetched row)
+    if (next_brow) {
+      if (!half) {
+        bias.p[0] = *reinterpret_cast<const u32x4*>(next_brow + 8 * lg);
+        bias.p[1] = *reinterpret_cast<const u32x4*>(next_brow + 32 + 8 * lg);
+      } else {
+        bias.p[2] = *reinterpret_cast<const u32x4*>(next_brow + 64 + 8 * lg);
+        bias.p[3] = *reinterpret_cast<const u32x4*>(next_brow + 96 + 8 * lg);
+        bias.t = *reinterpret_cast<const u32x2*>(next_brow + 128 + 4 * lg);
+      }
+    }
+    if (SHIFTED) {
+      if (zcut || hcut) {
+#pragma unroll
+        for (int jj = 0; jj < 5; ++jj)
+          if (jj < nj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if ((cut >> (4 * (j0 + jj) + r)) & 1ull) s[jj][r] += -100.0f;
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jj = 0; jj < 5; ++jj)
+      if (jj < nj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[jj][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (half) {
+      const float m_new = fmaxf(m_run, mx);
+      const float f = __builtin_amdgcn_exp2f((m_run - m_new) * L2E);     // rescale of half A's sums (<= 1)
+      o0 *= f;
+      o1 *= f;
+      sum *= f;
+      mx = m_new;
+    }
+    m_run = mx;
+    const float nmx = -mx * L2E;
+#pragma unroll
+    for (int jj = 0; jj < 5; ++jj)
+      if (jj < nj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(fmaf(s[jj][r], L2E, nmx));
+          s[jj][r] = e;
+          sum += e;                                          // per-lane partial sum: reduced once, after both halves
+        }
+    // PV k-steps of this half: u = 2 half + uu (8 consecutive keys per lane and step), and the tail step (4 keys) after half B
+#pragma unroll
+    for (int uu = 0; uu < 3; ++uu) {
+      if (uu == 2 && !half) break;
+      const int u = uu < 2 ? 2 * half + uu : 4;
+      u32x4 pb;
+      pb[0] = pack2(s[2 * uu][0], s[2 * uu][1]);
+      pb[1] = pack2(s[2 * uu][2], s[2 * uu][3]);
+      if (uu < 2) {
+        pb[2] = pack2(s[2 * uu + 1][0], s[2 * uu + 1][1]);
+        pb[3] = pack2(s[2 * uu + 1][2], s[2 * uu + 1][3]);
+      } else {
+        pb[2] = 0u; pb[3] = 0u;
+      }
+      const bf16x8 pf = __builtin_bit_cast(bf16x8, pb);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        u32x4 vq;
+        if (uu < 2) {
+          vq = *reinterpret_cast<const u32x4*>(Vtq + vt_off<VSWZ>(dt * 16 + lq, 32 * u + 8 * lg));
+        } else {
+          const u32x2 va = *reinterpret_cast<const u32x2*>(Vtq + vt_off<VSWZ>(dt * 16 + lq, 128 + 4 * lg));
+          vq = u32x4{va[0], va[1], 0u, 0u};
+        }
+        const bf16x8 vf = __builtin_bit_cast(bf16x8, vq);
+        if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o0, 0, 0, 0);
+        else o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o1, 0, 0, 0);
+      }
+    }
+  }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+  {
+    const auto r0 = __builtin_amdgcn_permlane16_swap(pack2(o0[0] * inv, o0[1] * inv), pack2(o1[0] * inv, o1[1] * inv), false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(pack2(o0[2] * inv, o0[3] * inv), pack2(o1[2] * inv, o1[3] * inv), false, false);
+    if (qtok >= 0) {
+      u16* dst = out + (size_t)qtok * C + hd * 32 + ((lg & 1) << 4) + ((lg >> 1) << 3);
+      *reinterpret_cast<u32x4*>(dst) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+      if (lse && lg == 0) lse[(size_t)qtok * heads + hd] = m_run + __logf(sum);
+    }
+  }
+}
+
 }  // namespace

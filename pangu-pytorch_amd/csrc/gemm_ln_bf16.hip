@@ -17,6 +17,12 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
+// Which widths take the persistent LDS-DMA kernel below (bit 0: N = 384, bit 1: N = 192); 0 = the register-staged kernel for both
+// (tools/ab_lib.sh builds the A/B libraries).
+#ifndef PANGU_GEMM_LN_DMA
+#define PANGU_GEMM_LN_DMA 3
+#endif
+
 constexpr int LBM = 128;
 constexpr int LBK = 64;
 constexpr float LN_EPS = 1e-5f;
@@ -185,6 +191,246 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_ln_residual_bf16_kernel(
   }
 }
 
+// ---- persistent LDS-DMA variant (round 6) ----------------------------------------------------------------------------
+// The kernel above owns one 128-row tile per workgroup and stages its operands through registers one K-step ahead: with K = C the
+// whole K-loop is 3-6 steps of ~770 MFMA cycles each, i.e. far shorter than one memory latency, and -- N = 384: 128 KB of LDS, ONE
+// workgroup per CU -- nothing overlaps a tile's prologue, its per-step load latencies and its epilogue: 22 us per tile, 1.84x the
+// HBM floor (profiles/r05_fwd_bf16_issue_table.md: 0.47 of the wave-cycles parked, MFMA busy 0.17).  Here the same tile, wave grid
+// and fragment reads run in a PERSISTENT workgroup whose operand ring never drains:
+//   * A and W travel L2/HBM -> LDS by LDS-DMA (buffer_load .. lds: no staging registers) in K-steps of 32 through a ring of RING
+//     slots; the requests of the NEXT tile's first RING-1 steps are issued under the current tile's last K-steps, so its epilogue
+//     (LayerNorm, residual, stores) runs with the next tile's operands already in flight;
+//   * the tile's 128 x N shortcut patch (the other HBM stream) is requested into registers at the tile's first K-step -- 12 16-B
+//     loads per thread in the layout the output rows leave in -- and is consumed by the epilogue one 16-row group at a time
+//     through a 3.3-KB per-wave LDS patch (26 KB instead of the 106 KB the tile-at-once epilogue needs);
+//   * every wait is a COUNTED s_waitcnt vmcnt(n): the in-order queue holds, per thread, LPS DMA requests per step, 12 shortcut
+//     loads and 12 output stores per tile at known positions.
+// LDS: RING x (128 + N) x 64 B ring + 2 WNW x 3328 B patches + 4 KB statistics (N = 384, RING = 3: 127 KB, one 8-wave workgroup
+// per CU; N = 192, RING = 3: 75 KB, two 4-wave workgroups per CU).
+constexpr int DBK = 32;
+
+__device__ inline int kswz64(int row, int chunk) {      // 64-byte rows, 4 chunks: F = {0,2,3,1}[(row>>2)&3]
+  const int f = (0x78 >> (((row >> 2) & 3) * 2)) & 3;
+  return row * 64 + ((chunk ^ f) << 4);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int WNW, int RING>
+__global__ __launch_bounds__(128 * WNW, 2) void gemm_ln_residual_bf16_dma_kernel(
+    const u16* __restrict__ A, int lda, const u16* __restrict__ W, const float* __restrict__ bias,
+    const u16* __restrict__ shortcut, const float* __restrict__ gamma, const float* __restrict__ beta, u16* __restrict__ out,
+    int ldo, int M, int K, int m_tiles) {
+  static_assert(RING == 3, "the counted waits below are written for a ring of three");
+  constexpr int NW = 2 * WNW;                              // waves
+  constexpr int BN = 96 * WNW;                             // = N
+  constexpr int ROWS = LBM + BN;
+  constexpr int STAGE = ROWS * 64;                         // bytes per ring slot
+  constexpr int LPS = ROWS / (16 * NW);                    // LDS-DMA instructions per wave and K-step (16 rows each)
+  static_assert(ROWS % (16 * NW) == 0, "whole DMA instructions per wave");
+  constexpr int EP_LD = 96 * 2 + 16;                       // bytes per patch row
+  constexpr int CPR = 12;                                  // 16-B chunks per patch row
+  constexpr int NS = 12;                                   // shortcut loads = output stores per thread and tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* ep = smem + RING * STAGE + (threadIdx.x >> 6) * (16 * EP_LD);
+  float* stats = reinterpret_cast<float*>(smem + RING * STAGE + NW * 16 * EP_LD);      // [2 wm][WNW][64 rows][sum, sumsq]
+  float* prm = stats + 2 * WNW * 64 * 2;                   // [bias | gamma | beta][N]: resident (72 registers per lane otherwise)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WNW, wn = wave % WNW;
+  const int lc = lane & 15, lg = lane >> 4;
+  const int wave_n0 = wn * 96;
+
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<u16*>(A), 0, (int)(((size_t)(M - 1) * lda + K) * sizeof(u16)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<u16*>(W), 0, (int)((size_t)BN * K * sizeof(u16)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      out, 0, (int)(((size_t)(M - 1) * ldo + BN) * sizeof(u16)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<u16*>(shortcut), 0, (int)((size_t)M * BN * sizeof(u16)), 0x00020000);
+
+  // DMA instruction q = i * NW + wave fills ring rows 16q .. 16q+15; this lane fills (row 16q + lane>>2, physical chunk lane&3)
+  // with the LOGICAL chunk (lane&3) ^ F(row) (source-side swizzle).  Rows < 128: A (tile-relative; the tile's byte offset is added
+  // to the VECTOR offset at issue time -- the descriptor's range check sees vector + immediate offsets only, and rows >= M must
+  // arrive as zeros), rows >= 128: W.
+  unsigned voff[LPS];
+#pragma unroll
+  for (int i = 0; i < LPS; ++i) {
+    const int row = 16 * (i * NW + wave) + (lane >> 2);
+    const int f = (0x78 >> (((row >> 2) & 3) * 2)) & 3;
+    const int c = (lane & 3) ^ f;
+    voff[i] = row < LBM ? ((unsigned)row * (unsigned)lda + c * 8) * 2u : ((unsigned)(row - LBM) * (unsigned)K + c * 8) * 2u;
+  }
+  const int KT = K / DBK;
+  // global step g = it * KT + kt of this workgroup's it-th tile
+  auto issue = [&](int g, int tile, int kt) {
+    unsigned char* base = smem + (g % RING) * STAGE;
+    const unsigned a_base = (unsigned)tile * (unsigned)(LBM * 2) * (unsigned)lda;      // < 2^32: checked by the launcher
+#pragma unroll
+    for (int i = 0; i < LPS; ++i) {
+      const int q = i * NW + wave;
+      auto dst = (__attribute__((address_space(3))) void*)(base + q * 1024);
+      if (16 * q < LBM) __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, dst, 16, (int)(voff[i] + a_base), kt * DBK * 2, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, dst, 16, (int)voff[i], kt * DBK * 2, 0, 0);
+    }
+  };
+
+  for (int c = tid; c < BN; c += 128 * WNW) {
+    prm[c] = bias ? bias[c] : 0.f;
+    prm[BN + c] = gamma[c];
+    prm[2 * BN + c] = beta[c];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the counted waits below see DMA / shortcut / store traffic only
+  __syncthreads();
+
+  int tile = blockIdx.x;
+  if (tile >= m_tiles) return;
+  issue(0, tile, 0);
+  if (KT > 1) issue(1, tile, 1);
+  bool first = true;
+  int g = 0;
+  for (; tile < m_tiles; tile += gridDim.x) {
+    const int next = tile + gridDim.x;
+    const bool has_next = next < m_tiles;
+    const int m0 = tile * LBM, wave_m0 = m0 + wm * 64;
+    f32x4 acc[4][6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) acc[i][j] = *reinterpret_cast<const f32x4*>(prm + wave_n0 + j * 16 + lg * 4);
+    u32x4 sc[NS];
+    for (int kt = 0; kt < KT; ++kt, ++g) {
+      // in-order queue of this thread at this point (oldest first), steady state:
+      //   kt = 0: DMA(kt) DMA(kt+1) stores(prev tile)            -> allow LPS + NS newer     (first tile: no stores)
+      //   kt = 1: DMA(1) stores(prev) DMA(2) shortcut            -> allow LPS + 2 NS         (first tile: LPS + NS)
+      //   kt = 2: DMA(2) shortcut DMA(3)                         -> allow NS + LPS
+      //   kt >= 3: DMA(kt) DMA(kt+1)                             -> allow LPS   (the very last step of the last tile: nothing newer)
+      const bool tail = !has_next && kt == KT - 1;
+      if (tail) wait_vmcnt<0>();
+      else if (kt == 0) { if (first) wait_vmcnt<LPS>(); else wait_vmcnt<LPS + NS>(); }
+      else if (kt == 1) { if (first) wait_vmcnt<LPS + NS>(); else wait_vmcnt<LPS + 2 * NS>(); }
+      else if (kt == 2) wait_vmcnt<LPS + NS>();
+      else wait_vmcnt<LPS>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's fragment reads of step g-1 have returned
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();                            // step g landed for every wave; slot (g-1) % RING is free
+      asm volatile("" ::: "memory");
+      if (kt + 2 < KT) issue(g + 2, tile, kt + 2);
+      else if (has_next) issue(g + 2, next, kt + 2 - KT);
+      if (kt == 0) {
+        // shortcut patch [64 rows][96 columns] of this wave, 16-B chunks in the order the output rows leave in (rows >= M: zeros)
+#pragma unroll
+        for (int it = 0; it < NS; ++it) {
+          const int f = lane + 64 * it, row = f / CPR, ch = f - row * CPR;
+          const unsigned off = ((unsigned)(wave_m0 + row) * (unsigned)BN + (unsigned)(wave_n0 + ch * 8)) * 2u;
+          sc[it] = __builtin_amdgcn_raw_buffer_load_b128(s_rsrc, (int)off, 0, 0);
+        }
+      }
+      const unsigned char* As = smem + (g % RING) * STAGE;
+      const unsigned char* Ws = As + LBM * 64;
+      bf16x8 fa[4], fw[6];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(As + kswz64(wm * 64 + i * 16 + lc, lg));
+#pragma unroll
+      for (int j = 0; j < 6; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(Ws + kswz64(wn * 96 + j * 16 + lc, lg));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);   // D[n][m]
+    }
+    first = false;
+
+    // ---- epilogue.  lane (lg, lc) of tile (i, j) holds y[m = wm*64 + 16i + lc][n = wn*96 + 16j + 4lg + r] (bias included)
+    // (the compiler guards each group's first use of the shortcut registers with vmcnt(9..11): in the in-order queue that is a
+    // wait for the OLDEST of the next tile's operand requests from the third group on -- requests issued two K-steps and half an
+    // epilogue earlier; forcing the registers "landed" inside the K-loop costs a full vmcnt(0) there instead, which is worse)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s += acc[i][j][r];
+          q = fmaf(acc[i][j][r], acc[i][j][r], q);
+        }
+      s += __shfl_xor(s, 16, 64);
+      q += __shfl_xor(q, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      q += __shfl_xor(q, 32, 64);
+      if (lg == 0) {
+        float* st = stats + (((wm * WNW + wn) * 64) + i * 16 + lc) * 2;
+        st[0] = s;
+        st[1] = q;
+      }
+    }
+    // (a raw barrier: __syncthreads() would also wait for the next tile's operand requests -- vmcnt(0); the statistics went
+    // through LDS only, and the next tile's statistics are >= KT barriers away)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    constexpr float INV_C = 1.0f / BN;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < WNW; ++w) {
+        const float* st = stats + (((wm * WNW + w) * 64) + i * 16 + lc) * 2;
+        s += st[0];
+        q += st[1];
+      }
+      const float mean = s * INV_C;
+      const float rstd = rsqrtf(fmaxf(q * INV_C - mean * mean, 0.f) + LN_EPS);
+      // the group's shortcut rows -> patch (the previous group's read-back must have returned: same wave, LDS in order)
+#pragma unroll
+      for (int it = 0; it < 3; ++it) {
+        const int f = lane + 64 * it, row = f / CPR, ch = f - row * CPR;
+        *reinterpret_cast<u32x4*>(ep + row * EP_LD + ch * 16) = sc[3 * i + it];
+      }
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        unsigned char* slot = ep + lc * EP_LD + (j * 16 + lg * 4) * 2;
+        const u32x2 xp = *reinterpret_cast<const u32x2*>(slot);
+        const f32x4 gj = *reinterpret_cast<const f32x4*>(prm + BN + wave_n0 + j * 16 + lg * 4);
+        const f32x4 bj = *reinterpret_cast<const f32x4*>(prm + 2 * BN + wave_n0 + j * 16 + lg * 4);
+        f32x4 v = (acc[i][j] - mean) * rstd * gj + bj;
+        v[0] += __builtin_bit_cast(float, xp[0] << 16);
+        v[1] += __builtin_bit_cast(float, xp[0] & 0xFFFF0000u);
+        v[2] += __builtin_bit_cast(float, xp[1] << 16);
+        v[3] += __builtin_bit_cast(float, xp[1] & 0xFFFF0000u);
+        *reinterpret_cast<u32x2*>(slot) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+      }
+#pragma unroll
+      for (int it = 0; it < 3; ++it) {
+        const int f = lane + 64 * it, row = f / CPR, ch = f - row * CPR;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(ep + row * EP_LD + ch * 16);
+        const unsigned off = ((unsigned)(wave_m0 + i * 16 + row) * (unsigned)ldo + (unsigned)(wave_n0 + ch * 8)) * 2u;
+        __builtin_amdgcn_raw_buffer_store_b128(v, o_rsrc, (int)off, 0, 2);
+      }
+    }
+  }
+}
+
+template <int WNW>
+int launch_ln_dma(hipStream_t s, const u16* A, int lda, const u16* W, const float* bias, const u16* shortcut, const float* gamma,
+                  const float* beta, u16* out, int ldo, int M, int K) {
+  constexpr int BN = 96 * WNW, RING = 3;
+  const int m_tiles = (M + LBM - 1) / LBM;
+  const size_t shm = (size_t)RING * (LBM + BN) * 64 + (size_t)2 * WNW * 16 * (96 * 2 + 16) + (size_t)2 * WNW * 64 * 2 * sizeof(float) +
+                     (size_t)3 * BN * sizeof(float);
+  auto kern = gemm_ln_residual_bf16_dma_kernel<WNW, RING>;
+  PANGU_ENSURE_DYN_LDS(kern, shm);
+  const int per_cu = WNW == 4 ? 1 : 2;                       // 127 KB / 75 KB of LDS per workgroup
+  int grid = 256 * per_cu;
+  if (grid > m_tiles) grid = m_tiles;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WNW), shm, s, A, lda, W, bias, shortcut, gamma, beta, out, ldo, M, K, m_tiles);
+  return pangu_launch_status();
+}
+
 template <int WNW>
 int launch_ln(hipStream_t s, const u16* A, int lda, const u16* W, const float* bias, const u16* shortcut, const float* gamma,
               const float* beta, u16* out, int ldo, int M, int K) {
@@ -209,7 +455,13 @@ extern "C" int pangu_linear_ln_residual_fwd_bf16(pangu_stream_t stream, const vo
   if (!pangu_fits_u32(M, lda, 2) || !pangu_fits_u32(M, ldo, 2)) return PANGU_E_RANGE;
   if (N != 192 && N != 384) return PANGU_E_SHAPE;          // the tile must span the whole row
   hipStream_t s = (hipStream_t)stream;
-  if (N == 192)
+  // the persistent LDS-DMA kernel: K a multiple of 32 and at least three K-steps, dense A rows addressable through the scalar offset
+  const bool dma = PANGU_GEMM_LN_DMA && K % 32 == 0 && K >= 96 && pangu_fits_u32(M, lda, 2) &&
+                   (N == 384 ? (PANGU_GEMM_LN_DMA & 1) : (PANGU_GEMM_LN_DMA & 2));
+  if (N == 192) {
+    if (dma) return launch_ln_dma<2>(s, (const u16*)A, lda, (const u16*)W, bias, (const u16*)shortcut, gamma, beta, (u16*)out, ldo, M, K);
     return launch_ln<2>(s, (const u16*)A, lda, (const u16*)W, bias, (const u16*)shortcut, gamma, beta, (u16*)out, ldo, M, K);
+  }
+  if (dma) return launch_ln_dma<4>(s, (const u16*)A, lda, (const u16*)W, bias, (const u16*)shortcut, gamma, beta, (u16*)out, ldo, M, K);
   return launch_ln<4>(s, (const u16*)A, lda, (const u16*)W, bias, (const u16*)shortcut, gamma, beta, (u16*)out, ldo, M, K);
 }

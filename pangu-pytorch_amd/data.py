@@ -66,9 +66,15 @@ class DevicePrefetcher:
                   pass it on (`train_step(..., levels_reversed=pf.levels_reversed)`).  False: a device-side `flip` per field.
     depth         batches staged ahead of the consumer (>= 1; 2 hides the copy behind a per-step host sync).
     threaded      False: stage on the consumer's thread (the pre-round-6 behaviour; for debugging / comparison).
-    copy_threads  host threads of one staging copy (default_copy_threads())."""
+    copy_threads  host threads of one staging copy (default_copy_threads()).
+    reuse_device_buffers   True: the device tensors of a batch are `depth + 3` STATIC buffer sets filled in turn (no allocator traffic
+                  in the loop: a fresh 270 MB block per field and step can mean a synchronous hipMalloc when the caching allocator's
+                  pool is fragmented) -- a yielded batch is valid until the consumer asks for the NEXT one (an event recorded then
+                  orders the buffer's refill behind the consumer's work on it); keep nothing from a batch across iterations.
+                  False (default): every batch is freshly allocated and stays valid as long as it is referenced."""
 
-    def __init__(self, loader, device, flip_levels=False, depth=2, fuse_flip=False, threaded=True, copy_threads=None):
+    def __init__(self, loader, device, flip_levels=False, depth=2, fuse_flip=False, threaded=True, copy_threads=None,
+                 reuse_device_buffers=False):
         self.loader, self.device = loader, torch.device(device)
         self.flip = bool(flip_levels) and not fuse_flip
         self.levels_reversed = bool(flip_levels) and bool(fuse_flip)
@@ -80,6 +86,11 @@ class DevicePrefetcher:
         self._pinned = [None] * self._nslots   # per slot: list of page-locked host buffers
         self._busy = [None] * self._nslots     # per slot: event of the last host->device copy that read those buffers
         self._slot = 0
+        self.reuse = bool(reuse_device_buffers)
+        self._ndev = self.depth + 3            # queued + being staged + held by the consumer + one whose release was just recorded
+        self._dev = [None] * self._ndev        # per device slot: list of static device tensors
+        self._consumed = [None] * self._ndev   # per device slot: event on the consumer's stream after its last use of that slot
+        self._dslot = 0
         self._filler = hasattr(loader, "fill_pinned")
         # what the pipeline did, for bench.py: seconds in the staging copy / bytes staged / seconds the consumer waited for a batch
         self.stats = {"host_copy_s": 0.0, "bytes": 0, "batches": 0, "consumer_wait_s": 0.0, "h2d_events": []}
@@ -103,15 +114,27 @@ class DevicePrefetcher:
 
     def _upload(self, slot, pins, layout):
         """pins: the slot's page-locked tensors; layout: per batch element either an index into pins or ('obj', value)."""
-        out = []
+        out, dslot = [], -1
         with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+            if self.reuse:
+                dslot = self._dslot
+                self._dslot = (dslot + 1) % self._ndev
+                dev = self._dev[dslot]
+                if dev is None or len(dev) != len(pins) or any(d.shape != p.shape or d.dtype != p.dtype for d, p in zip(dev, pins)):
+                    dev = self._dev[dslot] = [torch.empty(p.shape, dtype=p.dtype, device=self.device) for p in pins]
+                if self._consumed[dslot] is not None:
+                    self.stream.wait_event(self._consumed[dslot])      # the consumer's last kernels on this buffer set come first
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record(self.stream)
             for i, item in enumerate(layout):
                 if isinstance(item, tuple):
                     out.append(item[1])
                     continue
-                d = pins[item].to(self.device, non_blocking=True)
+                if self.reuse:
+                    d = dev[item]
+                    d.copy_(pins[item], non_blocking=True)
+                else:
+                    d = pins[item].to(self.device, non_blocking=True)
                 if self.flip and i in (0, 2) and d.dim() >= 4:
                     d = d.flip(-3)
                 out.append(d)
@@ -121,7 +144,7 @@ class DevicePrefetcher:
         st = self.stats
         st["h2d_events"].append((e0, ev, sum(p.numel() * p.element_size() for p in pins)))
         del st["h2d_events"][:-16]
-        return out, ev
+        return out, ev, dslot
 
     def _stage(self, batch):
         tensors = [t for t in batch if torch.is_tensor(t)]
@@ -184,13 +207,21 @@ class DevicePrefetcher:
         except BaseException as e:       # delivered to the consumer, which re-raises it
             q.put(e)
 
-    def _hand_over(self, batch, ev):
+    def _hand_over(self, batch, ev, dslot=-1):
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(ev)
-        for t in batch:
-            if torch.is_tensor(t):
-                t.record_stream(cur)
+        if dslot < 0:
+            for t in batch:
+                if torch.is_tensor(t):
+                    t.record_stream(cur)
         return tuple(batch)
+
+    def _release(self, dslot):
+        """The consumer asked for the next batch: everything it enqueued on the batch in device slot `dslot` precedes this event."""
+        if dslot >= 0:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._consumed[dslot] = ev
 
     def __iter__(self):
         if not self.threaded:
@@ -198,9 +229,10 @@ class DevicePrefetcher:
             gen = self._staged()
             pending = next(gen, None)
             while pending is not None:
-                batch, ev = pending
+                batch, ev, dslot = pending
                 pending = next(gen, None)
-                yield self._hand_over(batch, ev)
+                yield self._hand_over(batch, ev, dslot)
+                self._release(dslot)
             return
         q = queue.Queue(maxsize=self.depth)
         stop = threading.Event()
@@ -216,6 +248,7 @@ class DevicePrefetcher:
                 if isinstance(item, BaseException):
                     raise item
                 yield self._hand_over(*item)
+                self._release(item[2])
         finally:
             stop.set()
             while th.is_alive():          # unblock a worker stuck on a full queue (the consumer left early)
@@ -240,4 +273,4 @@ class DevicePrefetcher:
                 "h2d_GBps": h2d_b / (h2d_ms * 1e-3) / 1e9 if h2d_ms > 0 else None,
                 "consumer_wait_ms_per_batch": st["consumer_wait_s"] / max(st["batches"], 1) * 1e3,
                 "copy_threads": self.copy_threads, "depth": self.depth, "threaded": self.threaded,
-                "direct_fill": self._filler, "levels_reversed_fused": self.levels_reversed}
+                "direct_fill": self._filler, "levels_reversed_fused": self.levels_reversed, "static_device_buffers": self.reuse}

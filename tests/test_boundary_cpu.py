@@ -189,3 +189,49 @@ def test_eval_recompute_function_plumbs_gradients_like_plain_autograd():
     x2.add_(1.0)
     with pytest.raises(RuntimeError, match="modified by an inplace operation"):
         out.sum().backward()
+
+
+def test_dropped_branch_policy_scopes_are_counted_not_saved_and_restored():
+    """`ops.dropped_branch_grads` scopes entered from two training loops (two threads) in interleaved order must leave the
+    process at the DEFAULT policy ("zeros": the reference's autograd result for a DropPath-dropped branch), and a "zeros" scope wins
+    over a concurrent "none" scope (it only materialises what the reference materialises)."""
+    from pangu_pytorch_amd import ops
+    assert ops.dropped_branch_policy() == "zeros"
+    a, b = ops.dropped_branch_grads("none"), ops.dropped_branch_grads("none")
+    a.__enter__()
+    assert ops.dropped_branch_policy() == "none"
+    b.__enter__()
+    a.__exit__(None, None, None)                      # A leaves while B is still inside
+    assert ops.dropped_branch_policy() == "none"
+    b.__exit__(None, None, None)
+    assert ops.dropped_branch_policy() == "zeros"     # (save-and-restore would have left "none" here)
+    with ops.dropped_branch_grads("none"):
+        with ops.dropped_branch_grads("zeros"):
+            assert ops.dropped_branch_policy() == "zeros"
+        assert ops.dropped_branch_policy() == "none"
+    assert ops.dropped_branch_policy() == "zeros"
+
+
+def test_train_step_keeps_zero_gradients_for_a_foreign_grad_sync():
+    """train_step may drop the explicit zero gradients of DropPath-dropped branches only when the gradient
+    sync is None or a dist.FlatGradSync method (flat buffer: the zeros are there, every rank launches every bucket).  Any other
+    callable -- the repo's own API-parity dist.gather_grad all-reduces parameter by parameter and skips `p.grad is None` -- must
+    see materialised zeros, or ranks that drew different DropPath patterns issue different numbers of collectives."""
+    import torch
+    from pangu_pytorch_amd import dist, train
+    m = torch.nn.Linear(4, 4)
+    sync = dist.FlatGradSync(m)
+    try:
+        assert train._owns_dropped_branches(sync.finish)
+        assert not train._owns_dropped_branches(lambda: dist.gather_grad(m.parameters(), 1))
+        assert not train._owns_dropped_branches(dist.gather_grad)
+        assert not train._owns_dropped_branches(None)
+    finally:
+        sync.remove()
+    # bucket quantum: 16 bytes per rank whatever the element size (ADVICE r5: 4 ELEMENTS are 8 bytes for bf16 parameters)
+    mb = torch.nn.Linear(5, 3).to(torch.bfloat16)
+    sb = dist.FlatGradSync(mb)
+    try:
+        assert all((end - start) * 2 % 16 == 0 and start * 2 % 16 == 0 for start, end, _ in sb.buckets)
+    finally:
+        sb.remove()

@@ -73,10 +73,14 @@ def test_linear_bf16_add_epilogue(P, M, N, K, bias):
     assert got.dtype == BF and rel_err(got, ref) < ROUND
 
 
-@pytest.mark.parametrize("M,N,K", [(1000, 192, 192), (4099, 192, 768), (1531, 384, 384), (777, 384, 1536), (128, 384, 64)])
+@pytest.mark.parametrize("M,N,K", [(1000, 192, 192), (4099, 192, 768), (1531, 384, 384), (777, 384, 1536), (128, 384, 64),
+                                   (66001, 384, 384), (98400, 384, 96), (132070, 192, 192), (70000, 192, 128)])
 @pytest.mark.parametrize("strided_out", [False, True])
 def test_linear_ln_residual_bf16(P, M, N, K, strided_out):
-    """Fused projection + post-norm residual == linear -> LayerNorm -> + shortcut (reference layers.py:250-251)."""
+    """Fused projection + post-norm residual == linear -> LayerNorm -> + shortcut (reference layers.py:250-251).  The large M: more
+    128-row tiles than the persistent LDS-DMA kernel has workgroups (256 at N = 384, 512 at N = 192), so workgroups walk 2-4 tiles
+    with the operand ring running across tile boundaries, ragged last tile included; K = 96 / 128: three / four K-steps (the ring's
+    minimum); K = 64 takes the register-staged kernel."""
     from pangu_pytorch_amd import ops_bf16 as ob
     a = synth.uniform((M, K), 71).to(BF)
     w = synth.uniform((N, K), 72, 1.0 / K ** 0.5).to(BF)

@@ -238,6 +238,20 @@ def test_device_prefetcher_pipeline_semantics(P, threaded):
         raise ValueError("reader failed")
     with pytest.raises(ValueError, match="reader failed"):
         list(D.DevicePrefetcher(bad(), "cuda", threaded=threaded))
+    # static device buffers: a batch is valid until the next one is requested -- checked INSIDE the loop, over more batches than
+    # there are buffer sets (depth + 3), with a slow consumer kernel queued on each batch before the next is requested
+    st = D.DevicePrefetcher(batches * 2, "cuda", depth=2, threaded=threaded, reuse_device_buffers=True)
+    seen, ptrs = [], set()
+    big = torch.zeros(1 << 24, device="cuda")
+    for i, (a, b, c, d, tag) in enumerate(st):
+        for _ in range(20):
+            big.add_(1.0)                                    # keeps the consumer's stream busy while the worker refills
+        seen.append((a.clone(), tag))
+        ptrs.add(a.data_ptr())
+    assert len(seen) == 18 and len(ptrs) <= 5
+    for i, (a, tag) in enumerate(seen):
+        assert tag == {"tag": i % 9} and torch.equal(a.cpu(), batches[i % 9][0])
+    assert st.summary()["static_device_buffers"]
     fl = D.DevicePrefetcher(_Filler(7), "cuda", depth=2, threaded=threaded)
     for epoch in range(2):
         vals = [(float(a[0, 0, 0, 0, 0]), float(b[0, 0, 0, 0])) for a, b in fl]
@@ -284,7 +298,7 @@ def test_training_step_fed_from_host_full_size(P):
         losses, t0 = [], None
         if fed:
             loader = [host[i % 3] for i in range(n_warm + n_steps)]
-            pf = P.data.DevicePrefetcher(loader, dev, flip_levels=True, fuse_flip=True, depth=2)
+            pf = P.data.DevicePrefetcher(loader, dev, flip_levels=True, fuse_flip=True, depth=2, reuse_device_buffers=True)
             for k, batch in enumerate(pf):
                 if k == n_warm:
                     torch.cuda.synchronize()
