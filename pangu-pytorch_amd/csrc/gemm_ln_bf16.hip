@@ -17,10 +17,14 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-// Which widths take the persistent LDS-DMA kernel below (bit 0: N = 384, bit 1: N = 192); 0 = the register-staged kernel for both
+// Which widths take the persistent LDS-DMA kernel below (bit 0: N = 384, bit 1: N = 192); 0 = the register-staged kernel for both.
+// Default 1: at N = 192 (two 4-wave workgroups per CU either way) the two kernels measured level (K = 192) / +3 % (K = 768)
 // (tools/ab_lib.sh builds the A/B libraries).
 #ifndef PANGU_GEMM_LN_DMA
-#define PANGU_GEMM_LN_DMA 3
+#define PANGU_GEMM_LN_DMA 1
+#endif
+#ifndef PANGU_GEMM_LN_RING
+#define PANGU_GEMM_LN_RING 3      // N = 384: ring depth of the persistent kernel (3: 127 KB of LDS; 4: 159 KB measured level, profiles/r06_gemm_ln_bf16_ab.md)
 #endif
 
 constexpr int LBM = 128;
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_ln_residual_bf16_dma_kernel
     const u16* __restrict__ A, int lda, const u16* __restrict__ W, const float* __restrict__ bias,
     const u16* __restrict__ shortcut, const float* __restrict__ gamma, const float* __restrict__ beta, u16* __restrict__ out,
     int ldo, int M, int K, int m_tiles) {
-  static_assert(RING == 3, "the counted waits below are written for a ring of three");
+  static_assert(RING == 3 || RING == 4, "ring of three or four");
   constexpr int NW = 2 * WNW;                              // waves
   constexpr int BN = 96 * WNW;                             // = N
   constexpr int ROWS = LBM + BN;
@@ -234,8 +238,11 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_ln_residual_bf16_dma_kernel
   constexpr int NS = 12;                                   // shortcut loads = output stores per thread and tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* ep = smem + RING * STAGE + (threadIdx.x >> 6) * (16 * EP_LD);
-  float* stats = reinterpret_cast<float*>(smem + RING * STAGE + NW * 16 * EP_LD);      // [2 wm][WNW][64 rows][sum, sumsq]
-  float* prm = stats + 2 * WNW * 64 * 2;                   // [bias | gamma | beta][N]: resident (72 registers per lane otherwise)
+  // the statistics table [2 wm][WNW][64 rows][sum, sumsq] (4 KB for N = 384) ALIASES the patches: it is dead (every wave has taken
+  // its rows' mean / rstd into registers, second barrier) before the first patch is written -- what lets a ring of four fit
+  float* stats = reinterpret_cast<float*>(smem + RING * STAGE);
+  static_assert(2 * WNW * 64 * 2 * 4 <= 2 * WNW * 16 * (96 * 2 + 16), "statistics fit in the patch area");
+  float* prm = reinterpret_cast<float*>(smem + RING * STAGE + NW * 16 * EP_LD);      // [bias | gamma | beta][N]: resident
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -288,8 +295,8 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_ln_residual_bf16_dma_kernel
 
   int tile = blockIdx.x;
   if (tile >= m_tiles) return;
-  issue(0, tile, 0);
-  if (KT > 1) issue(1, tile, 1);
+#pragma unroll
+  for (int p0 = 0; p0 < RING - 1; ++p0) issue(p0, tile, p0);          // KT >= RING - 1: checked by the launcher
   bool first = true;
   int g = 0;
   for (; tile < m_tiles; tile += gridDim.x) {
@@ -303,23 +310,32 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_ln_residual_bf16_dma_kernel
       for (int j = 0; j < 6; ++j) acc[i][j] = *reinterpret_cast<const f32x4*>(prm + wave_n0 + j * 16 + lg * 4);
     u32x4 sc[NS];
     for (int kt = 0; kt < KT; ++kt, ++g) {
-      // in-order queue of this thread at this point (oldest first), steady state:
-      //   kt = 0: DMA(kt) DMA(kt+1) stores(prev tile)            -> allow LPS + NS newer     (first tile: no stores)
-      //   kt = 1: DMA(1) stores(prev) DMA(2) shortcut            -> allow LPS + 2 NS         (first tile: LPS + NS)
-      //   kt = 2: DMA(2) shortcut DMA(3)                         -> allow NS + LPS
-      //   kt >= 3: DMA(kt) DMA(kt+1)                             -> allow LPS   (the very last step of the last tile: nothing newer)
-      const bool tail = !has_next && kt == KT - 1;
-      if (tail) wait_vmcnt<0>();
-      else if (kt == 0) { if (first) wait_vmcnt<LPS>(); else wait_vmcnt<LPS + NS>(); }
-      else if (kt == 1) { if (first) wait_vmcnt<LPS + NS>(); else wait_vmcnt<LPS + 2 * NS>(); }
-      else if (kt == 2) wait_vmcnt<LPS + NS>();
-      else wait_vmcnt<LPS>();
+      // In-order queue of this thread (oldest first) within a tile: DMA(0 .. RING-2) were issued under the PREVIOUS tile's last
+      // K-steps, then that tile's NS output stores, then at step k: DMA(k + RING - 1), and at step 0 also the NS shortcut loads.
+      // Step k needs DMA(k); NEWER than it (allowed to stay in flight) are
+      //   the DMA groups k+1 .. k+RING-2 that exist, the stores iff k <= RING-2 (not in this workgroup's first tile), and the
+      //   shortcut loads iff 1 <= k <= RING-1.
+      {
+        int groups = RING - 2;
+        if (!has_next && KT - 1 - kt < groups) groups = KT - 1 - kt;
+        const int extra = ((kt <= RING - 2 && !first) ? 1 : 0) + ((kt >= 1 && kt <= RING - 1) ? 1 : 0);
+        const int code = groups * 3 + extra;                 // (groups 0..2) x (extra 0..2)
+        if (code == 0) wait_vmcnt<0>();
+        else if (code == 1) wait_vmcnt<NS>();
+        else if (code == 2) wait_vmcnt<2 * NS>();
+        else if (code == 3) wait_vmcnt<LPS>();
+        else if (code == 4) wait_vmcnt<LPS + NS>();
+        else if (code == 5) wait_vmcnt<LPS + 2 * NS>();
+        else if (code == 6) wait_vmcnt<2 * LPS>();
+        else if (code == 7) wait_vmcnt<2 * LPS + NS>();
+        else wait_vmcnt<2 * LPS + 2 * NS>();
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's fragment reads of step g-1 have returned
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();                            // step g landed for every wave; slot (g-1) % RING is free
       asm volatile("" ::: "memory");
-      if (kt + 2 < KT) issue(g + 2, tile, kt + 2);
-      else if (has_next) issue(g + 2, next, kt + 2 - KT);
+      if (kt + RING - 1 < KT) issue(g + RING - 1, tile, kt + RING - 1);
+      else if (has_next) issue(g + RING - 1, next, kt + RING - 1 - KT);
       if (kt == 0) {
         // shortcut patch [64 rows][96 columns] of this wave, 16-B chunks in the order the output rows leave in (rows >= M: zeros)
 #pragma unroll
@@ -374,6 +390,7 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_ln_residual_bf16_dma_kernel
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     constexpr float INV_C = 1.0f / BN;
+    float mean_[4], rstd_[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float s = 0.f, q = 0.f;
@@ -383,8 +400,15 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_ln_residual_bf16_dma_kernel
         s += st[0];
         q += st[1];
       }
-      const float mean = s * INV_C;
-      const float rstd = rsqrtf(fmaxf(q * INV_C - mean * mean, 0.f) + LN_EPS);
+      mean_[i] = s * INV_C;
+      rstd_[i] = rsqrtf(fmaxf(q * INV_C - mean_[i] * mean_[i], 0.f) + LN_EPS);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                              // the table is dead: the patches may overwrite it
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float mean = mean_[i], rstd = rstd_[i];
       // the group's shortcut rows -> patch (the previous group's read-back must have returned: same wave, LDS in order)
 #pragma unroll
       for (int it = 0; it < 3; ++it) {
@@ -415,17 +439,16 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_ln_residual_bf16_dma_kernel
   }
 }
 
-template <int WNW>
+template <int WNW, int RING>
 int launch_ln_dma(hipStream_t s, const u16* A, int lda, const u16* W, const float* bias, const u16* shortcut, const float* gamma,
                   const float* beta, u16* out, int ldo, int M, int K) {
-  constexpr int BN = 96 * WNW, RING = 3;
+  constexpr int BN = 96 * WNW;
   const int m_tiles = (M + LBM - 1) / LBM;
-  const size_t shm = (size_t)RING * (LBM + BN) * 64 + (size_t)2 * WNW * 16 * (96 * 2 + 16) + (size_t)2 * WNW * 64 * 2 * sizeof(float) +
-                     (size_t)3 * BN * sizeof(float);
+  const size_t shm = (size_t)RING * (LBM + BN) * 64 + (size_t)2 * WNW * 16 * (96 * 2 + 16) + (size_t)3 * BN * sizeof(float);
   auto kern = gemm_ln_residual_bf16_dma_kernel<WNW, RING>;
   PANGU_ENSURE_DYN_LDS(kern, shm);
-  const int per_cu = WNW == 4 ? 1 : 2;                       // 127 KB / 75 KB of LDS per workgroup
-  int grid = 256 * per_cu;
+  const int per_cu = (int)(160 * 1024 / shm) < 1 ? 1 : (int)(160 * 1024 / shm);      // N = 384: one 8-wave workgroup per CU; N = 192: two 4-wave
+  int grid = 256 * (per_cu > 2 ? 2 : per_cu);
   if (grid > m_tiles) grid = m_tiles;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WNW), shm, s, A, lda, W, bias, shortcut, gamma, beta, out, ldo, M, K, m_tiles);
   return pangu_launch_status();
@@ -459,9 +482,14 @@ extern "C" int pangu_linear_ln_residual_fwd_bf16(pangu_stream_t stream, const vo
   const bool dma = PANGU_GEMM_LN_DMA && K % 32 == 0 && K >= 96 && pangu_fits_u32(M, lda, 2) &&
                    (N == 384 ? (PANGU_GEMM_LN_DMA & 1) : (PANGU_GEMM_LN_DMA & 2));
   if (N == 192) {
-    if (dma) return launch_ln_dma<2>(s, (const u16*)A, lda, (const u16*)W, bias, (const u16*)shortcut, gamma, beta, (u16*)out, ldo, M, K);
+    if (dma) return launch_ln_dma<2, 3>(s, (const u16*)A, lda, (const u16*)W, bias, (const u16*)shortcut, gamma, beta, (u16*)out, ldo, M, K);
     return launch_ln<2>(s, (const u16*)A, lda, (const u16*)W, bias, (const u16*)shortcut, gamma, beta, (u16*)out, ldo, M, K);
   }
-  if (dma) return launch_ln_dma<4>(s, (const u16*)A, lda, (const u16*)W, bias, (const u16*)shortcut, gamma, beta, (u16*)out, ldo, M, K);
+  if (dma) {
+    // ring of four (three K-steps in flight: 96 KB per CU) where the K-loop is long enough for its wait pattern, three otherwise
+    if (PANGU_GEMM_LN_RING == 4 && K >= 160)
+      return launch_ln_dma<4, 4>(s, (const u16*)A, lda, (const u16*)W, bias, (const u16*)shortcut, gamma, beta, (u16*)out, ldo, M, K);
+    return launch_ln_dma<4, 3>(s, (const u16*)A, lda, (const u16*)W, bias, (const u16*)shortcut, gamma, beta, (u16*)out, ldo, M, K);
+  }
   return launch_ln<4>(s, (const u16*)A, lda, (const u16*)W, bias, (const u16*)shortcut, gamma, beta, (u16*)out, ldo, M, K);
 }
