@@ -293,6 +293,7 @@ def fed_from_host(model, opt, dev, consts, grad_sync, steps, rank):
     sync = torch.cuda.synchronize
 
     def timed(batches, item, rev, to_device=False):
+        torch.manual_seed(4242 + rank)          # every variant sees the SAME DropPath draws (a dropped stage-0 branch is worth ms)
         t0 = None
         for k, b in enumerate(batches):
             if k == n_warm:

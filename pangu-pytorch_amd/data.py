@@ -81,7 +81,8 @@ class DevicePrefetcher:
         self.depth = max(1, int(depth))
         self.threaded = bool(threaded)
         self.copy_threads = int(copy_threads) if copy_threads else default_copy_threads()
-        self.stream = torch.cuda.Stream(device=self.device)
+        # (high priority: the uploads are tiny next to a step's kernels and must not queue behind them)
+        self.stream = torch.cuda.Stream(device=self.device, priority=-1)
         self._nslots = self.depth + 1          # `depth` queued + the one being staged
         self._pinned = [None] * self._nslots   # per slot: list of page-locked host buffers
         self._busy = [None] * self._nslots     # per slot: event of the last host->device copy that read those buffers
