@@ -152,6 +152,26 @@ __device__ __forceinline__ unsigned long long attn_stamp() {
 }
 #endif
 
+// win_src_token (common.h) with the window type already split into (zwin, hwin): the split is a runtime division of a
+// workgroup-uniform value that the compiler would redo on the vector ALU for each of the kernel's eight token lookups.
+__device__ inline void split_type(const WinGeom& g, int t, int& zwin, int& hwin) {
+  zwin = 0;
+  hwin = t;
+#pragma unroll 1
+  for (int k = 1; k < g.nZw; ++k)            // nZw = 4 for the model's 8 levels: three scalar compares
+    if (t >= k * g.nHw) { zwin = k; hwin = t - k * g.nHw; }
+}
+__device__ inline int win_src_token_zh(const WinGeom& g, int l, int zwin, int hwin, int n, int shifted) {
+  int zi = n / 72, r = n - zi * 72, hi = r / 12, wi = r - hi * 12;
+  int z = 2 * zwin + zi, h = 6 * hwin + hi, w = 12 * l + wi;
+  if (shifted) {
+    z += 1; if (z >= g.Z) z -= g.Z;
+    h += 3; if (h >= g.Hp) h -= g.Hp;
+    w += 6; if (w >= g.W) w -= g.W;
+  }
+  return h >= g.H ? -1 : (z * g.H + h) * g.W + w;
+}
+
 // Waves per SIMD the register allocator must leave room for (the second __launch_bounds__ argument).  2 = the compiler's free
 // choice (138-156 VGPRs -> three waves per SIMD, four 3-wave workgroups per CU); 4 = capped at 128 VGPRs (five workgroups per CU):
 // the round-6 A/B build (tools/ab_lib.sh, profiles/r06_attn_qkv_occ4_ab.md).
@@ -188,14 +208,16 @@ __global__ __launch_bounds__(192, PANGU_ATTN_QKV_MIN_WAVES) void window_attn_qkv
   // Block order: blocks b, b+8, .. share an XCD (its L2).  Every head of a window reads the SAME 144 input rows, so the
   // heads of one window run back to back on one XCD (x leaves HBM once, not `heads` times: PMC FETCH_SIZE 0.67 -> ...
   // GB per launch, profiles/), then the next longitude window of the same type (its `heads` bias tiles stay in that L2).
-  const int b = blockIdx.x;
-  const int xcd = b & 7, local = b >> 3;
-  const int hd_ = local % heads, wl = local / heads;
-  const int l = wl % g.nLon;
-  const int t_ = (wl / g.nLon) * 8 + xcd;
-  const int pair = t_ * heads + hd_;
+  // (3-D grid since round 6: x = xcd + 8 * head, y = longitude window, z = type / 8 -- the SAME dispatch order as the former 1-D grid
+  // b = xcd + 8 * (head + heads * (l + nLon * z)), x fastest and gridDim.x a multiple of 8, but no runtime division: five uniform
+  // 32-bit divisions cost ~110 of the kernel's 1 300 vector instructions per wave)
+  const int xcd = blockIdx.x & 7, hd = blockIdx.x >> 3;
+  const int l = blockIdx.y;
+  const int t = blockIdx.z * 8 + xcd;
+  const int pair = t * heads + hd;
   if (pair >= n_pairs) return;
-  const int t = pair / heads, hd = pair - t * heads;
+  int zwin, hwin;
+  split_type(g, t, zwin, hwin);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lq = lane & 15, lg = lane >> 4;
@@ -217,7 +239,7 @@ __global__ __launch_bounds__(192, PANGU_ATTN_QKV_MIN_WAVES) void window_attn_qkv
     const int row = RPI * q + lane / CH;
     const int c = (lane % CH) ^ fsw(row);
     if (q < NIX) {
-      const int tok = win_src_token(g, l, t, row, SHIFTED);
+      const int tok = win_src_token_zh(g, l, zwin, hwin, row, SHIFTED);
       voff[i] = tok >= 0 ? ((unsigned)tok * (unsigned)ldx + c * 8) * 2u : 0x7FFFFFF0u;       // pad row: out of range -> zeros
     } else {
       const int r = row - PANGU_WTOK, which = r >> 5, d = r & 31;
@@ -240,7 +262,7 @@ __global__ __launch_bounds__(192, PANGU_ATTN_QKV_MIN_WAVES) void window_attn_qkv
   const int tile0 = 3 * wave;
   int qtok[3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) qtok[i] = win_src_token(g, l, t, (tile0 + i) * 16 + lq, SHIFTED);
+  for (int i = 0; i < 3; ++i) qtok[i] = win_src_token_zh(g, l, zwin, hwin, (tile0 + i) * 16 + lq, SHIFTED);
 
   // ---- accumulators: [rt 0,1 = q | 2,3 = k][token tile] transposed (d = 4lg + r on the registers, token on the lane);
   //      [rt 4,5 = v] token 4lg + r on the registers, d = 16(rt-4) + lq on the lane.  Initial value = bias.
@@ -341,7 +363,6 @@ __global__ __launch_bounds__(192, PANGU_ATTN_QKV_MIN_WAVES) void window_attn_qkv
   bool zcut = false, hcut = false;
   unsigned long long kz_bits = 0ull, kh_bits = 0ull;
   if (SHIFTED) {
-    const int zwin = t / g.nHw, hwin = t - zwin * g.nHw;
     zcut = zwin == g.nZw - 1;
     hcut = hwin == g.nHw - 1;
 #pragma unroll
@@ -412,7 +433,7 @@ static int launch_attn_qkv(pangu_stream_t stream, const void* x, int ldx, const 
   if (!pangu_fits_u32(n_tok, ldx, 2) || (size_t)n_tok * ldx * 2 >= 0x7FFFFFF0ull) return PANGU_E_RANGE;
   const WinGeom g = make_geom(Z, H, W);
   const int n_pairs = g.types * heads;
-  const int grid = ((g.types + 7) / 8) * 8 * g.nLon * heads;
+  const dim3 grid(8 * heads, g.nLon, (g.types + 7) / 8);
   // ring of 2 x 32 channels, four workgroups per CU.  Measured and removed (round 4; DESIGN.md keeps the numbers): ring of 3 (three
   // workgroups per CU, -5 %), one slot of 64 channels (+-1 %), ring of 2 x 64 channels (two workgroups per CU, -20 %), HG heads of a
   // window per workgroup sharing the x slice (-10..-30 %), window rows register-resident with the heads looped (-8 %), and the
@@ -423,7 +444,7 @@ static int launch_attn_qkv(pangu_stream_t stream, const void* x, int ldx, const 
   do {                                                                                                                    \
     auto kern = window_attn_qkv_bf16_kernel<SH, CC>;                                                                      \
     PANGU_ENSURE_DYN_LDS(kern, shm);                                                                                      \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(192), shm, s, (const u16*)x, ldx, (const u16*)w_qkv, b_qkv,                 \
+    hipLaunchKernelGGL(kern, grid, dim3(192), shm, s, (const u16*)x, ldx, (const u16*)w_qkv, b_qkv,                 \
                        (const u16*)esb, (u16*)out, lse, g, n_tok, heads, n_pairs);                                        \
   } while (0)
   if (C == 192) {

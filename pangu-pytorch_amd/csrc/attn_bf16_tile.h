@@ -69,22 +69,44 @@ __device__ inline BiasRow load_bias_row(const u16* __restrict__ bias_tile, int q
 
 // One 16-query tile of one wave: scores, softmax, PV, store.  Everything it needs from HBM (qf, bias) is already in
 // registers; K / V^T come from LDS.
-template <bool SHIFTED, bool VSWZ>
+// QSCALED (round 6 experiment, OFF): qf = q * scale rounded to bf16 and the unpacked bf16 bias as the score MFMAs' initial
+// accumulator -- the 36 `fma(s, scale, bias)` per lane and tile disappear (1 219 -> 1 123 vector instructions per wave, same bias
+// bytes, unlike round 5's fp32-parameter variant).  Measured LEVEL (0.360-0.375 vs 0.353-0.375 ms at C = 192) and it moves q's
+// rounding point (the fused kernel then disagrees with the two-launch path beyond one bf16 rounding): not used.
+template <bool SHIFTED, bool VSWZ, bool QSCALED = false>
 __device__ __forceinline__ void attn_tile(const unsigned char* Ks, const unsigned char* Vt, const bf16x8 qf,
                                           const BiasRow& bias, int qn, int qtok, int lq, int lg, bool zcut, bool hcut,
                                           unsigned long long kz_bits, unsigned long long kh_bits, u16* __restrict__ out,
                                           float* __restrict__ lse, int C, int heads, int hd) {
   const float scale = 0.17677669529663687f;
-  int lz = 0;
-  asm volatile("" : "+v"(lz));                   // keep the K / V^T fragment reads of the three tiles apart (no CSE across
-  const unsigned char* Ksq = Ks + lz;            // tiles: 76 fragment registers would stay live)
-  const unsigned char* Vtq = Vt + lz;
+  // Fragment addresses in closed form (round 6; tests/test_lds_layouts_cpu.py pins them against kswz / key_of / vt_off): of the
+  // kernel's 1 300 vector instructions per wave ~380 were integer address arithmetic, a good part of it these 19 swizzled LDS
+  // addresses recomputed for each of the three tiles.  Per lane they are SIX bases + immediates:
+  //   K, score tile j < 8: (j odd ? ke ^ 32 : ke) + 2048 (j >> 1) + 256 (j & 1);   tail tile: kt
+  //   V^T, k-step u < 4:   swizzled image (u odd ? vb ^ 64 : vb) + (u >= 2 ? 128 : 0), padded image vb + 64 u;   tail step: vt
+  // The bases are pure functions of the lane (computed once for the three inlined tiles); laundering them per tile keeps the
+  // fragment READS of the three tiles apart (no CSE across tiles: 76 fragment registers would stay live).
+  int ke = kswz(key_of(0, lq), lg), kt = kswz(128 + lq, lg);
+  int vb0 = vt_off<VSWZ>(lq, 8 * lg), vb1 = vt_off<VSWZ>(16 + lq, 8 * lg);
+  int vt0 = vt_off<VSWZ>(lq, 128 + 4 * lg), vt1 = vt_off<VSWZ>(16 + lq, 128 + 4 * lg);
+  asm volatile("" : "+v"(ke), "+v"(kt), "+v"(vb0), "+v"(vb1), "+v"(vt0), "+v"(vt1));
+  const int ko = ke ^ 32;
   f32x4 s[9];
+  if (QSCALED) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s[2 * u] = f32x4{bflo(bias.p[u][0]), bfhi(bias.p[u][0]), bflo(bias.p[u][1]), bfhi(bias.p[u][1])};
+      s[2 * u + 1] = f32x4{bflo(bias.p[u][2]), bfhi(bias.p[u][2]), bflo(bias.p[u][3]), bfhi(bias.p[u][3])};
+    }
+    s[8] = f32x4{bflo(bias.t[0]), bfhi(bias.t[0]), bflo(bias.t[1]), bfhi(bias.t[1])};
+  }
 #pragma unroll
   for (int j = 0; j < 9; ++j) {
-    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ksq + kswz(key_of(j, lq), lg));
-    s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    const int ka = j == 8 ? kt : ((j & 1) ? ko : ke) + 2048 * (j >> 1) + 256 * (j & 1);
+    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + ka);
+    s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, QSCALED ? s[j] : f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
   }
+  if (!QSCALED) {
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     s[2 * u][0] = fmaf(s[2 * u][0], scale, bflo(bias.p[u][0]));
@@ -100,6 +122,7 @@ __device__ __forceinline__ void attn_tile(const unsigned char* Ks, const unsigne
   s[8][1] = fmaf(s[8][1], scale, bfhi(bias.t[0]));
   s[8][2] = fmaf(s[8][2], scale, bflo(bias.t[1]));
   s[8][3] = fmaf(s[8][3], scale, bfhi(bias.t[1]));
+  }
   float mx = -INFINITY;
   if (SHIFTED) {
     if (zcut || hcut) {
@@ -149,10 +172,12 @@ __device__ __forceinline__ void attn_tile(const unsigned char* Ks, const unsigne
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
       u32x4 vq;
+      const int vb = dt ? vb1 : vb0;
       if (u < 4) {
-        vq = *reinterpret_cast<const u32x4*>(Vtq + vt_off<VSWZ>(dt * 16 + lq, 32 * u + 8 * lg));
+        const int va_ = VSWZ ? (((u & 1) ? (vb ^ 64) : vb) + (u >= 2 ? 128 : 0)) : vb + 64 * u;
+        vq = *reinterpret_cast<const u32x4*>(Vt + va_);
       } else {
-        const u32x2 va = *reinterpret_cast<const u32x2*>(Vtq + vt_off<VSWZ>(dt * 16 + lq, 128 + 4 * lg));
+        const u32x2 va = *reinterpret_cast<const u32x2*>(Vt + (dt ? vt1 : vt0));
         vq = u32x4{va[0], va[1], 0u, 0u};
       }
       const bf16x8 vf = __builtin_bit_cast(bf16x8, vq);

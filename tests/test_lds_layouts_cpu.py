@@ -101,3 +101,22 @@ def test_wgrad_bf16_dma_slab_images(rowb):
                 lc, lg = l & 15, l >> 4
                 return _wgrad_swz(rowb, row0 + 4 * lg + (lc >> 2), (col0 >> 3) + ((lc & 3) >> 1)) + 8 * (lc & 1)
             assert conflict_free("read_tr16", addr), (rowb, row0, col0)
+
+
+def test_closed_form_fragment_addresses_of_attn_tile():
+    """Round 6: `attn_tile` (csrc/attn_bf16_tile.h) no longer evaluates kswz / vt_off per fragment read but uses, per lane, six bases
+    + immediates -- K: (j odd ? ke ^ 32 : ke) + 2048 (j >> 1) + 256 (j & 1), tail kt; V^T (swizzled image): (u odd ? vb ^ 64 : vb) +
+    (u >= 2 ? 128 : 0), tail vt; padded image: vb + 64 u.  They must be the swizzle functions, for every lane, tile and k-step."""
+    for lane in range(64):
+        lq, lg = lane & 15, lane >> 4
+        ke, kt = kswz(key_of(0, lq), lg), kswz(128 + lq, lg)
+        for j in range(9):
+            got = kt if j == 8 else ((ke ^ 32) if j & 1 else ke) + 2048 * (j >> 1) + 256 * (j & 1)
+            assert got == kswz(key_of(j, lq), lg), (lane, j)
+        for dt in range(2):
+            vb = vt_off(dt * 16 + lq, 8 * lg)
+            for u in range(4):
+                assert ((vb ^ 64) if u & 1 else vb) + (128 if u >= 2 else 0) == vt_off(dt * 16 + lq, 32 * u + 8 * lg), (lane, dt, u)
+            pad = lambda d, key: d * 336 + key * 2                  # vt_off<false>
+            for u in range(4):
+                assert pad(dt * 16 + lq, 8 * lg) + 64 * u == pad(dt * 16 + lq, 32 * u + 8 * lg)
