@@ -524,7 +524,10 @@ def main():
             tg, tb, tr = t[:3].tolist()
             bf16_res.update(value=world * args.steps / tg, ms_per_step=tg / args.steps * 1e3,
                             eager_ms_per_step=tb / args.steps * 1e3, model_tflops=FWD_GFLOP_EXEC / (tg / args.steps * 1e3),
+                            frac_of_bf16_mfma_peak=FWD_GFLOP_EXEC / (tg / args.steps * 1e3) / PEAK_BF16_MFMA_TFLOPS,
                             rollout_7x24h_ms=tr * 1e3)
+            if isinstance(bf16_res.get("roofline"), dict):
+                bf16_res["roofline"]["times_of"] = "rank 0 (per-launch HIP events are local); the step times above: max over ranks"
 
     # ---- secondary metric: DDP finetune step (BASELINE configs[3] shape: 1 sample/GPU, fwd + bwd + bucketed RCCL
     # gradient all-reduce overlapped with backward + Adam), reported beside the headline number
@@ -565,6 +568,7 @@ def main():
                 del exposed[:]
                 if sync:
                     sync.bucket_times_ms()                # (drops the warm-up steps' event pairs)
+                copied0 = sync.copied_bytes if sync else 0
                 drops0 = [tuple(d.n_dropped_branch) for _, d in dps]
                 t1 = time.perf_counter()
                 for _ in range(args.train_steps):
@@ -573,6 +577,7 @@ def main():
                 t_train = time.perf_counter() - t1
                 bucket_ms = sync.bucket_times_ms() if sync else None
                 exposed_main = sum(a.elapsed_time(b) for a, b in exposed) / max(len(exposed), 1) if sync else None
+                copied_per_step = (sync.copied_bytes - copied0) / args.train_steps if sync else None
                 skipped = dropped_gflop(drops0) / args.train_steps            # forward GFLOP per step that was NOT executed
                 n_drop = sum(d.n_dropped_branch[0] + d.n_dropped_branch[1] - b[0] - b[1] for (_, d), b in zip(dps, drops0))
                 exec_gflop = 3.0 * (FWD_GFLOP_EXEC - skipped)                 # fwd + bwd = 3 x forward
@@ -657,7 +662,7 @@ def main():
                     train_res[tag]["allreduce_rehearsal_ms_per_step"] = reh
                 if sync:
                     train_res[tag]["exposed_allreduce_ms_per_step"] = exposed_main
-                    train_res[tag]["grad_copy_fallback_mib"] = sync.copied_bytes / 2**20
+                    train_res[tag]["grad_copy_fallback_mib"] = copied_per_step / 2**20          # per step, over the timed steps
                     train_res[tag]["grad_sync_mode"] = args.grad_sync
                     # per bucket (0 = the first one backward completes: the output layer; 19 = the input layer): launch -> its last
                     # collective done, mean over the timed steps -- events on a side stream that only waits for that collective
