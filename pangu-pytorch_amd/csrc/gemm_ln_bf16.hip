@@ -24,7 +24,10 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define PANGU_GEMM_LN_DMA 1
 #endif
 #ifndef PANGU_GEMM_LN_RING
-#define PANGU_GEMM_LN_RING 3      // N = 384: ring depth of the persistent kernel (3: 127 KB of LDS; 4: 159 KB measured level, profiles/r06_gemm_ln_bf16_ab.md)
+// N = 384: ring of the persistent kernel.  2 (default since the second A/B of round 6): TWO slots of 64-channel K-steps (128 KB) --
+// half the barriers and the second half-step's fragment reads overlap the first's MFMAs: -6...-9 % against 3 / 4 = three / four slots
+// of 32-channel K-steps (96 / 128 KB; level with each other).  profiles/r06_gemm_ln_bf16_ab.md
+#define PANGU_GEMM_LN_RING 2
 #endif
 
 constexpr int LBM = 128;
@@ -211,8 +214,6 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_ln_residual_bf16_kernel(
 //     loads and 12 output stores per tile at known positions.
 // LDS: RING x (128 + N) x 64 B ring + 2 WNW x 3328 B patches + 4 KB statistics (N = 384, RING = 3: 127 KB, one 8-wave workgroup
 // per CU; N = 192, RING = 3: 75 KB, two 4-wave workgroups per CU).
-constexpr int DBK = 32;
-
 __device__ inline int kswz64(int row, int chunk) {      // 64-byte rows, 4 chunks: F = {0,2,3,1}[(row>>2)&3]
   const int f = (0x78 >> (((row >> 2) & 3) * 2)) & 3;
   return row * 64 + ((chunk ^ f) << 4);
@@ -221,18 +222,23 @@ __device__ inline int kswz64(int row, int chunk) {      // 64-byte rows, 4 chunk
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int WNW, int RING>
+// DBK = channels per K-step: 32 (64-byte ring rows, swizzle kswz64) or 64 (128-byte rows, swizzle swz: half the barriers, the second
+// half-step's fragment reads can overlap the first's MFMAs; ring of 2 only -- 2 x 64 KB at N = 384).
+template <int WNW, int RING, int DBK = 32>
 __global__ __launch_bounds__(128 * WNW, 2) void gemm_ln_residual_bf16_dma_kernel(
     const u16* __restrict__ A, int lda, const u16* __restrict__ W, const float* __restrict__ bias,
     const u16* __restrict__ shortcut, const float* __restrict__ gamma, const float* __restrict__ beta, u16* __restrict__ out,
     int ldo, int M, int K, int m_tiles) {
-  static_assert(RING == 3 || RING == 4, "ring of three or four");
+  static_assert((DBK == 32 && (RING == 3 || RING == 4)) || (DBK == 64 && RING == 2), "ring of three or four K-steps of 32, or two of 64");
+  constexpr int ROWB = DBK * 2;                            // bytes per ring row
+  constexpr int RPI = 1024 / ROWB;                         // ring rows per LDS-DMA instruction (1 KB)
+  constexpr int CH = DBK / 8;                              // 16-B chunks per ring row
   constexpr int NW = 2 * WNW;                              // waves
   constexpr int BN = 96 * WNW;                             // = N
   constexpr int ROWS = LBM + BN;
-  constexpr int STAGE = ROWS * 64;                         // bytes per ring slot
-  constexpr int LPS = ROWS / (16 * NW);                    // LDS-DMA instructions per wave and K-step (16 rows each)
-  static_assert(ROWS % (16 * NW) == 0, "whole DMA instructions per wave");
+  constexpr int STAGE = ROWS * ROWB;                       // bytes per ring slot
+  constexpr int LPS = ROWS / (RPI * NW);                   // LDS-DMA instructions per wave and K-step (RPI rows each)
+  static_assert(ROWS % (RPI * NW) == 0, "whole DMA instructions per wave");
   constexpr int EP_LD = 96 * 2 + 16;                       // bytes per patch row
   constexpr int CPR = 12;                                  // 16-B chunks per patch row
   constexpr int NS = 12;                                   // shortcut loads = output stores per thread and tile
@@ -259,16 +265,16 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_ln_residual_bf16_dma_kernel
   const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<u16*>(shortcut), 0, (int)((size_t)M * BN * sizeof(u16)), 0x00020000);
 
-  // DMA instruction q = i * NW + wave fills ring rows 16q .. 16q+15; this lane fills (row 16q + lane>>2, physical chunk lane&3)
-  // with the LOGICAL chunk (lane&3) ^ F(row) (source-side swizzle).  Rows < 128: A (tile-relative; the tile's byte offset is added
+  // DMA instruction q = i * NW + wave fills ring rows RPI q .. RPI q + RPI - 1; this lane fills (row RPI q + lane / CH, physical
+  // chunk lane % CH) with the LOGICAL chunk (lane % CH) ^ F(row) (source-side swizzle).  Rows < 128: A (tile-relative; the tile's byte offset is added
   // to the VECTOR offset at issue time -- the descriptor's range check sees vector + immediate offsets only, and rows >= M must
   // arrive as zeros), rows >= 128: W.
   unsigned voff[LPS];
 #pragma unroll
   for (int i = 0; i < LPS; ++i) {
-    const int row = 16 * (i * NW + wave) + (lane >> 2);
-    const int f = (0x78 >> (((row >> 2) & 3) * 2)) & 3;
-    const int c = (lane & 3) ^ f;
+    const int row = RPI * (i * NW + wave) + lane / CH;
+    const int f = DBK == 32 ? ((0x78 >> (((row >> 2) & 3) * 2)) & 3) : ((row >> 1) & 7);
+    const int c = (lane % CH) ^ f;
     voff[i] = row < LBM ? ((unsigned)row * (unsigned)lda + c * 8) * 2u : ((unsigned)(row - LBM) * (unsigned)K + c * 8) * 2u;
   }
   const int KT = K / DBK;
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_ln_residual_bf16_dma_kernel
     for (int i = 0; i < LPS; ++i) {
       const int q = i * NW + wave;
       auto dst = (__attribute__((address_space(3))) void*)(base + q * 1024);
-      if (16 * q < LBM) __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, dst, 16, (int)(voff[i] + a_base), kt * DBK * 2, 0, 0);
+      if (RPI * q < LBM) __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, dst, 16, (int)(voff[i] + a_base), kt * DBK * 2, 0, 0);
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, dst, 16, (int)voff[i], kt * DBK * 2, 0, 0);
     }
   };
@@ -346,17 +352,26 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_ln_residual_bf16_dma_kernel
         }
       }
       const unsigned char* As = smem + (g % RING) * STAGE;
-      const unsigned char* Ws = As + LBM * 64;
-      bf16x8 fa[4], fw[6];
+      const unsigned char* Ws = As + LBM * ROWB;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(As + kswz64(wm * 64 + i * 16 + lc, lg));
+      for (int kk = 0; kk < DBK / 32; ++kk) {
+        bf16x8 fa[4], fw[6];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(Ws + kswz64(wn * 96 + j * 16 + lc, lg));
+        for (int i = 0; i < 4; ++i) {
+          const int row = wm * 64 + i * 16 + lc;
+          fa[i] = *reinterpret_cast<const bf16x8*>(As + (DBK == 32 ? kswz64(row, lg) : swz(row, kk * 4 + lg)));
+        }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 6; ++j) {
+          const int row = wn * 96 + j * 16 + lc;
+          fw[j] = *reinterpret_cast<const bf16x8*>(Ws + (DBK == 32 ? kswz64(row, lg) : swz(row, kk * 4 + lg)));
+        }
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);   // D[n][m]
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 6; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);   // D[n][m]
+      }
     }
     first = false;
 
@@ -439,13 +454,13 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_ln_residual_bf16_dma_kernel
   }
 }
 
-template <int WNW, int RING>
+template <int WNW, int RING, int DBK = 32>
 int launch_ln_dma(hipStream_t s, const u16* A, int lda, const u16* W, const float* bias, const u16* shortcut, const float* gamma,
                   const float* beta, u16* out, int ldo, int M, int K) {
   constexpr int BN = 96 * WNW;
   const int m_tiles = (M + LBM - 1) / LBM;
-  const size_t shm = (size_t)RING * (LBM + BN) * 64 + (size_t)2 * WNW * 16 * (96 * 2 + 16) + (size_t)3 * BN * sizeof(float);
-  auto kern = gemm_ln_residual_bf16_dma_kernel<WNW, RING>;
+  const size_t shm = (size_t)RING * (LBM + BN) * (DBK * 2) + (size_t)2 * WNW * 16 * (96 * 2 + 16) + (size_t)3 * BN * sizeof(float);
+  auto kern = gemm_ln_residual_bf16_dma_kernel<WNW, RING, DBK>;
   PANGU_ENSURE_DYN_LDS(kern, shm);
   const int per_cu = (int)(160 * 1024 / shm) < 1 ? 1 : (int)(160 * 1024 / shm);      // N = 384: one 8-wave workgroup per CU; N = 192: two 4-wave
   int grid = 256 * (per_cu > 2 ? 2 : per_cu);
@@ -487,6 +502,8 @@ extern "C" int pangu_linear_ln_residual_fwd_bf16(pangu_stream_t stream, const vo
   }
   if (dma) {
     // ring of four (three K-steps in flight: 96 KB per CU) where the K-loop is long enough for its wait pattern, three otherwise
+    if (PANGU_GEMM_LN_RING == 2 && K % 64 == 0 && K >= 192)      // K-steps of 64, ring of two (A/B build)
+      return launch_ln_dma<4, 2, 64>(s, (const u16*)A, lda, (const u16*)W, bias, (const u16*)shortcut, gamma, beta, (u16*)out, ldo, M, K);
     if (PANGU_GEMM_LN_RING == 4 && K >= 160)
       return launch_ln_dma<4, 4>(s, (const u16*)A, lda, (const u16*)W, bias, (const u16*)shortcut, gamma, beta, (u16*)out, ldo, M, K);
     return launch_ln_dma<4, 3>(s, (const u16*)A, lda, (const u16*)W, bias, (const u16*)shortcut, gamma, beta, (u16*)out, ldo, M, K);
