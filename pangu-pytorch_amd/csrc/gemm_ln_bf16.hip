@@ -17,9 +17,8 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-// Which widths take the persistent LDS-DMA kernel below (bit 0: N = 384, bit 1: N = 192); 0 = the register-staged kernel for both.
-// Default 1: at N = 192 (two 4-wave workgroups per CU either way) the two kernels measured level (K = 192) / +3 % (K = 768)
-// (tools/ab_lib.sh builds the A/B libraries).
+// Which widths take the persistent LDS-DMA kernel below (bit 0: N = 384 and N = 192 with K >= 384, bit 1: N = 192 always); 0 = the
+// register-staged kernel for everything (tools/ab_lib.sh builds the A/B libraries).
 #ifndef PANGU_GEMM_LN_DMA
 #define PANGU_GEMM_LN_DMA 1
 #endif
@@ -224,8 +223,10 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 
 // DBK = channels per K-step: 32 (64-byte ring rows, swizzle kswz64) or 64 (128-byte rows, swizzle swz: half the barriers, the second
 // half-step's fragment reads can overlap the first's MFMAs; ring of 2 only -- 2 x 64 KB at N = 384).
-template <int WNW, int RING, int DBK = 32>
-__global__ __launch_bounds__(128 * WNW, 2) void gemm_ln_residual_bf16_dma_kernel(
+// WM = wave rows of 64 tokens: the tile is 64 WM x N (2: 128 rows, the N = 384 form; 4: 256 rows x 192 columns -- one 8-wave workgroup
+// per CU at N = 192 as well, the W panel re-streamed half as often).
+template <int WNW, int RING, int DBK = 32, int WM = 2>
+__global__ __launch_bounds__(64 * WM * WNW, 2) void gemm_ln_residual_bf16_dma_kernel(
     const u16* __restrict__ A, int lda, const u16* __restrict__ W, const float* __restrict__ bias,
     const u16* __restrict__ shortcut, const float* __restrict__ gamma, const float* __restrict__ beta, u16* __restrict__ out,
     int ldo, int M, int K, int m_tiles) {
@@ -233,9 +234,10 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_ln_residual_bf16_dma_kernel
   constexpr int ROWB = DBK * 2;                            // bytes per ring row
   constexpr int RPI = 1024 / ROWB;                         // ring rows per LDS-DMA instruction (1 KB)
   constexpr int CH = DBK / 8;                              // 16-B chunks per ring row
-  constexpr int NW = 2 * WNW;                              // waves
+  constexpr int NW = WM * WNW;                             // waves
+  constexpr int TBM = 64 * WM;                             // token rows per tile
   constexpr int BN = 96 * WNW;                             // = N
-  constexpr int ROWS = LBM + BN;
+  constexpr int ROWS = TBM + BN;
   constexpr int STAGE = ROWS * ROWB;                       // bytes per ring slot
   constexpr int LPS = ROWS / (RPI * NW);                   // LDS-DMA instructions per wave and K-step (RPI rows each)
   static_assert(ROWS % (RPI * NW) == 0, "whole DMA instructions per wave");
@@ -244,10 +246,10 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_ln_residual_bf16_dma_kernel
   constexpr int NS = 12;                                   // shortcut loads = output stores per thread and tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* ep = smem + RING * STAGE + (threadIdx.x >> 6) * (16 * EP_LD);
-  // the statistics table [2 wm][WNW][64 rows][sum, sumsq] (4 KB for N = 384) ALIASES the patches: it is dead (every wave has taken
+  // the statistics table [WM][WNW][64 rows][sum, sumsq] (4 KB) ALIASES the patches: it is dead (every wave has taken
   // its rows' mean / rstd into registers, second barrier) before the first patch is written -- what lets a ring of four fit
   float* stats = reinterpret_cast<float*>(smem + RING * STAGE);
-  static_assert(2 * WNW * 64 * 2 * 4 <= 2 * WNW * 16 * (96 * 2 + 16), "statistics fit in the patch area");
+  static_assert(WM * WNW * 64 * 2 * 4 <= NW * 16 * (96 * 2 + 16), "statistics fit in the patch area");
   float* prm = reinterpret_cast<float*>(smem + RING * STAGE + NW * 16 * EP_LD);      // [bias | gamma | beta][N]: resident
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -275,23 +277,23 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_ln_residual_bf16_dma_kernel
     const int row = RPI * (i * NW + wave) + lane / CH;
     const int f = DBK == 32 ? ((0x78 >> (((row >> 2) & 3) * 2)) & 3) : ((row >> 1) & 7);
     const int c = (lane % CH) ^ f;
-    voff[i] = row < LBM ? ((unsigned)row * (unsigned)lda + c * 8) * 2u : ((unsigned)(row - LBM) * (unsigned)K + c * 8) * 2u;
+    voff[i] = row < TBM ? ((unsigned)row * (unsigned)lda + c * 8) * 2u : ((unsigned)(row - TBM) * (unsigned)K + c * 8) * 2u;
   }
   const int KT = K / DBK;
   // global step g = it * KT + kt of this workgroup's it-th tile
   auto issue = [&](int g, int tile, int kt) {
     unsigned char* base = smem + (g % RING) * STAGE;
-    const unsigned a_base = (unsigned)tile * (unsigned)(LBM * 2) * (unsigned)lda;      // < 2^32: checked by the launcher
+    const unsigned a_base = (unsigned)tile * (unsigned)(TBM * 2) * (unsigned)lda;      // < 2^32: checked by the launcher
 #pragma unroll
     for (int i = 0; i < LPS; ++i) {
       const int q = i * NW + wave;
       auto dst = (__attribute__((address_space(3))) void*)(base + q * 1024);
-      if (RPI * q < LBM) __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, dst, 16, (int)(voff[i] + a_base), kt * DBK * 2, 0, 0);
+      if (RPI * q < TBM) __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, dst, 16, (int)(voff[i] + a_base), kt * DBK * 2, 0, 0);
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, dst, 16, (int)voff[i], kt * DBK * 2, 0, 0);
     }
   };
 
-  for (int c = tid; c < BN; c += 128 * WNW) {
+  for (int c = tid; c < BN; c += 64 * NW) {
     prm[c] = bias ? bias[c] : 0.f;
     prm[BN + c] = gamma[c];
     prm[2 * BN + c] = beta[c];
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_ln_residual_bf16_dma_kernel
   for (; tile < m_tiles; tile += gridDim.x) {
     const int next = tile + gridDim.x;
     const bool has_next = next < m_tiles;
-    const int m0 = tile * LBM, wave_m0 = m0 + wm * 64;
+    const int m0 = tile * TBM, wave_m0 = m0 + wm * 64;
     f32x4 acc[4][6];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_ln_residual_bf16_dma_kernel
         }
       }
       const unsigned char* As = smem + (g % RING) * STAGE;
-      const unsigned char* Ws = As + LBM * ROWB;
+      const unsigned char* Ws = As + TBM * ROWB;
 #pragma unroll
       for (int kk = 0; kk < DBK / 32; ++kk) {
         bf16x8 fa[4], fw[6];
@@ -454,18 +456,18 @@ __global__ __launch_bounds__(128 * WNW, 2) void gemm_ln_residual_bf16_dma_kernel
   }
 }
 
-template <int WNW, int RING, int DBK = 32>
+template <int WNW, int RING, int DBK = 32, int WM = 2>
 int launch_ln_dma(hipStream_t s, const u16* A, int lda, const u16* W, const float* bias, const u16* shortcut, const float* gamma,
                   const float* beta, u16* out, int ldo, int M, int K) {
-  constexpr int BN = 96 * WNW;
-  const int m_tiles = (M + LBM - 1) / LBM;
-  const size_t shm = (size_t)RING * (LBM + BN) * (DBK * 2) + (size_t)2 * WNW * 16 * (96 * 2 + 16) + (size_t)3 * BN * sizeof(float);
-  auto kern = gemm_ln_residual_bf16_dma_kernel<WNW, RING, DBK>;
+  constexpr int BN = 96 * WNW, TBM = 64 * WM, NW = WM * WNW;
+  const int m_tiles = (M + TBM - 1) / TBM;
+  const size_t shm = (size_t)RING * (TBM + BN) * (DBK * 2) + (size_t)NW * 16 * (96 * 2 + 16) + (size_t)3 * BN * sizeof(float);
+  auto kern = gemm_ln_residual_bf16_dma_kernel<WNW, RING, DBK, WM>;
   PANGU_ENSURE_DYN_LDS(kern, shm);
-  const int per_cu = (int)(160 * 1024 / shm) < 1 ? 1 : (int)(160 * 1024 / shm);      // N = 384: one 8-wave workgroup per CU; N = 192: two 4-wave
+  const int per_cu = (int)(160 * 1024 / shm) < 1 ? 1 : (int)(160 * 1024 / shm);
   int grid = 256 * (per_cu > 2 ? 2 : per_cu);
   if (grid > m_tiles) grid = m_tiles;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WNW), shm, s, A, lda, W, bias, shortcut, gamma, beta, out, ldo, M, K, m_tiles);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), shm, s, A, lda, W, bias, shortcut, gamma, beta, out, ldo, M, K, m_tiles);
   return pangu_launch_status();
 }
 
@@ -494,9 +496,13 @@ extern "C" int pangu_linear_ln_residual_fwd_bf16(pangu_stream_t stream, const vo
   if (N != 192 && N != 384) return PANGU_E_SHAPE;          // the tile must span the whole row
   hipStream_t s = (hipStream_t)stream;
   // the persistent LDS-DMA kernel: K a multiple of 32 and at least three K-steps, dense A rows addressable through the scalar offset
+  // N = 384: always (bit 0).  N = 192: the 256-row-tile form where the K-loop is long enough to pay (K >= 384: -7 % at K = 768; at
+  // K = 192 -- the forward's launch -- it measured level with the register-staged kernel, which then stays); bit 1 forces it.
   const bool dma = PANGU_GEMM_LN_DMA && K % 32 == 0 && K >= 96 && pangu_fits_u32(M, lda, 2) &&
-                   (N == 384 ? (PANGU_GEMM_LN_DMA & 1) : (PANGU_GEMM_LN_DMA & 2));
+                   (N == 384 ? (PANGU_GEMM_LN_DMA & 1) : ((PANGU_GEMM_LN_DMA & 2) || K >= 384));
   if (N == 192) {
+    if (dma && K % 64 == 0 && K >= 192)      // 256 x 192 tiles, one 8-wave workgroup per CU, K-steps of 64, ring of two
+      return launch_ln_dma<2, 2, 64, 4>(s, (const u16*)A, lda, (const u16*)W, bias, (const u16*)shortcut, gamma, beta, (u16*)out, ldo, M, K);
     if (dma) return launch_ln_dma<2, 3>(s, (const u16*)A, lda, (const u16*)W, bias, (const u16*)shortcut, gamma, beta, (u16*)out, ldo, M, K);
     return launch_ln<2>(s, (const u16*)A, lda, (const u16*)W, bias, (const u16*)shortcut, gamma, beta, (u16*)out, ldo, M, K);
   }
