@@ -242,7 +242,17 @@ class DevicePrefetcher:
         try:
             while True:
                 t0 = time.perf_counter()
-                item = q.get()
+                while True:                   # never block forever on a worker that died without posting its end marker
+                    try:
+                        item = q.get(timeout=1.0)
+                        break
+                    except queue.Empty:
+                        if not th.is_alive():
+                            try:
+                                item = q.get_nowait()
+                                break
+                            except queue.Empty:
+                                raise RuntimeError("DevicePrefetcher: the staging thread ended without delivering a batch or its end marker")
                 self.stats["consumer_wait_s"] += time.perf_counter() - t0
                 if item is _END:
                     return

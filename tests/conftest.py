@@ -13,6 +13,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # (pytest-timeout registers this marker itself when installed -- it is in this image; declared here so that a box without the
+    # plugin collects the threaded-pipeline tests instead of failing on an unknown marker)
+    config.addinivalue_line("markers", "timeout(seconds): per-test limit of the threaded input-pipeline tests (pytest-timeout)")
 
 
 @pytest.fixture(scope="session")

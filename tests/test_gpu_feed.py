@@ -205,6 +205,7 @@ class _Filler:
         return True
 
 
+@pytest.mark.timeout(300)
 @pytest.mark.parametrize("threaded", [True, False])
 def test_device_prefetcher_pipeline_semantics(P, threaded):
     """data.DevicePrefetcher: order and values over more batches than slots (buffer reuse), non-tensor items passed through, the
@@ -272,6 +273,7 @@ def _host_batches(n, ascending):
     return out
 
 
+@pytest.mark.timeout(600)
 def test_training_step_fed_from_host_full_size(P):
     """the bf16 training step fed from PAGEABLE full-size host batches (573 MB per step, three distinct samples
     in file level order) through data.DevicePrefetcher(fuse_flip=True) with the reference's per-step `loss.item()`
