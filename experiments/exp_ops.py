@@ -25,7 +25,8 @@ _handle = None
 def load():
     global _handle
     if _handle is None:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpangu_experiments.so")
+        # PANGU_EXP_LIB: an ablation build of this library (experiments/tools/ablate_mlp_f32.sh)
+        path = os.environ.get("PANGU_EXP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpangu_experiments.so")
         if not os.path.exists(path):
             raise RuntimeError(f"{path} not found: run `make -C experiments`")
         _lib.load()
