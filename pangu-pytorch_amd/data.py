@@ -70,7 +70,8 @@ class DevicePrefetcher:
     reuse_device_buffers   True: the device tensors of a batch are `depth + 3` STATIC buffer sets filled in turn (no allocator traffic
                   in the loop: a fresh 270 MB block per field and step can mean a synchronous hipMalloc when the caching allocator's
                   pool is fragmented) -- a yielded batch is valid until the consumer asks for the NEXT one (an event recorded then
-                  orders the buffer's refill behind the consumer's work on it); keep nothing from a batch across iterations.
+                  orders the buffer's refill behind the consumer's work on it -- work enqueued on the stream that is CURRENT when the next
+                  batch is requested); keep nothing from a batch across iterations.
                   False (default): every batch is freshly allocated and stays valid as long as it is referenced."""
 
     def __init__(self, loader, device, flip_levels=False, depth=2, fuse_flip=False, threaded=True, copy_threads=None,
