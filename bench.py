@@ -321,7 +321,8 @@ def fed_from_host(model, opt, dev, consts, grad_sync, steps, rank):
     res["fed_over_resident"] = res["fed_item_per_step_ms"] / res["resident_item_per_step_ms"]
     res["bytes_per_step"] = sum(t.numel() * 4 for t in host[0])
     res["host_cpus"] = os.cpu_count()
-    res["note"] = ("ms per training step, DropPath on, three distinct pageable host samples in file (ascending) level order cycled; "
+    res["note"] = ("ms per training step, DropPath on with the SAME draws in all four loops (their own seed: compare the four numbers with each "
+                   "other, not with the section's ms_per_step), three distinct pageable host samples in file (ascending) level order cycled; "
                    "needed host->device rate = bytes_per_step / step time; pipeline.host_stage_GBps is the page-locked staging copy "
                    "(pangu_host_copy, pipeline.copy_threads threads), pipeline.h2d_GBps the copy engine, consumer_wait what the training "
                    "thread waited for batches (both fed loops)")
