@@ -120,3 +120,19 @@ def test_closed_form_fragment_addresses_of_attn_tile():
             pad = lambda d, key: d * 336 + key * 2                  # vt_off<false>
             for u in range(4):
                 assert pad(dt * 16 + lq, 8 * lg) + 64 * u == pad(dt * 16 + lq, 32 * u + 8 * lg)
+
+
+@pytest.mark.parametrize("base", [0, 64, 128, 128 + 96, 128 + 288])
+def test_gemm_ln_bf16_ring_images_conflict_free(base):
+    """Round 6, csrc/gemm_ln_bf16.hip: the operand ring of the persistent projection + LayerNorm kernel.  K-steps of 32 channels:
+    64-byte rows, chunk ^ F[(row >> 2) & 3] (`kswz64`); K-steps of 64: 128-byte rows, chunk ^ ((row >> 1) & 7) (`swz`).  A fragment
+    read = 16 consecutive rows (lane & 15) x one 16-B chunk per 16-lane group: conflict-free under the real ds_read_b128 lane groups
+    for every wave tile's base row; the DMA fills whole 1-KB runs linearly (the swizzle is on the source side)."""
+    kswz64 = lambda row, chunk: row * 64 + ((chunk ^ F[(row >> 2) & 3]) << 4)
+    swz = lambda row, chunk: row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)
+    assert conflict_free("read_b128", lambda l: kswz64(base + (l & 15), l >> 4))
+    for kk in range(2):
+        assert conflict_free("read_b128", lambda l: swz(base + (l & 15), kk * 4 + (l >> 4)))
+    # the images are bijective over a stage's rows
+    assert len({kswz64(r, c) for r in range(512) for c in range(4)}) == 2048
+    assert len({swz(r, c) for r in range(512) for c in range(8)}) == 4096
