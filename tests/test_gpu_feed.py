@@ -325,3 +325,42 @@ def test_training_step_fed_from_host_full_size(P):
     assert l_fed[0] == l_res[0], (l_fed, l_res)
     assert all(abs(a - b) <= 1e-5 * abs(b) for a, b in zip(l_fed, l_res)), (l_fed, l_res)
     assert ms_fed <= 1.15 * ms_res, (ms_fed, ms_res, summ)
+
+
+def test_train_step_with_physical_targets_in_file_order(P):
+    """The reference's loop body as it is written (models/pangu_sample.py:52-71): targets arrive in PHYSICAL units and are normalised
+    inside the step (`normData`, :57), and the reader has reversed the level axis (era5_data/utils_data.py:117).  train_step with
+    `stats_last` + `levels_reversed` on fields in file order == train_step on fields flipped and normalised beforehand: the loss bit
+    for bit (the fold changes no rounding), every parameter gradient to the run-to-run spread of the backward's atomics, and the
+    updated parameters within one Adam step of each other."""
+    from pangu_pytorch_amd import train
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    m = P.PanguModel(device=dev).to(dev)
+    m.set_compute_dtype(torch.bfloat16)
+    state0 = {k: v.clone() for k, v in m.state_dict().items()}
+    inp, inp_s, stats, maps, const_h = cases.model_inputs("cuda")
+    g = lambda n, s, sc, sh: synth.uniform(s, synth.name_seed(n), sc, sh, device="cuda")
+    tgt_phys, tgt_s_phys = g("tp", (1, 5, 13, 721, 1440), 40.0, 250.0), g("tsp", (1, 4, 721, 1440), 500.0, 1e5)
+    sl = (g("slm", (1, 4, 1, 1), 300.0, 1e5), g("sls", (1, 4, 1, 1), 100.0, 700.0), g("ulm", (1, 5, 13, 1, 1), 20.0, 250.0),
+          g("uls", (1, 5, 13, 1, 1), 5.0, 30.0))
+    tgt_n, tgt_s_n = train.norm_data(tgt_phys, tgt_s_phys, sl)
+
+    def run(batch, **kw):
+        m.load_state_dict(state0)
+        m.train()
+        opt = train.make_optimizer(m)
+        torch.manual_seed(5)
+        loss = train.train_step(m, opt, batch, stats, maps, const_h, **kw)
+        return loss.item(), [p.detach().clone() for p in m.parameters()], [None if p.grad is None else p.grad.detach().clone() for p in m.parameters()]
+
+    l_ref, p_ref, g_ref = run((inp, inp_s, tgt_n, tgt_s_n))
+    l_new, p_new, g_new = run((inp.flip(-3).contiguous(), inp_s, tgt_phys.flip(-3).contiguous(), tgt_s_phys), stats_last=sl,
+                              levels_reversed=True)
+    assert l_new == l_ref, (l_new, l_ref)
+    assert [a is None for a in g_new] == [b is None for b in g_ref]                    # the same DropPath draws: the same dropped branches
+    worst = max(((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item() for a, b in zip(g_new, g_ref) if b is not None)
+    assert worst < 1e-4, worst
+    # (an Adam step moves every element by at most ~lr = 5e-6: a gradient element whose sign sits inside the atomics' noise may move the
+    # other way)
+    assert max(float((a - b).abs().max()) for a, b in zip(p_new, p_ref)) <= 2.5e-5
